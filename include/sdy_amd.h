@@ -1,0 +1,199 @@
+/*
+ * sdy_amd.h -- C ABI of the MI355X-native Spherical-DYffusion sampling path.
+ *
+ * The reference (Rose-STL-Lab/spherical-dyffusion) is 100 % Python and has no FFI boundary for this path;
+ * the objects this library replaces are Python callables.  Each entry point below cites the reference
+ * interface it stands in for (file:line under the reference root).  INTEGRATION.md shows the ctypes stub a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device (HBM) pointer; "host" pointers are ordinary host memory
+ *   - all tensors are contiguous fp32; grid-space activations are NCHW = (B, C, nlat, nlon)
+ *   - every function returns SDY_OK (0), a negative SDY_ERR_* for a bad argument, or a positive hipError_t
+ *   - nothing here synchronises the device, allocates in a launch path, or throws; work is enqueued on the
+ *     given stream (a hipStream_t passed as void*), so calls are graph-capturable
+ *   - workspaces are supplied by the caller (PyTorch caching allocator on the Python side)
+ *
+ * Internal spectral layouts (fp32):
+ *   grid-frequency  Xf[m][k][b][ri][c]   m < mtr = min(mmax, lmax), k < nlat, ri in {re, im}
+ *   coefficients    Cs[l][m][b][ri][c]   l < lmax, m < mtr; entries with m > l are never read or written
+ *
+ * Dropout stream (the reference uses torch's global generator: src/models/sfno/layers.py:76-78,
+ * src/models/modules/drop_path.py:19 -- not reproducible across devices, so the product defines its own):
+ *   Philox4x32-10, key = (seed_lo, seed_hi), counter = (c0, c1, stream, call)
+ *     element dropout : c0 = pixel (h*nlon + w), c1 = b_global*(C/4) + (ch>>2), word = ch & 3,
+ *                       stream = 2*layer + kind (kind 0 = MLP hidden, 1 = MLP output)
+ *     drop path       : c0 = b_global, c1 = 0xFFFFFFFF, stream = 0x1000 + layer, word 0
+ *   keep <=> word >= floor(p * 2^32);  kept values are scaled by 1/(1-p).
+ */
+#ifndef SDY_AMD_H
+#define SDY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDY_OK 0
+#define SDY_ERR_ARG (-1)         /* null pointer / non-positive extent */
+#define SDY_ERR_UNSUPPORTED (-2) /* size the kernels do not cover (e.g. nlon with a prime factor > 5) */
+#define SDY_ERR_ALIGN (-3)       /* extent along a contiguous dimension not a multiple of 4 */
+#define SDY_ERR_WORKSPACE (-4)   /* workspace too small */
+#define SDY_ERR_NAME (-5)        /* unknown parameter name */
+#define SDY_ERR_SHAPE (-6)       /* parameter has the wrong number of elements */
+#define SDY_ERR_STATE (-7)       /* object not fully initialised (missing parameters) */
+
+#define SDY_GRID_EQUIANGULAR 0
+#define SDY_GRID_LEGENDRE_GAUSS 1
+
+int sdy_version(void);
+const char* sdy_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Spherical-harmonic transform plan.
+ * Replaces torch_harmonics.RealSHT / InverseRealSHT construction (third-party, un-vendored; reference call
+ * sites src/models/sfno/sfnonet.py:551-554; attributes read at src/models/sfno/s2convolutions.py:73-83).
+ * One plan holds the forward (quadrature-weighted) and inverse Legendre tables of one grid, in fp32 on the
+ * device (computed in fp64 on the host, cast like `.float()` at sfnonet.py:551-554), plus FFT twiddles. */
+typedef struct sdy_sht_plan sdy_sht_plan;
+
+/* Host-only: fp64 tables exactly as torch_harmonics builds them.  pct: [mmax][lmax][nlat], w: [nlat]
+ * quadrature weights, theta: [nlat] colatitudes (any may be NULL).  No GPU needed. */
+int sdy_sht_tables_host(int nlat, int nlon, int lmax, int mmax, int grid, double* pct, double* w, double* theta);
+
+int sdy_sht_plan_create(int nlat, int nlon, int lmax, int mmax, int grid, sdy_sht_plan** out);
+void sdy_sht_plan_destroy(sdy_sht_plan* plan);
+/* dims[0..5] = nlat, nlon, lmax, mmax, mtr, grid */
+int sdy_sht_plan_dims(const sdy_sht_plan* plan, int dims[6]);
+/* floats needed by sdy_sht_forward / sdy_sht_inverse for B*C fields */
+size_t sdy_sht_workspace_floats(const sdy_sht_plan* plan, int B, int C);
+
+/* RealSHT.forward (torch_harmonics; called at src/models/sfno/s2convolutions.py:165):
+ * x dev (B,C,nlat,nlon) f32 -> out dev (B,C,lmax,mmax) complex64 (re,im interleaved). C % 4 == 0. */
+int sdy_sht_forward(const sdy_sht_plan* plan, const float* x, float* out_c64, int B, int C, float* ws,
+                    size_t ws_floats, void* stream);
+/* InverseRealSHT.forward (called at src/models/sfno/s2convolutions.py:168,186):
+ * in dev (B,C,lmax,mmax) complex64 -> y dev (B,C,nlat,nlon) f32. */
+int sdy_sht_inverse(const sdy_sht_plan* plan, const float* in_c64, float* y, int B, int C, float* ws,
+                    size_t ws_floats, void* stream);
+
+/* Stage-level entry points on the internal layouts (what the fused network path launches). */
+/* longitude real FFT x (2*pi/nlon) fused with the per-(b,c) affine a*x+d of InstanceNorm + time scale/shift
+ * (src/models/sfno/sfnonet.py:292,298-299).  a, d: dev [B*C] or NULL.  xn_out: dev (B,C,nlat,nlon) or NULL. */
+int sdy_rfft_lon(const sdy_sht_plan* plan, const float* x, const float* a, const float* d, float* xn_out,
+                 float* Xf, int B, int C, void* stream);
+/* Legendre analysis: Cs[l][m][n] = sum_k Wq[m][l][k] Xf[m][k][n]  (einsum '...km,mlk->...lm') */
+int sdy_legendre_fwd(const sdy_sht_plan* plan, const float* Xf, float* Cs, int B, int C, void* stream);
+/* Legendre synthesis: Yf[m][k][n] = sum_l P[m][l][k] Cs[l][m][n]  (einsum '...lm,mlk->...km') */
+int sdy_legendre_inv(const sdy_sht_plan* plan, const float* Cs, float* Yf, int B, int C, void* stream);
+/* inverse longitude FFT (irfft n=nlon, norm="forward") + optional per-channel bias (s2convolutions.py:188-189) */
+int sdy_irfft_lon(const sdy_sht_plan* plan, const float* Yf, const float* bias, float* y, int B, int C,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * _contract_dhconv (src/models/sfno/contractions.py:159-169 via factorizations.py:165-186; called at
+ * src/models/sfno/s2convolutions.py:173-178):  out[b,o,l,m] = sum_i x[b,i,l,m] * w[i,o,l]  (complex).
+ * sdy_dhconv_pack_weight: host (Ci,Co,L,2) reference layout -> dev packed [l][2][Ci][Co].
+ * sdy_dhconv: Cs_in / Cs_out in the coefficient layout above (channel counts Ci / Co, both % 4 == 0). */
+int sdy_dhconv_pack_weight(const float* w_host, int Ci, int Co, int L, float* w_packed_dev, void* stream);
+int sdy_dhconv(const float* Cs_in, const float* w_packed, float* Cs_out, int L, int mtr, int B, int Ci, int Co,
+               void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * nn.InstanceNorm2d(C, eps, affine=True, track_running_stats=False) statistics folded with the block's time
+ * scale/shift (src/models/sfno/sfnonet.py:280-299,641-648) into per-(b,c) coefficients:
+ *   xn = a*x + d,  a = gamma*rstd*(1+scale),  d = (beta - mean*gamma*rstd)*(1+scale) + shift
+ * scale_shift: dev, element (b, j) at scale_shift[b*ss_stride + j], j < 2C (scale | shift), or NULL. */
+int sdy_instnorm_coeffs(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
+                        const float* scale_shift, long ss_stride, float eps, float* a, float* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 1x1 convolution = per-pixel GEMM with fused prologue/epilogue.  Replaces nn.Conv2d(k=1) + bias + GELU +
+ * Dropout + DropPath + residual adds of src/models/sfno/sfnonet.py:303-335,609-618,734-744 and
+ * src/models/sfno/layers.py:73-80.
+ *   out[b,o,p] = post( act( sum_i wt[i,o] * (pa[b,i]*x[b,i,p] + pd[b,i]) + bias[o] + add_pre[b,o,p] ) )
+ *   post(v)    = batch_scale[b] * dropout(v) + add_post[b,o,p]
+ * wt is the TRANSPOSED weight, dev [Cin][ldw] (ldw >= Cout, ldw % 4 == 0, columns >= Cout zero). */
+typedef struct sdy_conv_args {
+  const float* x;  long x_bstride;   /* dev (B, >=Cin, HW) ; batch stride in floats */
+  const float* wt; int ldw;          /* dev [Cin][ldw] */
+  float* out;      long out_bstride; /* dev (B, >=Cout, HW) */
+  int B, Cin, Cout, HW;
+  const float* pa; const float* pd;  /* dev [B*Cin] each or NULL (prologue affine) */
+  const float* bias;                 /* dev [Cout] or NULL */
+  const float* add; long add_bstride;/* dev (B or 1, Cout, HW) or NULL; add_bstride 0 broadcasts over b */
+  int add_mode;                      /* 0 none, 1 before activation, 2 after dropout/batch_scale */
+  int act;                           /* 0 none, 1 exact-erf GELU */
+  float drop_p;                      /* 0 = no dropout */
+  const float* keep_mask;            /* dev (B,Cout,HW) 0/1 injected mask (tests) or NULL = Philox stream */
+  uint64_t seed; uint32_t call; uint32_t stream_id; uint32_t batch_offset;
+  const float* batch_scale;          /* dev [B] or NULL (drop-path scale) */
+} sdy_conv_args;
+int sdy_conv1x1(const sdy_conv_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Whole network.  Replaces SphericalFourierNeuralOperatorNet.__init__/forward
+ * (src/models/sfno/sfnonet.py:426-841) + BaseModel.concat_condition_if_needed (src/models/_base_model.py:166-192)
+ * for the configuration the shipped YAML selects (filter_type=linear, operator_type=dhconv, factorization=None,
+ * instance_norm, use_mlp, pos_embed, big_skip, scale_factor=1, encoder_layers=1). */
+typedef struct sdy_sfno_config {
+  int nlat, nlon;
+  int in_chans;        /* inputs + conditional channels, as the encoder sees them */
+  int out_chans;
+  int embed_dim;
+  int num_layers;
+  int mlp_hidden;      /* int(embed_dim * mlp_ratio) */
+  int lmax, mmax;      /* modes_lat, modes_lon (sfnonet.py:526-527) */
+  int data_grid;       /* SDY_GRID_* of the first forward / last inverse transform */
+  int with_time_emb;
+  int time_dim;        /* embed_dim * time_dim_mult */
+  float dropout_mlp;   /* MLP dropout rate (active only when a forward call enables dropout) */
+  float drop_path_rate;
+  int big_skip, pos_embed;
+} sdy_sfno_config;
+
+typedef struct sdy_sfno sdy_sfno;
+int sdy_sfno_create(const sdy_sfno_config* cfg, sdy_sfno** out);
+void sdy_sfno_destroy(sdy_sfno* net);
+/* Load one tensor by its reference state_dict name, host fp32, `numel` elements.
+ * The library re-lays it out for the kernels.  Names of non-persistent SHT buffers are accepted and ignored. */
+int sdy_sfno_set_param(sdy_sfno* net, const char* name, const float* host, size_t numel);
+/* 0 when every required parameter has been set; otherwise SDY_ERR_STATE (missing name via sdy_sfno_missing). */
+int sdy_sfno_ready(const sdy_sfno* net);
+const char* sdy_sfno_missing(const sdy_sfno* net);
+size_t sdy_sfno_workspace_floats(const sdy_sfno* net, int B);
+
+typedef struct sdy_sfno_fwd_args {
+  /* up to three channel groups concatenated on dim 1 (inputs | condition | static_condition) */
+  const float* in[3]; int in_chans[3];   /* dev (B, in_chans[i], nlat, nlon); unused slots NULL / 0 */
+  const float* time;                     /* dev [B] or NULL when !with_time_emb */
+  float* out;                            /* dev (B, out_chans, nlat, nlon) */
+  int B;
+  int enable_dropout;                    /* inference_dropout_scope (src/models/_base_model.py:273-286) */
+  uint64_t seed; uint32_t call; uint32_t batch_offset;
+  const float* const* keep_masks;        /* optional injected masks (tests): [num_layers*2] dev pointers
+                                            (hidden, out) per layer, or NULL */
+  const float* drop_path_keep;           /* optional injected drop-path keep flags, dev [num_layers][B], or NULL */
+  float* ws; size_t ws_floats;
+} sdy_sfno_fwd_args;
+int sdy_sfno_forward(sdy_sfno* net, const sdy_sfno_fwd_args* args, void* stream);
+
+/* Debug/parity taps: time embedding + per-block (scale|shift) as the network computes them.
+ * t_repr dev [B*time_dim] (or NULL), ss dev [B*num_layers*2*embed_dim] (or NULL). */
+int sdy_sfno_time_embed(sdy_sfno* net, const float* time, int B, float* t_repr, float* ss, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Sampler arithmetic of BaseDYffusion.sample_loop (src/diffusion/dyffusion.py:517-519, :655-661). */
+/* out = x_s + (x_ip_next - x_ip_s); any of the three may alias out.  x_ip_s NULL means "x_ip_s == x_s" (s = 0). */
+int sdy_cold_update(const float* x_s, const float* x_ip_next, const float* x_ip_s, float* out, size_t n,
+                    void* stream);
+/* channel concat of up to 4 NCHW tensors (torch.cat(dim=1)) */
+int sdy_concat_channels(const float* const* src, const int* chans, int nsrc, float* out, int B, int HW,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDY_AMD_H */

@@ -1,0 +1,82 @@
+"""Oracle: numpy restatement of the product's counter-based dropout stream.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+The reference draws its inference-time dropout / drop-path masks from torch's
+global generator (`nn.Dropout` in `src/models/sfno/layers.py:76-78`,
+`torch.rand` in `src/models/modules/drop_path.py:19`); bitwise reproduction of
+that stream on another device is impossible, so the product defines its own
+stream: Philox4x32-10 (Salmon et al., SC'11; same constants as Random123 /
+cuRAND / torch's CUDA generator), keyed and countered as documented in
+`include/sdy_amd.h` ("Dropout stream").  This file restates it so the parity
+tests can compare the device masks bit for bit.
+
+  key      = (seed_lo, seed_hi)
+  counter  = (c0, c1, stream, call)
+  element dropout (kind 0/1):  c0 = pixel index p (h*W + w)
+                               c1 = b_global * (C/4) + (ch >> 2);  word = ch & 3
+                               stream = 2*layer + kind
+  drop path:                   c0 = b_global, c1 = 0xFFFFFFFF, stream = 0x1000 + layer, word 0
+  keep  <=>  word >= floor(p * 2**32)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+M0 = np.uint64(0xD2511F53)
+M1 = np.uint64(0xCD9E8D57)
+W0 = np.uint32(0x9E3779B9)
+W1 = np.uint32(0xBB67AE85)
+MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10.  All inputs broadcastable uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3))
+    shape = np.broadcast(c0, c1, c2, c3).shape
+    c0, c1, c2, c3 = (np.broadcast_to(c, shape).copy() for c in (c0, c1, c2, c3))
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for r in range(10):
+            p0 = M0 * c0.astype(np.uint64)
+            p1 = M1 * c2.astype(np.uint64)
+            hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
+            lo0 = (p0 & MASK32).astype(np.uint32)
+            hi1 = (p1 >> np.uint64(32)).astype(np.uint32)
+            lo1 = (p1 & MASK32).astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            if r < 9:
+                k0 = np.uint32((int(k0) + int(W0)) & 0xFFFFFFFF)
+                k1 = np.uint32((int(k1) + int(W1)) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def drop_threshold(p: float) -> int:
+    """uint32 threshold: keep <=> word >= threshold.  p is taken at fp32 precision, as the C ABI carries it."""
+    return min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF)
+
+
+def element_keep_mask(seed: int, call: int, layer: int, kind: int, p: float,
+                      B: int, C: int, H: int, W: int, batch_offset: int = 0) -> np.ndarray:
+    """Keep mask (B, C, H, W) of 0/1 float32 for MLP dropout (kind 0 = hidden, 1 = output)."""
+    assert C % 4 == 0
+    thr = np.uint32(drop_threshold(p))
+    pix = np.arange(H * W, dtype=np.uint32)[None, None, :]
+    b = (np.arange(B, dtype=np.uint64) + np.uint64(batch_offset))[:, None, None]
+    g = np.arange(C // 4, dtype=np.uint64)[None, :, None]
+    c1 = ((b * np.uint64(C // 4) + g) & MASK32).astype(np.uint32)
+    words = philox4x32_10(pix, c1, np.uint32(2 * layer + kind), np.uint32(call & 0xFFFFFFFF),
+                          seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    w = np.stack(words, axis=2)  # (B, C/4, 4, HW)
+    keep = (w >= thr).astype(np.float32)
+    return keep.reshape(B, C, H, W)
+
+
+def drop_path_keep(seed: int, call: int, layer: int, p: float, B: int, batch_offset: int = 0) -> np.ndarray:
+    """Keep flags (B,) of 0/1 float32 for drop path of `layer`."""
+    thr = np.uint32(drop_threshold(p))
+    b = ((np.arange(B, dtype=np.uint64) + np.uint64(batch_offset)) & MASK32).astype(np.uint32)
+    w0, _, _, _ = philox4x32_10(b, np.uint32(0xFFFFFFFF), np.uint32(0x1000 + layer),
+                                np.uint32(call & 0xFFFFFFFF), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return (w0 >= thr).astype(np.float32)

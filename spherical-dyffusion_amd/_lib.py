@@ -1,0 +1,132 @@
+"""ctypes binding of libsdy_amd.so (the C ABI declared in include/sdy_amd.h).
+
+The HIP library is the product: there is NO Python/PyTorch fallback for any op.  If the shared object is
+missing the import fails loudly (build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C spherical-dyffusion_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdy_amd.so")
+
+SDY_GRID = {"equiangular": 0, "legendre-gauss": 1}
+
+
+class SdyError(RuntimeError):
+    pass
+
+
+class SdyConvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_bstride", C.c_long),
+        ("wt", C.c_void_p), ("ldw", C.c_int),
+        ("out", C.c_void_p), ("out_bstride", C.c_long),
+        ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("HW", C.c_int),
+        ("pa", C.c_void_p), ("pd", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("add", C.c_void_p), ("add_bstride", C.c_long),
+        ("add_mode", C.c_int),
+        ("act", C.c_int),
+        ("drop_p", C.c_float),
+        ("keep_mask", C.c_void_p),
+        ("seed", C.c_uint64), ("call", C.c_uint32), ("stream_id", C.c_uint32), ("batch_offset", C.c_uint32),
+        ("batch_scale", C.c_void_p),
+    ]
+
+
+class SdySfnoConfig(C.Structure):
+    _fields_ = [
+        ("nlat", C.c_int), ("nlon", C.c_int),
+        ("in_chans", C.c_int), ("out_chans", C.c_int),
+        ("embed_dim", C.c_int), ("num_layers", C.c_int), ("mlp_hidden", C.c_int),
+        ("lmax", C.c_int), ("mmax", C.c_int),
+        ("data_grid", C.c_int),
+        ("with_time_emb", C.c_int), ("time_dim", C.c_int),
+        ("dropout_mlp", C.c_float), ("drop_path_rate", C.c_float),
+        ("big_skip", C.c_int), ("pos_embed", C.c_int),
+    ]
+
+
+class SdySfnoFwdArgs(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p * 3), ("in_chans", C.c_int * 3),
+        ("time", C.c_void_p),
+        ("out", C.c_void_p),
+        ("B", C.c_int),
+        ("enable_dropout", C.c_int),
+        ("seed", C.c_uint64), ("call", C.c_uint32), ("batch_offset", C.c_uint32),
+        ("keep_masks", C.POINTER(C.c_void_p)),
+        ("drop_path_keep", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_floats", C.c_size_t),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/sdy_amd.h declares
+SIGNATURES = {
+    "sdy_version": (C.c_int, []),
+    "sdy_error_string": (C.c_char_p, [C.c_int]),
+    "sdy_sht_tables_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdy_sht_plan_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sdy_sht_plan_destroy": (None, [C.c_void_p]),
+    "sdy_sht_plan_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int * 6)]),
+    "sdy_sht_workspace_floats": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "sdy_sht_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdy_sht_inverse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdy_rfft_lon": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sdy_legendre_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sdy_legendre_inv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sdy_irfft_lon": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sdy_dhconv_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sdy_dhconv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sdy_instnorm_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdy_conv1x1": (C.c_int, [C.POINTER(SdyConvArgs), C.c_void_p]),
+    "sdy_sfno_create": (C.c_int, [C.POINTER(SdySfnoConfig), C.POINTER(C.c_void_p)]),
+    "sdy_sfno_destroy": (None, [C.c_void_p]),
+    "sdy_sfno_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "sdy_sfno_ready": (C.c_int, [C.c_void_p]),
+    "sdy_sfno_missing": (C.c_char_p, [C.c_void_p]),
+    "sdy_sfno_workspace_floats": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "sdy_sfno_forward": (C.c_int, [C.c_void_p, C.POINTER(SdySfnoFwdArgs), C.c_void_p]),
+    "sdy_sfno_time_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdy_cold_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdy_concat_channels": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_void_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP library is required (no CPU/PyTorch fallback exists). "
+            "Build it with `make -C spherical-dyffusion_amd/csrc` or `__graft_entry__.build()`."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.sdy_error_string(rc).decode()
+        raise SdyError(f"{what or 'sdy call'} failed with code {rc}: {msg}")
+
+
+def ptr(t) -> int:
+    """Device/host pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,667 @@
+// extern "C" boundary (include/sdy_amd.h): SHT plan, stage launchers, 1x1-conv GEMM, the SFNO network object and
+// the sampler arithmetic.  Host orchestration only -- every kernel lives in gemm.hip / fft.hip / pointwise.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "fft.h"
+#include "pointwise.h"
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+extern "C" int sdy_version(void) { return 100; }
+
+extern "C" const char* sdy_error_string(int code) {
+  switch (code) {
+    case SDY_OK: return "ok";
+    case SDY_ERR_ARG: return "bad argument (null pointer or non-positive extent)";
+    case SDY_ERR_UNSUPPORTED: return "unsupported size/configuration";
+    case SDY_ERR_ALIGN: return "extent along a contiguous dimension is not a multiple of 4";
+    case SDY_ERR_WORKSPACE: return "workspace too small";
+    case SDY_ERR_NAME: return "unknown parameter name";
+    case SDY_ERR_SHAPE: return "parameter has the wrong number of elements";
+    case SDY_ERR_STATE: return "object not fully initialised";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+// =========================================================================================================
+// SHT plan
+// =========================================================================================================
+struct sdy_sht_plan {
+  int nlat, nlon, lmax, mmax, mtr, grid;
+  int Lpad4, Kpad4;
+  float* d_wqT = nullptr;  // [mtr][nlat][Lpad4]   forward table, quadrature-weighted, l contiguous
+  float* d_pct = nullptr;  // [mtr][lmax][Kpad4]   inverse table, k contiguous
+  float* d_tw = nullptr;
+  float* d_pw = nullptr;
+  SdyFftDesc fft;
+};
+
+extern "C" int sdy_sht_plan_create(int nlat, int nlon, int lmax, int mmax, int grid, sdy_sht_plan** out) {
+  if (!out || nlat < 2 || nlon < 4 || lmax < 1 || mmax < 1) return SDY_ERR_ARG;
+  if (nlon % 4) return SDY_ERR_ALIGN;
+  if (mmax > nlon / 2 + 1) return SDY_ERR_ARG;
+  if (grid != SDY_GRID_EQUIANGULAR && grid != SDY_GRID_LEGENDRE_GAUSS) return SDY_ERR_ARG;
+  sdy_sht_plan* p = new sdy_sht_plan();
+  p->nlat = nlat; p->nlon = nlon; p->lmax = lmax; p->mmax = mmax; p->grid = grid;
+  p->mtr = mmax < lmax ? mmax : lmax;  // columns m >= lmax are identically zero
+  p->Lpad4 = round_up(lmax, 4);
+  p->Kpad4 = round_up(nlat, 4);
+  const int n = nlon / 2;
+  p->fft.n = n;
+  p->fft.S = (n + 1) | 1;
+  int r = sdy_factor_radices(n, p->fft.radices, &p->fft.nstages);
+  if (r != SDY_OK) { delete p; return r; }
+  if ((size_t)(4 * 16 * p->fft.S + 4 * n + 2) * sizeof(float) > 64 * 1024) { delete p; return SDY_ERR_UNSUPPORTED; }
+
+  // fp64 tables on the host, cast to fp32 like `.float()` (src/models/sfno/sfnonet.py:551-554)
+  std::vector<double> pct((size_t)mmax * lmax * nlat), w(nlat);
+  r = sdy_sht_tables_host(nlat, nlon, lmax, mmax, grid, pct.data(), w.data(), nullptr);
+  if (r != SDY_OK) { delete p; return r; }
+  const int mtr = p->mtr;
+  std::vector<float> wqT((size_t)mtr * nlat * p->Lpad4, 0.0f), pf((size_t)mtr * lmax * p->Kpad4, 0.0f);
+  for (int m = 0; m < mtr; ++m)
+    for (int l = 0; l < lmax; ++l)
+      for (int k = 0; k < nlat; ++k) {
+        const double v = pct[((size_t)m * lmax + l) * nlat + k];
+        // reference casts the fp64 product pct*w to fp32 (weights buffer), and pct to fp32 (pct buffer)
+        wqT[((size_t)m * nlat + k) * p->Lpad4 + l] = (float)(v * w[k]);
+        pf[((size_t)m * lmax + l) * p->Kpad4 + k] = (float)v;
+      }
+  std::vector<float> tw(2 * (size_t)n), pw(2 * (size_t)(n + 1));
+  for (int j = 0; j < n; ++j) {
+    const double a = -2.0 * M_PI * j / n;
+    tw[2 * j] = (float)std::cos(a);
+    tw[2 * j + 1] = (float)std::sin(a);
+  }
+  for (int m = 0; m <= n; ++m) {
+    const double a = -2.0 * M_PI * m / nlon;
+    pw[2 * m] = (float)std::cos(a);
+    pw[2 * m + 1] = (float)std::sin(a);
+  }
+  hipError_t e;
+#define PLAN_UP(dst, vec)                                                                         \
+  e = hipMalloc((void**)&(dst), (vec).size() * sizeof(float));                                    \
+  if (e == hipSuccess) e = hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(float), hipMemcpyHostToDevice); \
+  if (e != hipSuccess) { sdy_sht_plan_destroy(p); return (int)e; }
+  PLAN_UP(p->d_wqT, wqT)
+  PLAN_UP(p->d_pct, pf)
+  PLAN_UP(p->d_tw, tw)
+  PLAN_UP(p->d_pw, pw)
+#undef PLAN_UP
+  p->fft.tw = p->d_tw;
+  p->fft.pw = p->d_pw;
+  *out = p;
+  return SDY_OK;
+}
+
+extern "C" void sdy_sht_plan_destroy(sdy_sht_plan* p) {
+  if (!p) return;
+  if (p->d_wqT) (void)hipFree(p->d_wqT);
+  if (p->d_pct) (void)hipFree(p->d_pct);
+  if (p->d_tw) (void)hipFree(p->d_tw);
+  if (p->d_pw) (void)hipFree(p->d_pw);
+  delete p;
+}
+
+extern "C" int sdy_sht_plan_dims(const sdy_sht_plan* p, int dims[6]) {
+  if (!p || !dims) return SDY_ERR_ARG;
+  dims[0] = p->nlat; dims[1] = p->nlon; dims[2] = p->lmax; dims[3] = p->mmax; dims[4] = p->mtr; dims[5] = p->grid;
+  return SDY_OK;
+}
+
+static inline size_t xf_floats(const sdy_sht_plan* p, int B, int C) { return (size_t)p->mtr * p->nlat * B * 2 * C; }
+static inline size_t cs_floats(const sdy_sht_plan* p, int B, int C) { return (size_t)p->lmax * p->mtr * B * 2 * C; }
+
+extern "C" size_t sdy_sht_workspace_floats(const sdy_sht_plan* p, int B, int C) {
+  if (!p || B <= 0 || C <= 0) return 0;
+  return round_up_sz(xf_floats(p, B, C), 64) + round_up_sz(cs_floats(p, B, C), 64);
+}
+
+extern "C" int sdy_rfft_lon(const sdy_sht_plan* p, const float* x, const float* a, const float* d, float* xn_out,
+                            float* Xf, int B, int C, void* stream) {
+  if (!p || !x || !Xf || B <= 0 || C <= 0) return SDY_ERR_ARG;
+  if ((a == nullptr) != (d == nullptr)) return SDY_ERR_ARG;
+  return sdy_fft_launch_fwd(p->fft, x, a, d, xn_out, Xf, B, C, p->nlat, p->mtr, (hipStream_t)stream);
+}
+
+extern "C" int sdy_irfft_lon(const sdy_sht_plan* p, const float* Yf, const float* bias, float* y, int B, int C,
+                             void* stream) {
+  if (!p || !Yf || !y || B <= 0 || C <= 0) return SDY_ERR_ARG;
+  return sdy_fft_launch_inv(p->fft, Yf, bias, y, B, C, p->nlat, p->mtr, (hipStream_t)stream);
+}
+
+extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, void* stream) {
+  if (!p || !Xf || !Cs || B <= 0 || C <= 0) return SDY_ERR_ARG;
+  if (C & 1) return SDY_ERR_ALIGN;
+  const int N = 2 * B * C;
+  GemmParams g{};
+  g.A = p->d_wqT; g.lda = p->Lpad4; g.sA = (long)p->nlat * p->Lpad4;
+  g.B = Xf; g.ldb = N; g.sB = (long)p->nlat * N;
+  g.C = Cs; g.ldc = p->mtr * N; g.sC = N;
+  g.M = p->Lpad4; g.M_store = p->lmax; g.N = N; g.K = p->nlat; g.nbatch = p->mtr;
+  g.tri_mode = SDY_TRI_LEG_FWD; g.tile = SDY_TILE_64x128;
+  return sdy_gemm_launch(g, (hipStream_t)stream);
+}
+
+extern "C" int sdy_legendre_inv(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, void* stream) {
+  if (!p || !Cs || !Yf || B <= 0 || C <= 0) return SDY_ERR_ARG;
+  if (C & 1) return SDY_ERR_ALIGN;
+  const int N = 2 * B * C;
+  GemmParams g{};
+  g.A = p->d_pct; g.lda = p->Kpad4; g.sA = (long)p->lmax * p->Kpad4;
+  g.B = Cs; g.ldb = p->mtr * N; g.sB = N;
+  g.C = Yf; g.ldc = N; g.sC = (long)p->nlat * N;
+  g.M = p->Kpad4; g.M_store = p->nlat; g.N = N; g.K = p->lmax; g.nbatch = p->mtr;
+  g.tri_mode = SDY_TRI_LEG_INV; g.tile = SDY_TILE_64x128;
+  return sdy_gemm_launch(g, (hipStream_t)stream);
+}
+
+extern "C" int sdy_sht_forward(const sdy_sht_plan* p, const float* x, float* out_c64, int B, int C, float* ws,
+                               size_t ws_floats, void* stream) {
+  if (!p || !x || !out_c64 || !ws) return SDY_ERR_ARG;
+  if (ws_floats < sdy_sht_workspace_floats(p, B, C)) return SDY_ERR_WORKSPACE;
+  float* Xf = ws;
+  float* Cs = ws + round_up_sz(xf_floats(p, B, C), 64);
+  SDY_TRY(sdy_rfft_lon(p, x, nullptr, nullptr, nullptr, Xf, B, C, stream));
+  SDY_TRY(sdy_legendre_fwd(p, Xf, Cs, B, C, stream));
+  return sdy_spec_to_torch_launch(Cs, out_c64, B, C, p->lmax, p->mtr, p->mmax, (hipStream_t)stream);
+}
+
+extern "C" int sdy_sht_inverse(const sdy_sht_plan* p, const float* in_c64, float* y, int B, int C, float* ws,
+                               size_t ws_floats, void* stream) {
+  if (!p || !in_c64 || !y || !ws) return SDY_ERR_ARG;
+  if (ws_floats < sdy_sht_workspace_floats(p, B, C)) return SDY_ERR_WORKSPACE;
+  float* Yf = ws;
+  float* Cs = ws + round_up_sz(xf_floats(p, B, C), 64);
+  SDY_TRY(sdy_torch_to_spec_launch(in_c64, Cs, B, C, p->lmax, p->mtr, p->mmax, (hipStream_t)stream));
+  SDY_TRY(sdy_legendre_inv(p, Cs, Yf, B, C, stream));
+  return sdy_irfft_lon(p, Yf, nullptr, y, B, C, stream);
+}
+
+// =========================================================================================================
+// dhconv
+// =========================================================================================================
+extern "C" int sdy_dhconv_pack_weight(const float* w_host, int Ci, int Co, int L, float* w_packed_dev, void* stream) {
+  if (!w_host || !w_packed_dev || Ci <= 0 || Co <= 0 || L <= 0) return SDY_ERR_ARG;
+  // (Ci, Co, L, 2) -> [l][2][Ci][Co]
+  std::vector<float> packed((size_t)L * 2 * Ci * Co);
+  for (int i = 0; i < Ci; ++i)
+    for (int o = 0; o < Co; ++o)
+      for (int l = 0; l < L; ++l) {
+        const float* s = w_host + (((size_t)i * Co + o) * L + l) * 2;
+        packed[(((size_t)l * 2 + 0) * Ci + i) * Co + o] = s[0];
+        packed[(((size_t)l * 2 + 1) * Ci + i) * Co + o] = s[1];
+      }
+  (void)stream;
+  SDY_HIP_TRY(hipMemcpy(w_packed_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  return SDY_OK;
+}
+
+extern "C" int sdy_dhconv(const float* Cs_in, const float* w_packed, float* Cs_out, int L, int mtr, int B, int Ci,
+                          int Co, void* stream) {
+  if (!Cs_in || !w_packed || !Cs_out || L <= 0 || mtr <= 0 || B <= 0 || Ci <= 0 || Co <= 0) return SDY_ERR_ARG;
+  if ((Ci & 3) || (Co & 3)) return SDY_ERR_ALIGN;
+  GemmParams g{};
+  g.A = Cs_in; g.a_kcontig = 1; g.lda = 2 * Ci; g.sA = (long)mtr * B * 2 * Ci;
+  g.B = w_packed; g.b_cplx = 1; g.cplx_Ei = Ci; g.cplx_Eo = Co; g.ldb = 2 * Co; g.sB = (long)2 * Ci * Co;
+  g.C = Cs_out; g.ldc = 2 * Co; g.sC = (long)mtr * B * 2 * Co;
+  g.M = mtr * B; g.M_store = mtr * B; g.N = 2 * Co; g.K = 2 * Ci; g.nbatch = L;
+  g.tri_mode = SDY_TRI_DHCONV; g.tri_B = B; g.tile = SDY_TILE_64x128;
+  return sdy_gemm_launch(g, (hipStream_t)stream);
+}
+
+// =========================================================================================================
+// InstanceNorm coefficients, 1x1 conv, sampler arithmetic
+// =========================================================================================================
+extern "C" int sdy_instnorm_coeffs(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
+                                   const float* scale_shift, long ss_stride, float eps, float* a, float* d,
+                                   void* stream) {
+  return sdy_instnorm_coeffs_launch(x, B, C, HW, gamma, beta, scale_shift, ss_stride, eps, a, d, (hipStream_t)stream);
+}
+
+extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
+  if (!a || !a->x || !a->wt || !a->out) return SDY_ERR_ARG;
+  if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->HW <= 0 || a->ldw < a->Cout) return SDY_ERR_ARG;
+  if ((a->pa == nullptr) != (a->pd == nullptr)) return SDY_ERR_ARG;
+  if (a->add_mode != 0 && !a->add) return SDY_ERR_ARG;
+  if ((a->ldw & 3) || (a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3)) return SDY_ERR_ALIGN;
+  if (a->drop_p < 0.0f || a->drop_p >= 1.0f) return SDY_ERR_ARG;
+  GemmParams g{};
+  g.A = a->wt; g.lda = a->ldw; g.sA = 0;
+  g.B = a->x; g.ldb = a->HW; g.sB = a->x_bstride;
+  g.C = a->out; g.ldc = a->HW; g.sC = a->out_bstride;
+  g.M = round_up(a->Cout, 4); g.M_store = a->Cout; g.N = a->HW; g.K = a->Cin; g.nbatch = a->B;
+  g.tile = a->Cout > 64 ? SDY_TILE_128x128 : SDY_TILE_64x128;
+  g.pa = a->pa; g.pd = a->pd; g.p_bstride = a->Cin;
+  g.bias = a->bias;
+  g.add = a->add_mode ? a->add : nullptr; g.sAdd = a->add_bstride; g.ldadd = a->HW; g.add_mode = a->add_mode;
+  g.act = a->act;
+  if (a->drop_p > 0.0f) {
+    g.drop_thr = sdy_drop_threshold(a->drop_p);
+    if (g.drop_thr == 0u) g.drop_thr = 1u;
+    g.drop_scale = 1.0f / (1.0f - a->drop_p);
+    g.keep_mask = a->keep_mask;
+  }
+  g.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFu); g.seed_hi = (uint32_t)(a->seed >> 32);
+  g.stream_id = a->stream_id; g.call = a->call; g.batch_offset = a->batch_offset;
+  g.batch_scale = a->batch_scale;
+  return sdy_gemm_launch(g, (hipStream_t)stream);
+}
+
+extern "C" int sdy_cold_update(const float* x_s, const float* x_ip_next, const float* x_ip_s, float* out, size_t n,
+                               void* stream) {
+  return sdy_cold_update_launch(x_s, x_ip_next, x_ip_s, out, n, (hipStream_t)stream);
+}
+
+extern "C" int sdy_concat_channels(const float* const* src, const int* chans, int nsrc, float* out, int B, int HW,
+                                   void* stream) {
+  if (!src || !chans || nsrc < 1 || nsrc > 4) return SDY_ERR_ARG;
+  long total = 0;
+  for (int i = 0; i < nsrc; ++i) total += chans[i];
+  return sdy_concat_launch(src, chans, nsrc, out, total * HW, B, HW, (hipStream_t)stream);
+}
+
+// =========================================================================================================
+// SFNO network object
+// =========================================================================================================
+namespace {
+
+struct DevBuf {
+  float* p = nullptr;
+  size_t n = 0;
+  bool set = false;
+};
+
+struct BlockW {
+  DevBuf n0w, n0b, n1w, n1b;  // [E]
+  DevBuf tw, tb;              // time_mlp: staged into the shared wbt/bb arrays (flags only)
+  DevBuf fw;                  // dhconv packed [l][2][E][E]
+  DevBuf fb;                  // [E]
+  DevBuf skw, skb;            // inner skip: [E][E] transposed, [E]
+  DevBuf w1, b1, w2, b2;      // MLP: [E][hid], [hid], [hid][E], [E]
+};
+
+}  // namespace
+
+struct sdy_sfno {
+  sdy_sfno_config cfg;
+  int HW, catC, decC, ldo;
+  sdy_sht_plan* plan_data = nullptr;  // data grid (first forward / last inverse)
+  sdy_sht_plan* plan_lg = nullptr;    // legendre-gauss (inner transforms); may alias plan_data
+  DevBuf pos, e0w, e0b, e2w, d0w, d0b, d2w;
+  DevBuf t1w, t1b, t3w, t3b, freq, wbt, bb;
+  std::vector<BlockW> blk;
+  SdyTimeMlp tm;
+  std::string missing;
+};
+
+static int dev_alloc(DevBuf& b, size_t n) {
+  if (b.p && b.n == n) return SDY_OK;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  SDY_HIP_TRY(hipMalloc((void**)&b.p, n * sizeof(float)));
+  b.n = n;
+  return SDY_OK;
+}
+static int dev_upload(DevBuf& b, const float* host, size_t n) {
+  SDY_TRY(dev_alloc(b, n));
+  SDY_HIP_TRY(hipMemcpy(b.p, host, n * sizeof(float), hipMemcpyHostToDevice));
+  b.set = true;
+  return SDY_OK;
+}
+// host (rows=out, cols=in) row-major -> dev [in][ld] (ld >= out, zero padded)
+static int dev_upload_T(DevBuf& b, const float* host, int out, int in, int ld) {
+  std::vector<float> t((size_t)in * ld, 0.0f);
+  for (int o = 0; o < out; ++o)
+    for (int i = 0; i < in; ++i) t[(size_t)i * ld + o] = host[(size_t)o * in + i];
+  return dev_upload(b, t.data(), t.size());
+}
+static void dev_free(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.set = false;
+}
+
+extern "C" int sdy_sfno_create(const sdy_sfno_config* c, sdy_sfno** out) {
+  if (!c || !out) return SDY_ERR_ARG;
+  if (c->nlat < 2 || c->nlon < 4 || c->in_chans < 1 || c->out_chans < 1 || c->embed_dim < 4 || c->num_layers < 1 ||
+      c->num_layers > 32 || c->mlp_hidden < 4)
+    return SDY_ERR_ARG;
+  if ((c->embed_dim & 3) || (c->mlp_hidden & 3) || ((c->nlat * c->nlon) & 3)) return SDY_ERR_ALIGN;
+  if (c->with_time_emb && (c->time_dim < 4 || (c->embed_dim & 1))) return SDY_ERR_ARG;
+  if (c->dropout_mlp < 0.f || c->dropout_mlp >= 1.f || c->drop_path_rate < 0.f || c->drop_path_rate >= 1.f)
+    return SDY_ERR_ARG;
+  sdy_sfno* n = new sdy_sfno();
+  n->cfg = *c;
+  n->HW = c->nlat * c->nlon;
+  n->catC = c->embed_dim + c->in_chans;                      // [ last block output | concatenated inputs ]
+  n->decC = c->embed_dim + (c->big_skip ? c->in_chans : 0);  // what the decoder reads (sfnonet.py:736)
+  n->ldo = round_up(c->out_chans, 4);
+  n->blk.resize(c->num_layers);
+  int r = sdy_sht_plan_create(c->nlat, c->nlon, c->lmax, c->mmax, c->data_grid, &n->plan_data);
+  if (r != SDY_OK) { delete n; return r; }
+  if (c->data_grid == SDY_GRID_LEGENDRE_GAUSS) {
+    n->plan_lg = n->plan_data;
+  } else {
+    r = sdy_sht_plan_create(c->nlat, c->nlon, c->lmax, c->mmax, SDY_GRID_LEGENDRE_GAUSS, &n->plan_lg);
+    if (r != SDY_OK) { sdy_sfno_destroy(n); return r; }
+  }
+  // defaults that a caller may override with "@time_freq" / "@drop_path_rates"
+  std::memset(&n->tm, 0, sizeof(n->tm));
+  n->tm.num_layers = c->num_layers;
+  for (int i = 0; i < c->num_layers; ++i) {
+    const float rate = c->num_layers > 1 ? c->drop_path_rate * (float)i / (float)(c->num_layers - 1) : 0.0f;
+    n->tm.dp_rate[i] = rate;
+    n->tm.dp_thr[i] = sdy_drop_threshold(rate);
+  }
+  if (c->with_time_emb) {
+    const int E = c->embed_dim, T = c->time_dim, L = c->num_layers, half = E / 2;
+    std::vector<float> f(half);
+    const float e = (float)(-std::log(10000.0) / (half - 1));
+    for (int i = 0; i < half; ++i) f[i] = expf((float)i * e);
+    r = dev_upload(n->freq, f.data(), half);
+    if (r == SDY_OK) r = dev_alloc(n->wbt, (size_t)L * T * 2 * E);
+    if (r == SDY_OK) r = dev_alloc(n->bb, (size_t)L * 2 * E);
+    if (r != SDY_OK) { sdy_sfno_destroy(n); return r; }
+  }
+  *out = n;
+  return SDY_OK;
+}
+
+extern "C" void sdy_sfno_destroy(sdy_sfno* n) {
+  if (!n) return;
+  if (n->plan_lg && n->plan_lg != n->plan_data) sdy_sht_plan_destroy(n->plan_lg);
+  if (n->plan_data) sdy_sht_plan_destroy(n->plan_data);
+  DevBuf* top[] = {&n->pos, &n->e0w, &n->e0b, &n->e2w, &n->d0w, &n->d0b, &n->d2w, &n->t1w, &n->t1b,
+                   &n->t3w, &n->t3b, &n->freq, &n->wbt, &n->bb};
+  for (DevBuf* b : top) dev_free(*b);
+  for (BlockW& w : n->blk) {
+    DevBuf* bs[] = {&w.n0w, &w.n0b, &w.n1w, &w.n1b, &w.fw, &w.fb, &w.skw, &w.skb, &w.w1, &w.b1, &w.w2, &w.b2};
+    for (DevBuf* b : bs) dev_free(*b);
+  }
+  delete n;
+}
+
+#define EXPECT_NUMEL(n_expected)                      \
+  do {                                                \
+    if (numel != (size_t)(n_expected)) return SDY_ERR_SHAPE; \
+  } while (0)
+
+extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* host, size_t numel) {
+  if (!n || !name_c || !host) return SDY_ERR_ARG;
+  const sdy_sfno_config& c = n->cfg;
+  const int E = c.embed_dim, T = c.time_dim, L = c.num_layers, H = c.mlp_hidden, Cin = c.in_chans;
+  const std::string name(name_c);
+  // non-persistent SHT buffers of older torch-harmonics releases: accepted, ignored
+  if (name.find("trans") != std::string::npos && (name.find(".weights") != std::string::npos ||
+                                                   name.find(".pct") != std::string::npos))
+    return SDY_OK;
+  if (name == "@time_freq") { EXPECT_NUMEL(E / 2); return dev_upload(n->freq, host, numel); }
+  if (name == "@drop_path_rates") {
+    EXPECT_NUMEL(L);
+    for (int i = 0; i < L; ++i) {
+      if (host[i] < 0.f || host[i] >= 1.f) return SDY_ERR_ARG;
+      n->tm.dp_rate[i] = host[i];
+      n->tm.dp_thr[i] = sdy_drop_threshold(host[i]);
+    }
+    return SDY_OK;
+  }
+  if (name == "pos_embed") { EXPECT_NUMEL((size_t)E * n->HW); return dev_upload(n->pos, host, numel); }
+  if (name == "encoder.0.weight") { EXPECT_NUMEL((size_t)E * Cin); return dev_upload_T(n->e0w, host, E, Cin, E); }
+  if (name == "encoder.0.bias") { EXPECT_NUMEL(E); return dev_upload(n->e0b, host, numel); }
+  if (name == "encoder.2.weight") { EXPECT_NUMEL((size_t)E * E); return dev_upload_T(n->e2w, host, E, E, E); }
+  if (name == "decoder.0.weight") { EXPECT_NUMEL((size_t)E * n->decC); return dev_upload_T(n->d0w, host, E, n->decC, E); }
+  if (name == "decoder.0.bias") { EXPECT_NUMEL(E); return dev_upload(n->d0b, host, numel); }
+  if (name == "decoder.2.weight") {
+    EXPECT_NUMEL((size_t)c.out_chans * E);
+    return dev_upload_T(n->d2w, host, c.out_chans, E, n->ldo);
+  }
+  if (c.with_time_emb) {
+    if (name == "time_emb_mlp.1.weight") { EXPECT_NUMEL((size_t)T * E); return dev_upload_T(n->t1w, host, T, E, T); }
+    if (name == "time_emb_mlp.1.bias") { EXPECT_NUMEL(T); return dev_upload(n->t1b, host, numel); }
+    if (name == "time_emb_mlp.3.weight") { EXPECT_NUMEL((size_t)T * T); return dev_upload_T(n->t3w, host, T, T, T); }
+    if (name == "time_emb_mlp.3.bias") { EXPECT_NUMEL(T); return dev_upload(n->t3b, host, numel); }
+  }
+  if (name.rfind("blocks.", 0) == 0) {
+    const size_t dot = name.find('.', 7);
+    if (dot == std::string::npos) return SDY_ERR_NAME;
+    const int i = std::atoi(name.substr(7, dot - 7).c_str());
+    if (i < 0 || i >= L) return SDY_ERR_NAME;
+    const std::string rest = name.substr(dot + 1);
+    BlockW& w = n->blk[i];
+    if (rest == "norm0.weight") { EXPECT_NUMEL(E); return dev_upload(w.n0w, host, numel); }
+    if (rest == "norm0.bias") { EXPECT_NUMEL(E); return dev_upload(w.n0b, host, numel); }
+    if (rest == "norm1.weight") { EXPECT_NUMEL(E); return dev_upload(w.n1w, host, numel); }
+    if (rest == "norm1.bias") { EXPECT_NUMEL(E); return dev_upload(w.n1b, host, numel); }
+    if (c.with_time_emb && rest == "time_mlp.1.weight") {
+      EXPECT_NUMEL((size_t)2 * E * T);
+      std::vector<float> t((size_t)T * 2 * E);
+      for (int o = 0; o < 2 * E; ++o)
+        for (int k = 0; k < T; ++k) t[(size_t)k * 2 * E + o] = host[(size_t)o * T + k];
+      SDY_HIP_TRY(hipMemcpy(n->wbt.p + (size_t)i * T * 2 * E, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+      w.tw.set = true;
+      return SDY_OK;
+    }
+    if (c.with_time_emb && rest == "time_mlp.1.bias") {
+      EXPECT_NUMEL((size_t)2 * E);
+      SDY_HIP_TRY(hipMemcpy(n->bb.p + (size_t)i * 2 * E, host, numel * sizeof(float), hipMemcpyHostToDevice));
+      w.tb.set = true;
+      return SDY_OK;
+    }
+    if (rest == "filter.filter.weight") {
+      EXPECT_NUMEL((size_t)E * E * c.lmax * 2);
+      SDY_TRY(dev_alloc(w.fw, numel));
+      SDY_TRY(sdy_dhconv_pack_weight(host, E, E, c.lmax, w.fw.p, nullptr));
+      w.fw.set = true;
+      return SDY_OK;
+    }
+    if (rest == "filter.filter.bias") { EXPECT_NUMEL(E); return dev_upload(w.fb, host, numel); }
+    if (rest == "inner_skip.weight") { EXPECT_NUMEL((size_t)E * E); return dev_upload_T(w.skw, host, E, E, E); }
+    if (rest == "inner_skip.bias") { EXPECT_NUMEL(E); return dev_upload(w.skb, host, numel); }
+    if (rest == "mlp.fwd.0.weight") { EXPECT_NUMEL((size_t)H * E); return dev_upload_T(w.w1, host, H, E, H); }
+    if (rest == "mlp.fwd.0.bias") { EXPECT_NUMEL(H); return dev_upload(w.b1, host, numel); }
+    // layers.py:76-80: fc2 is index 3 of the Sequential when dropout > 0, else index 2
+    if (rest == "mlp.fwd.2.weight" || rest == "mlp.fwd.3.weight") {
+      EXPECT_NUMEL((size_t)E * H);
+      return dev_upload_T(w.w2, host, E, H, E);
+    }
+    if (rest == "mlp.fwd.2.bias" || rest == "mlp.fwd.3.bias") { EXPECT_NUMEL(E); return dev_upload(w.b2, host, numel); }
+  }
+  return SDY_ERR_NAME;
+}
+
+extern "C" int sdy_sfno_ready(const sdy_sfno* n_c) {
+  sdy_sfno* n = const_cast<sdy_sfno*>(n_c);
+  if (!n) return SDY_ERR_ARG;
+  const sdy_sfno_config& c = n->cfg;
+  n->missing.clear();
+  auto need = [&](const DevBuf& b, const std::string& nm) {
+    if (!b.set && n->missing.empty()) n->missing = nm;
+  };
+  if (c.pos_embed) need(n->pos, "pos_embed");
+  need(n->e0w, "encoder.0.weight"); need(n->e0b, "encoder.0.bias"); need(n->e2w, "encoder.2.weight");
+  need(n->d0w, "decoder.0.weight"); need(n->d0b, "decoder.0.bias"); need(n->d2w, "decoder.2.weight");
+  if (c.with_time_emb) {
+    need(n->t1w, "time_emb_mlp.1.weight"); need(n->t1b, "time_emb_mlp.1.bias");
+    need(n->t3w, "time_emb_mlp.3.weight"); need(n->t3b, "time_emb_mlp.3.bias");
+  }
+  for (int i = 0; i < c.num_layers; ++i) {
+    const BlockW& w = n->blk[i];
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    need(w.n0w, p + "norm0.weight"); need(w.n0b, p + "norm0.bias");
+    need(w.n1w, p + "norm1.weight"); need(w.n1b, p + "norm1.bias");
+    if (c.with_time_emb) { need(w.tw, p + "time_mlp.1.weight"); need(w.tb, p + "time_mlp.1.bias"); }
+    need(w.fw, p + "filter.filter.weight"); need(w.fb, p + "filter.filter.bias");
+    need(w.skw, p + "inner_skip.weight"); need(w.skb, p + "inner_skip.bias");
+    need(w.w1, p + "mlp.fwd.0.weight"); need(w.b1, p + "mlp.fwd.0.bias");
+    need(w.w2, p + "mlp.fwd.{2|3}.weight"); need(w.b2, p + "mlp.fwd.{2|3}.bias");
+  }
+  if (!n->missing.empty()) return SDY_ERR_STATE;
+  if (c.with_time_emb) {
+    n->tm.E = c.embed_dim; n->tm.T = c.time_dim;
+    n->tm.freq = n->freq.p; n->tm.w1t = n->t1w.p; n->tm.b1 = n->t1b.p; n->tm.w2t = n->t3w.p; n->tm.b2 = n->t3b.p;
+    n->tm.wbt = n->wbt.p; n->tm.bb = n->bb.p;
+  } else {
+    n->tm.E = 0;
+  }
+  return SDY_OK;
+}
+
+extern "C" const char* sdy_sfno_missing(const sdy_sfno* n) { return n ? n->missing.c_str() : ""; }
+
+namespace {
+struct WsLayout {
+  size_t cat, xa, xb, xn, y, hid, xf, cs, cs2, ca, cd, ss, dp, trep, total;
+};
+WsLayout ws_layout(const sdy_sfno* n, int B) {
+  const sdy_sfno_config& c = n->cfg;
+  const size_t HW = n->HW, E = c.embed_dim;
+  WsLayout w;
+  size_t off = 0;
+  auto take = [&](size_t floats) { size_t o = off; off += round_up_sz(floats, 64); return o; };
+  w.cat = take((size_t)B * n->catC * HW);
+  w.xa = take((size_t)B * E * HW);
+  w.xb = take((size_t)B * E * HW);
+  w.xn = take((size_t)B * E * HW);
+  w.y = take((size_t)B * E * HW);
+  w.hid = take((size_t)B * c.mlp_hidden * HW);
+  w.xf = take(xf_floats(n->plan_data, B, (int)E));
+  w.cs = take(cs_floats(n->plan_data, B, (int)E));
+  w.cs2 = take(cs_floats(n->plan_data, B, (int)E));
+  w.ca = take((size_t)B * E);
+  w.cd = take((size_t)B * E);
+  w.ss = take((size_t)B * c.num_layers * 2 * E);
+  w.dp = take((size_t)B * c.num_layers);
+  w.trep = take((size_t)B * (c.with_time_emb ? c.time_dim : 1));
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t sdy_sfno_workspace_floats(const sdy_sfno* n, int B) {
+  if (!n || B <= 0) return 0;
+  return ws_layout(n, B).total;
+}
+
+extern "C" int sdy_sfno_time_embed(sdy_sfno* n, const float* time, int B, float* t_repr, float* ss, void* stream) {
+  if (!n || !time || B <= 0) return SDY_ERR_ARG;
+  SDY_TRY(sdy_sfno_ready(n));
+  if (!n->cfg.with_time_emb) return SDY_ERR_UNSUPPORTED;
+  if (!ss) return SDY_ERR_ARG;
+  return sdy_time_mlp_launch(n->tm, time, B, t_repr, ss, nullptr, nullptr, 0, 0, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* stream_v) {
+  if (!n || !a || !a->out || !a->ws || a->B <= 0) return SDY_ERR_ARG;
+  SDY_TRY(sdy_sfno_ready(n));
+  const sdy_sfno_config& c = n->cfg;
+  hipStream_t stream = (hipStream_t)stream_v;
+  const int B = a->B, E = c.embed_dim, L = c.num_layers, HW = n->HW, Cin = c.in_chans, Hd = c.mlp_hidden;
+  if (c.with_time_emb && !a->time) return SDY_ERR_ARG;
+  const WsLayout w = ws_layout(n, B);
+  if (a->ws_floats < w.total) return SDY_ERR_WORKSPACE;
+  float* ws = a->ws;
+  float *cat = ws + w.cat, *xa = ws + w.xa, *xb = ws + w.xb, *xn = ws + w.xn, *y = ws + w.y, *hid = ws + w.hid;
+  float *Xf = ws + w.xf, *Cs = ws + w.cs, *Cs2 = ws + w.cs2, *ca = ws + w.ca, *cd = ws + w.cd;
+  float *ss = ws + w.ss, *dp = ws + w.dp, *trep = ws + w.trep;
+
+  // ---- input concat (BaseModel.concat_condition_if_needed, _base_model.py:166-192) into the tail of the big-skip
+  //      buffer: cat = [ block output (E) | inputs (Cin) ]  (sfnonet.py:804-805,831-832)
+  const float* srcs[3];
+  int chans[3];
+  int ns = 0, ctot = 0;
+  for (int i = 0; i < 3; ++i)
+    if (a->in[i] && a->in_chans[i] > 0) { srcs[ns] = a->in[i]; chans[ns] = a->in_chans[i]; ctot += a->in_chans[i]; ++ns; }
+  if (ns == 0 || ctot != Cin) return SDY_ERR_SHAPE;
+  const long cat_bs = (long)n->catC * HW;
+  float* cat_in = cat + (size_t)(n->catC - Cin) * HW;
+  SDY_TRY(sdy_concat_launch(srcs, chans, ns, cat_in, cat_bs, B, HW, stream));
+
+  // ---- time embedding + per-layer (scale|shift) + drop-path scales
+  const bool drop = a->enable_dropout != 0;
+  SDY_TRY(sdy_time_mlp_launch(n->tm, a->time, B, trep, ss, dp, a->drop_path_keep, drop ? 1 : 0, a->seed, a->call,
+                              a->batch_offset, stream));
+
+  sdy_conv_args cv;
+  auto conv_reset = [&]() {
+    std::memset(&cv, 0, sizeof(cv));
+    cv.B = B; cv.HW = HW; cv.seed = a->seed; cv.call = a->call; cv.batch_offset = a->batch_offset;
+  };
+
+  // ---- encoder (sfnonet.py:609-618,810,824): conv+bias -> GELU -> conv (no bias) -> + pos_embed
+  conv_reset();
+  cv.x = cat_in; cv.x_bstride = cat_bs; cv.wt = n->e0w.p; cv.ldw = E; cv.out = xa; cv.out_bstride = (long)E * HW;
+  cv.Cin = Cin; cv.Cout = E; cv.bias = n->e0b.p; cv.act = 1;
+  SDY_TRY(sdy_conv1x1(&cv, stream));
+  conv_reset();
+  cv.x = xa; cv.x_bstride = (long)E * HW; cv.wt = n->e2w.p; cv.ldw = E; cv.out = xb; cv.out_bstride = (long)E * HW;
+  cv.Cin = E; cv.Cout = E;
+  if (c.pos_embed) { cv.add = n->pos.p; cv.add_bstride = 0; cv.add_mode = 2; }
+  SDY_TRY(sdy_conv1x1(&cv, stream));
+
+  float* cur = xb;
+  float* nxt = xa;
+  for (int i = 0; i < L; ++i) {
+    const BlockW& bw = n->blk[i];
+    const sdy_sht_plan* pin = (i == 0) ? n->plan_data : n->plan_lg;
+    const sdy_sht_plan* pout = (i == L - 1) ? n->plan_data : n->plan_lg;
+    const bool scale_residual = pin != pout;  // s2convolutions.py:79-83
+    // norm0 + time scale/shift folded into a*x+d (sfnonet.py:292,298-299)
+    SDY_TRY(sdy_instnorm_coeffs_launch(cur, B, E, HW, bw.n0w.p, bw.n0b.p, c.with_time_emb ? ss + (size_t)i * 2 * E : nullptr,
+                                       (long)L * 2 * E, 1e-6f, ca, cd, stream));
+    // SpectralConvS2.forward (s2convolutions.py:158-193)
+    SDY_TRY(sdy_fft_launch_fwd(pin->fft, cur, ca, cd, scale_residual ? nullptr : xn, Xf, B, E, pin->nlat, pin->mtr, stream));
+    SDY_TRY(sdy_legendre_fwd(pin, Xf, Cs, B, E, stream));
+    if (scale_residual) {  // residual = inverse_transform(forward_transform(x))
+      SDY_TRY(sdy_legendre_inv(pout, Cs, Xf, B, E, stream));
+      SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, stream));
+    }
+    SDY_TRY(sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
+    SDY_TRY(sdy_legendre_inv(pout, Cs2, Xf, B, E, stream));
+    SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, stream));
+    // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
+    conv_reset();
+    cv.x = xn; cv.x_bstride = (long)E * HW; cv.wt = bw.skw.p; cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
+    cv.Cin = E; cv.Cout = E; cv.bias = bw.skb.p; cv.add = y; cv.add_bstride = (long)E * HW; cv.add_mode = 1; cv.act = 1;
+    SDY_TRY(sdy_conv1x1(&cv, stream));
+    // norm1 (sfnonet.py:313-320) folded into the fc1 prologue
+    SDY_TRY(sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca, cd, stream));
+    // MLP (layers.py:73-80): fc1 + GELU + dropout
+    const float pm = (drop && c.dropout_mlp > 0.f) ? c.dropout_mlp : 0.f;
+    conv_reset();
+    cv.x = y; cv.x_bstride = (long)E * HW; cv.wt = bw.w1.p; cv.ldw = Hd; cv.out = hid; cv.out_bstride = (long)Hd * HW;
+    cv.Cin = E; cv.Cout = Hd; cv.pa = ca; cv.pd = cd; cv.bias = bw.b1.p; cv.act = 1;
+    cv.drop_p = pm; cv.stream_id = 2u * i; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i] : nullptr;
+    SDY_TRY(sdy_conv1x1(&cv, stream));
+    // fc2 + dropout, DropPath, + residual (sfnonet.py:325-335)
+    float* dst = (i == L - 1) ? cat : nxt;
+    const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;
+    conv_reset();
+    cv.x = hid; cv.x_bstride = (long)Hd * HW; cv.wt = bw.w2.p; cv.ldw = E; cv.out = dst; cv.out_bstride = dst_bs;
+    cv.Cin = Hd; cv.Cout = E; cv.bias = bw.b2.p;
+    cv.drop_p = pm; cv.stream_id = 2u * i + 1u; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i + 1] : nullptr;
+    if (drop && n->tm.dp_rate[i] > 0.f) cv.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
+    cv.add = xn; cv.add_bstride = (long)E * HW; cv.add_mode = 2;
+    SDY_TRY(sdy_conv1x1(&cv, stream));
+    cur = dst;
+    nxt = (dst == xa) ? xb : xa;
+  }
+
+  // ---- decoder (sfnonet.py:734-744,831-837)
+  float* dh = xa;
+  conv_reset();
+  cv.x = cat; cv.x_bstride = cat_bs; cv.wt = n->d0w.p; cv.ldw = E;
+  cv.out = dh; cv.out_bstride = (long)E * HW; cv.Cin = n->decC; cv.Cout = E; cv.bias = n->d0b.p; cv.act = 1;
+  SDY_TRY(sdy_conv1x1(&cv, stream));
+  conv_reset();
+  cv.x = dh; cv.x_bstride = (long)E * HW; cv.wt = n->d2w.p; cv.ldw = n->ldo; cv.out = a->out;
+  cv.out_bstride = (long)c.out_chans * HW; cv.Cin = E; cv.Cout = c.out_chans;
+  SDY_TRY(sdy_conv1x1(&cv, stream));
+  return SDY_OK;
+}

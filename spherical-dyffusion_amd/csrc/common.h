@@ -1,0 +1,89 @@
+// Shared host/device helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sdy_amd.h"
+
+#define SDY_HIP_TRY(expr)                       \
+  do {                                          \
+    hipError_t _e = (expr);                     \
+    if (_e != hipSuccess) return (int)_e;       \
+  } while (0)
+
+#define SDY_TRY(expr)             \
+  do {                            \
+    int _r = (expr);              \
+    if (_r != SDY_OK) return _r;  \
+  } while (0)
+
+// launch check that does not synchronise
+static inline int sdy_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SDY_OK : (int)e;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- exact-erf GELU (nn.GELU default, src/models/sfno/sfnonet.py:602-603) ------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// ---- Philox4x32-10 (dropout stream, see include/sdy_amd.h) ----------------------------------------------
+struct philox4 {
+  uint32_t x, y, z, w;
+};
+__host__ __device__ __forceinline__ philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0;
+    uint64_t p1 = (uint64_t)M1 * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  return philox4{c0, c1, c2, c3};
+}
+static inline uint32_t sdy_drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t >= 4294967295.0) return 0xFFFFFFFFu;
+  if (t <= 0.0) return 0u;
+  return (uint32_t)t;
+}
+
+// ---- GEMM launcher (gemm.hip) --------------------------------------------------------------------------
+enum { SDY_TRI_NONE = 0, SDY_TRI_LEG_FWD = 1, SDY_TRI_LEG_INV = 2, SDY_TRI_DHCONV = 3 };
+enum { SDY_TILE_128x128 = 0, SDY_TILE_64x128 = 1 };
+
+// C[z][m][n] = epilogue( sum_k A[z][k][m] * prologue(B[z][k][n]) )
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  int M, N, K;         // loader extents; M is the padded row count of A (multiple of 4 when A is k-major)
+  int M_store;         // rows actually stored (<= M)
+  int lda, ldb, ldc;
+  long sA, sB, sC;     // batch strides (floats)
+  int nbatch;
+  int a_kcontig;       // 0: A stored [K][M] (m contiguous); 1: A stored [M][K] (k contiguous)
+  int b_cplx;          // 1: B is packed complex weight [z][2][E][E], expanded to [[wr, wi], [-wi, wr]]
+  int cplx_Ei, cplx_Eo;
+  int tri_mode, tri_B;
+  int tile;
+  // prologue affine on B rows
+  const float* pa; const float* pd; long p_bstride;
+  // epilogue
+  const float* bias;
+  const float* add; long sAdd; int ldadd; int add_mode;
+  int act;
+  uint32_t drop_thr; float drop_scale; const float* keep_mask;
+  uint32_t seed_lo, seed_hi, stream_id, call, batch_offset;
+  const float* batch_scale;
+};
+int sdy_gemm_launch(const GemmParams& p, hipStream_t stream);
+
+// ---- host tables (tables.cpp) --------------------------------------------------------------------------
+int sdy_factor_radices(int n, int* radices, int* nstages);  // n = prod(radices), radices in {4,2,3,5}

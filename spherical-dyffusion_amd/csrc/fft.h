@@ -1,0 +1,17 @@
+// Descriptor shared between the SHT plan (plan.hip) and the FFT kernels (fft.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct SdyFftDesc {
+  int n;           // complex length = nlon / 2
+  int S;           // LDS row stride (odd, >= n + 1)
+  int nstages;
+  int radices[10]; // product = n, each in {2,3,4,5}
+  const float* tw; // dev [n][2]    exp(-2*pi*i*j/n)
+  const float* pw; // dev [n+1][2]  exp(-2*pi*i*m/nlon)
+};
+
+int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
+                       int B, int C, int K, int mtr, hipStream_t stream);
+int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
+                       hipStream_t stream);

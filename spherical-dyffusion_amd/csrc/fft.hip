@@ -1,0 +1,310 @@
+// Longitude real FFT / inverse real FFT for the spherical-harmonic transform, gfx950.
+//
+// Restates the two torch.fft calls inside torch_harmonics (third-party; reference call sites
+// src/models/sfno/s2convolutions.py:165,168,186):
+//   forward : X = 2*pi * rfft(x, dim=-1, norm="forward")           (keeps m < mtr)
+//   inverse : x = irfft(Y, n=nlon, dim=-1, norm="forward")          (imag of the m=0 / Nyquist bins ignored)
+// and does the layout change between NCHW activations and the m-major spectral layout the Legendre GEMMs want:
+//   x[b][c][k][w]  <->  Xf[m][k][b][ri][c]
+// A workgroup owns CB channels of one (b, k) latitude ring: rows are read as coalesced 16-byte loads, transformed in
+// LDS (real FFT of length N as a complex Stockham FFT of length n = N/2 with radices {4,2,3,5} plus a split step),
+// and written as CB-float runs for each m.  HBM-bound; see DESIGN.md for the byte model.
+// Fused on the way in: the per-(b,c) affine a*x+d (InstanceNorm + time scale/shift, sfnonet.py:292,298-299) and the
+// optional store of the normalised field (the block's residual); on the way out: the filter bias
+// (s2convolutions.py:188-189).
+#include "common.h"
+#include "fft.h"
+
+namespace {
+
+constexpr int CB = 16;        // channels (rows) per workgroup
+constexpr int NT = 256;       // threads
+
+struct cpx {
+  float r, i;
+};
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return cpx{a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return cpx{a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return cpx{a.r - b.r, a.i - b.i}; }
+// multiply by (s * i), s = +-1
+__device__ __forceinline__ cpx cmul_si(cpx a, float s) { return cpx{-s * a.i, s * a.r}; }
+
+template <int R>
+__device__ __forceinline__ void dft(cpx* v, float s);
+template <>
+__device__ __forceinline__ void dft<2>(cpx* v, float) {
+  cpx a = v[0], b = v[1];
+  v[0] = cadd(a, b);
+  v[1] = csub(a, b);
+}
+template <>
+__device__ __forceinline__ void dft<4>(cpx* v, float s) {
+  cpx t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = cmul_si(csub(v[1], v[3]), s);
+  v[0] = cadd(t0, t2);
+  v[1] = cadd(t1, t3);
+  v[2] = csub(t0, t2);
+  v[3] = csub(t1, t3);
+}
+template <>
+__device__ __forceinline__ void dft<3>(cpx* v, float s) {
+  const float c = -0.5f, sn = 0.86602540378443864676f;
+  cpx a = cadd(v[1], v[2]), b = csub(v[1], v[2]);
+  cpx m = cpx{v[0].r + c * a.r, v[0].i + c * a.i};
+  cpx t = cmul_si(cpx{sn * b.r, sn * b.i}, s);
+  v[0] = cadd(v[0], a);
+  v[1] = cadd(m, t);
+  v[2] = csub(m, t);
+}
+template <>
+__device__ __forceinline__ void dft<5>(cpx* v, float s) {
+  const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+  const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+  cpx a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+  cpx r1 = cpx{v[0].r + c1 * a1.r + c2 * a2.r, v[0].i + c1 * a1.i + c2 * a2.i};
+  cpx r2 = cpx{v[0].r + c2 * a1.r + c1 * a2.r, v[0].i + c2 * a1.i + c1 * a2.i};
+  cpx i1 = cmul_si(cpx{s1 * b1.r + s2 * b2.r, s1 * b1.i + s2 * b2.i}, s);
+  cpx i2 = cmul_si(cpx{s2 * b1.r - s1 * b2.r, s2 * b1.i - s1 * b2.i}, s);
+  v[0] = cadd(v[0], cadd(a1, a2));
+  v[1] = cadd(r1, i1);
+  v[4] = csub(r1, i1);
+  v[2] = cadd(r2, i2);
+  v[3] = csub(r2, i2);
+}
+
+// One Stockham butterfly: inputs src[j + q*nb], outputs dst[j0 + t*Ns];  s = -1 forward, +1 inverse.
+template <int R>
+__device__ __forceinline__ void butterfly(const float* sre, const float* sim, float* dre, float* dim_, int j, int nb,
+                                          int Ns, int tstride, const float* twr, const float* twi, float s) {
+  const int k = j % Ns;
+  cpx v[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    cpx x = cpx{sre[j + q * nb], sim[j + q * nb]};
+    if (q > 0 && k > 0) {
+      const int ti = q * k * tstride;
+      x = cmul(x, cpx{twr[ti], -s * twi[ti]});  // table holds exp(-2*pi*i*j/n)
+    }
+    v[q] = x;
+  }
+  dft<R>(v, s);
+  const int j0 = (j / Ns) * Ns * R + k;
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    dre[j0 + t * Ns] = v[t].r;
+    dim_[j0 + t * Ns] = v[t].i;
+  }
+}
+
+struct LdsView {
+  float *a_re, *a_im, *b_re, *b_im, *tw_re, *tw_im, *pw_re, *pw_im;
+};
+__device__ __forceinline__ LdsView carve(float* sm, int S, int n) {
+  LdsView v;
+  v.a_re = sm;
+  v.a_im = v.a_re + CB * S;
+  v.b_re = v.a_im + CB * S;
+  v.b_im = v.b_re + CB * S;
+  v.tw_re = v.b_im + CB * S;
+  v.tw_im = v.tw_re + n;
+  v.pw_re = v.tw_im + n;
+  v.pw_im = v.pw_re + (n + 1);
+  return v;
+}
+
+// complex FFT of length n on CB rows, ping-pong between (a) and (b); returns with result in *res_re / *res_im
+__device__ __forceinline__ void fft_rows(const SdyFftDesc& f, LdsView& L, int S, float s, float** res_re,
+                                         float** res_im) {
+  float *sre = L.a_re, *sim = L.a_im, *dre = L.b_re, *dim_ = L.b_im;
+  const int n = f.n;
+  int Ns = 1;
+  for (int st = 0; st < f.nstages; ++st) {
+    const int R = f.radices[st];
+    const int nb = n / R;
+    const int tstride = n / (Ns * R);
+    for (int id = threadIdx.x; id < CB * nb; id += NT) {
+      const int r = id / nb, j = id - r * nb;
+      const float* pr = sre + r * S;
+      const float* pi = sim + r * S;
+      float* qr = dre + r * S;
+      float* qi = dim_ + r * S;
+      switch (R) {
+        case 2: butterfly<2>(pr, pi, qr, qi, j, nb, Ns, tstride, L.tw_re, L.tw_im, s); break;
+        case 3: butterfly<3>(pr, pi, qr, qi, j, nb, Ns, tstride, L.tw_re, L.tw_im, s); break;
+        case 4: butterfly<4>(pr, pi, qr, qi, j, nb, Ns, tstride, L.tw_re, L.tw_im, s); break;
+        default: butterfly<5>(pr, pi, qr, qi, j, nb, Ns, tstride, L.tw_re, L.tw_im, s); break;
+      }
+    }
+    __syncthreads();
+    float* t;
+    t = sre; sre = dre; dre = t;
+    t = sim; sim = dim_; dim_ = t;
+    Ns *= R;
+  }
+  *res_re = sre;
+  *res_im = sim;
+}
+
+__device__ __forceinline__ void load_tables(const SdyFftDesc& f, LdsView& L) {
+  const int n = f.n;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    L.tw_re[i] = f.tw[2 * i];
+    L.tw_im[i] = f.tw[2 * i + 1];
+  }
+  for (int i = threadIdx.x; i <= n; i += NT) {
+    L.pw_re[i] = f.pw[2 * i];
+    L.pw_im[i] = f.pw[2 * i + 1];
+  }
+}
+
+// x (B,C,K,N) -> Xf[m][k][b][ri][c]
+__global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const float* __restrict__ x,
+                                                       const float* __restrict__ pa, const float* __restrict__ pd,
+                                                       float* __restrict__ xn_out, float* __restrict__ Xf, int B,
+                                                       int C, int K, int mtr) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int n = f.n, N = 2 * n, S = f.S;
+  LdsView L = carve(sm, S, n);
+  const int c0 = blockIdx.x * CB, k = blockIdx.y, b = blockIdx.z;
+  load_tables(f, L);
+
+  const int q4 = N / 4;
+  for (int idx = threadIdx.x; idx < CB * q4; idx += NT) {
+    const int r = idx / q4, q = idx - r * q4;
+    const int c = c0 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+      const long off = (((long)b * C + c) * K + k) * N + 4 * q;
+      v = *reinterpret_cast<const f32x4*>(x + off);
+      if (pa) v = v * pa[b * C + c] + pd[b * C + c];
+      if (xn_out) *reinterpret_cast<f32x4*>(xn_out + off) = v;
+    }
+    L.a_re[r * S + 2 * q] = v.x;
+    L.a_im[r * S + 2 * q] = v.y;
+    L.a_re[r * S + 2 * q + 1] = v.z;
+    L.a_im[r * S + 2 * q + 1] = v.w;
+  }
+  __syncthreads();
+
+  float *zr, *zi;
+  fft_rows(f, L, S, -1.0f, &zr, &zi);
+
+  // split step: X[m] = E + w^m O, X[n-m] = conj(E - w^m O); scaled by 2*pi/N
+  const float scale = 6.28318530717958647692f / (float)N;
+  const int np = n / 2 + 1;
+  for (int id = threadIdx.x; id < CB * np; id += NT) {
+    const int r = id / np, m = id - r * np;
+    float* re = zr + r * S;
+    float* im = zi + r * S;
+    const int m2 = (m == 0) ? 0 : n - m;
+    const float a = re[m], bq = im[m], c = re[m2], d = im[m2];
+    const cpx E = cpx{0.5f * (a + c), 0.5f * (bq - d)};
+    const cpx O = cpx{0.5f * (bq + d), -0.5f * (a - c)};
+    const cpx T = cmul(cpx{L.pw_re[m], L.pw_im[m]}, O);
+    re[m] = scale * (E.r + T.r);
+    im[m] = scale * (E.i + T.i);
+    re[n - m] = scale * (E.r - T.r);
+    im[n - m] = -scale * (E.i - T.i);
+  }
+  __syncthreads();
+
+  const int r = threadIdx.x % CB, mg = threadIdx.x / CB;
+  const int c = c0 + r;
+  if (c < C) {
+    for (int m = mg; m < mtr; m += NT / CB) {
+      const long o = (((long)m * K + k) * B + b) * (2L * C) + c;
+      Xf[o] = zr[r * S + m];
+      Xf[o + C] = zi[r * S + m];
+    }
+  }
+}
+
+// Yf[m][k][b][ri][c] -> y (B,C,K,N) (+ bias[c])
+__global__ __launch_bounds__(NT) void irfft_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
+                                                    const float* __restrict__ bias, float* __restrict__ y, int B, int C,
+                                                    int K, int mtr) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int n = f.n, N = 2 * n, S = f.S;
+  LdsView L = carve(sm, S, n);
+  const int c0 = blockIdx.x * CB, k = blockIdx.y, b = blockIdx.z;
+  load_tables(f, L);
+
+  {
+    const int r = threadIdx.x % CB, mg = threadIdx.x / CB;
+    const int c = c0 + r;
+    for (int m = mg; m <= n; m += NT / CB) {
+      float vr = 0.f, vi = 0.f;
+      if (c < C && m < mtr) {
+        const long o = (((long)m * K + k) * B + b) * (2L * C) + c;
+        vr = Yf[o];
+        vi = Yf[o + C];
+      }
+      L.a_re[r * S + m] = vr;
+      L.a_im[r * S + m] = vi;
+    }
+  }
+  __syncthreads();
+
+  // merge step: Z[m] = S + i D, Z[n-m] = conj(S - i D),  S = X[m] + conj(X[n-m]),  D = e^{+2 pi i m/N} (X[m] - conj(X[n-m]))
+  const int np = n / 2 + 1;
+  for (int id = threadIdx.x; id < CB * np; id += NT) {
+    const int r = id / np, m = id - r * np;
+    float* re = L.a_re + r * S;
+    float* im = L.a_im + r * S;
+    cpx A = cpx{re[m], im[m]};
+    cpx Bc = cpx{re[n - m], -im[n - m]};
+    if (m == 0) {  // irfft ignores the imaginary parts of the DC and Nyquist bins
+      A.i = 0.f;
+      Bc.i = 0.f;
+    }
+    const cpx Sm = cadd(A, Bc);
+    const cpx D = cmul(cpx{L.pw_re[m], -L.pw_im[m]}, csub(A, Bc));
+    // Z[m] = S + iD
+    re[m] = Sm.r - D.i;
+    im[m] = Sm.i + D.r;
+    if (m > 0) {  // Z[n-m] = conj(S - iD) = conj( (S.r + D.i) + i (S.i - D.r) )
+      re[n - m] = Sm.r + D.i;
+      im[n - m] = -(Sm.i - D.r);
+    }
+  }
+  __syncthreads();
+
+  float *zr, *zi;
+  fft_rows(f, L, S, +1.0f, &zr, &zi);
+
+  const int q4 = N / 4;
+  for (int idx = threadIdx.x; idx < CB * q4; idx += NT) {
+    const int r = idx / q4, q = idx - r * q4;
+    const int c = c0 + r;
+    if (c < C) {
+      const float bv = bias ? bias[c] : 0.0f;
+      f32x4 v;
+      v.x = zr[r * S + 2 * q] + bv;
+      v.y = zi[r * S + 2 * q] + bv;
+      v.z = zr[r * S + 2 * q + 1] + bv;
+      v.w = zi[r * S + 2 * q + 1] + bv;
+      *reinterpret_cast<f32x4*>(y + (((long)b * C + c) * K + k) * N + 4 * q) = v;
+    }
+  }
+}
+
+size_t fft_smem_bytes(const SdyFftDesc& f) { return ((size_t)4 * CB * f.S + 2 * f.n + 2 * (f.n + 1)) * sizeof(float); }
+
+}  // namespace
+
+int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
+                       int B, int C, int K, int mtr, hipStream_t stream) {
+  const size_t smem = fft_smem_bytes(f);
+  if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
+  dim3 grid((C + CB - 1) / CB, K, B);
+  hipLaunchKernelGGL(rfft_fwd_kernel, grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  return sdy_launch_status();
+}
+
+int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
+                       hipStream_t stream) {
+  const size_t smem = fft_smem_bytes(f);
+  if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
+  dim3 grid((C + CB - 1) / CB, K, B);
+  hipLaunchKernelGGL(irfft_kernel, grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+  return sdy_launch_status();
+}

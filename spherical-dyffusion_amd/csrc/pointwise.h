@@ -1,0 +1,30 @@
+// Launchers of pointwise.hip (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct SdyTimeMlp {
+  int E;            // embed_dim (0 = network has no time embedding)
+  int T;            // time_dim
+  int num_layers;
+  const float* freq;  // dev [E/2]   exp(arange(E/2) * -log(1e4)/(E/2-1))
+  const float* w1t;   // dev [E][T]
+  const float* b1;    // dev [T]
+  const float* w2t;   // dev [T][T]
+  const float* b2;    // dev [T]
+  const float* wbt;   // dev [L][T][2E]
+  const float* bb;    // dev [L][2E]
+  float dp_rate[32];
+  uint32_t dp_thr[32];
+};
+
+int sdy_instnorm_coeffs_launch(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
+                               const float* ss, long ss_stride, float eps, float* a, float* d, hipStream_t stream);
+int sdy_concat_launch(const float* const* src, const int* chans, int nsrc, float* out, long out_bstride, int B, int HW,
+                      hipStream_t stream);
+int sdy_cold_update_launch(const float* xs, const float* xn, const float* xi, float* out, size_t n, hipStream_t stream);
+int sdy_time_mlp_launch(const SdyTimeMlp& t, const float* time, int B, float* trep, float* ss, float* dp,
+                        const float* dp_keep_in, int enable_dropout, uint64_t seed, uint32_t call,
+                        uint32_t batch_offset, hipStream_t stream);
+int sdy_spec_to_torch_launch(const float* Cs, float* out, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);
+int sdy_torch_to_spec_launch(const float* in, float* Cs, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);

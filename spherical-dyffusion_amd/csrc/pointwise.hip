@@ -1,0 +1,303 @@
+// HBM-bound pointwise / reduction kernels of the SFNO block and the DYffusion sampler, gfx950.
+#include "common.h"
+#include "pointwise.h"
+
+namespace {
+
+// ---- InstanceNorm statistics -> per-(b,c) affine coefficients ------------------------------------------
+// nn.InstanceNorm2d(eps=1e-6, affine=True, track_running_stats=False): biased variance over H*W per (b,c)
+// (src/models/sfno/sfnonet.py:641-648), folded with the block's time scale/shift (sfnonet.py:280-287).
+// One workgroup per (c, b) plane; 16-byte loads; fp64 accumulation (HBM-bound, the DP adds are free).
+__global__ __launch_bounds__(256) void instnorm_coeffs_kernel(const float* __restrict__ x, int C, int HW,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ ss, long ss_stride, float eps,
+                                                               float* __restrict__ a_out, float* __restrict__ d_out) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* px = x + ((long)b * C + c) * HW;
+  double s = 0.0, s2 = 0.0;
+  const int n4 = HW >> 2;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(px);
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 v = p4[i];
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < HW; i += 256) {
+    const double v = px[i];
+    s += v;
+    s2 += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  __shared__ double sh[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[wave] = s;
+    sh[4 + wave] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double S = sh[0] + sh[1] + sh[2] + sh[3];
+    const double S2 = sh[4] + sh[5] + sh[6] + sh[7];
+    const double mean = S / HW;
+    double var = S2 / HW - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float a = gamma[c] * rstd;
+    float d = beta[c] - (float)mean * a;
+    if (ss) {
+      const float sc = ss[(long)b * ss_stride + c] + 1.0f;
+      const float sh_ = ss[(long)b * ss_stride + C + c];
+      a = a * sc;
+      d = d * sc + sh_;
+    }
+    a_out[b * C + c] = a;
+    d_out[b * C + c] = d;
+  }
+}
+
+// ---- channel concat (torch.cat(dim=1)) ------------------------------------------------------------------
+struct ConcatArgs {
+  const float* src[4];
+  int chans[4];
+  int nsrc;
+};
+__global__ __launch_bounds__(256) void concat_kernel(const ConcatArgs a, float* __restrict__ out, long out_bstride,
+                                                      int HW4) {
+  // grid: (ceil(HW4/256), total_chans, B); one float4 per thread
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW4) return;
+  int c = blockIdx.y;
+  const int b = blockIdx.z;
+  int s = 0, coff = 0;
+  while (s < a.nsrc - 1 && c >= a.chans[s]) {
+    c -= a.chans[s];
+    coff += a.chans[s];
+    ++s;
+  }
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.src[s] + ((long)b * a.chans[s] + c) * HW4 * 4);
+  f32x4* dst = reinterpret_cast<f32x4*>(out + (long)b * out_bstride + (long)(coff + c) * HW4 * 4);
+  dst[i] = src[i];
+}
+
+// ---- cold-sampling update: out = x_s + (x_ip_next - x_ip_s)   (src/diffusion/dyffusion.py:517-519) -------
+__global__ __launch_bounds__(256) void cold_update_kernel(const float* __restrict__ xs, const float* __restrict__ xn,
+                                                           const float* __restrict__ xi, float* __restrict__ out,
+                                                           size_t n) {
+  const size_t n4 = n >> 2;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(xs)[i];
+    const f32x4 b = reinterpret_cast<const f32x4*>(xn)[i];
+    const f32x4 c = xi ? reinterpret_cast<const f32x4*>(xi)[i] : a;
+    reinterpret_cast<f32x4*>(out)[i] = a + (b - c);
+  }
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float a = xs[i], b = xn[i], c = xi ? xi[i] : a;
+    out[i] = a + (b - c);
+  }
+}
+
+// ---- time embedding ---------------------------------------------------------------------------------------
+// SinusoidalPosEmb -> Linear -> GELU -> Linear (src/models/modules/misc.py:21-33,132-148), then per block
+// SiLU -> Linear (src/models/sfno/sfnonet.py:210-213,280-284); also the per-(sample, layer) drop-path scale
+// (src/models/modules/drop_path.py:15-22).  grid (num_layers + 1, B): block y=b, x<num_layers computes that
+// layer's (scale|shift); x == num_layers writes t_repr.  Every workgroup recomputes t_repr (0.4 MFLOP).
+// All weights are stored transposed ([in][out]) so consecutive threads read consecutive addresses.
+__global__ __launch_bounds__(256) void time_mlp_kernel(const SdyTimeMlp t, const float* __restrict__ time,
+                                                        float* __restrict__ trep_out, float* __restrict__ ss_out,
+                                                        float* __restrict__ dp_out, const float* __restrict__ dp_keep_in,
+                                                        int enable_dropout, uint32_t seed_lo, uint32_t seed_hi,
+                                                        uint32_t call, uint32_t batch_offset) {
+  extern __shared__ float sm[];
+  const int E = t.E, T = t.T, L = t.num_layers;
+  float* emb = sm;         // [E]
+  float* h1 = emb + E;     // [T]
+  float* tr = h1 + T;      // [T]
+  const int layer = blockIdx.x, b = blockIdx.y;
+  const float tv = time[b];
+  const int half = E / 2;
+  for (int i = threadIdx.x; i < E; i += 256) {
+    const float f = t.freq[i < half ? i : i - half];
+    const float arg = tv * f;
+    emb[i] = i < half ? sinf(arg) : cosf(arg);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < T; o += 256) {
+    float acc = t.b1[o];
+    for (int i = 0; i < E; ++i) acc += t.w1t[(long)i * T + o] * emb[i];
+    h1[o] = gelu_erf(acc);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < T; o += 256) {
+    float acc = t.b2[o];
+    for (int i = 0; i < T; ++i) acc += t.w2t[(long)i * T + o] * h1[i];
+    tr[o] = acc;
+  }
+  __syncthreads();
+  if (layer == L) {
+    if (trep_out)
+      for (int o = threadIdx.x; o < T; o += 256) trep_out[(long)b * T + o] = tr[o];
+    return;
+  }
+  for (int i = threadIdx.x; i < T; i += 256) h1[i] = silu(tr[i]);
+  __syncthreads();
+  const float* wb = t.wbt + (long)layer * T * 2 * E;
+  const float* bb = t.bb + (long)layer * 2 * E;
+  for (int o = threadIdx.x; o < 2 * E; o += 256) {
+    float acc = bb[o];
+    for (int i = 0; i < T; ++i) acc += wb[(long)i * 2 * E + o] * h1[i];
+    ss_out[((long)b * L + layer) * 2 * E + o] = acc;
+  }
+  if (threadIdx.x == 0 && dp_out) {
+    float scale = 1.0f;
+    const float p = t.dp_rate[layer];
+    if (enable_dropout && p > 0.0f) {
+      bool keep;
+      if (dp_keep_in) {
+        keep = dp_keep_in[layer * gridDim.y + b] != 0.0f;
+      } else {
+        const philox4 w = philox4x32_10((uint32_t)(b + batch_offset), 0xFFFFFFFFu, 0x1000u + (uint32_t)layer, call,
+                                        seed_lo, seed_hi);
+        keep = w.x >= t.dp_thr[layer];
+      }
+      scale = keep ? 1.0f / (1.0f - p) : 0.0f;
+    }
+    dp_out[layer * gridDim.y + b] = scale;  // [layer][b]
+  }
+}
+
+// drop-path scales only (network without time embedding)
+__global__ void droppath_kernel(const SdyTimeMlp t, float* __restrict__ dp_out, const float* __restrict__ dp_keep_in,
+                                int B, int enable_dropout, uint32_t seed_lo, uint32_t seed_hi, uint32_t call,
+                                uint32_t batch_offset) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int L = t.num_layers;
+  if (i >= B * L) return;
+  const int b = i / L, layer = i - b * L;
+  float scale = 1.0f;
+  const float p = t.dp_rate[layer];
+  if (enable_dropout && p > 0.0f) {
+    bool keep;
+    if (dp_keep_in) {
+      keep = dp_keep_in[layer * B + b] != 0.0f;
+    } else {
+      const philox4 w = philox4x32_10((uint32_t)(b + batch_offset), 0xFFFFFFFFu, 0x1000u + (uint32_t)layer, call,
+                                      seed_lo, seed_hi);
+      keep = w.x >= t.dp_thr[layer];
+    }
+    scale = keep ? 1.0f / (1.0f - p) : 0.0f;
+  }
+  dp_out[layer * B + b] = scale;  // [layer][b]
+}
+
+// ---- layout converters for the stand-alone SHT entry points (parity tests; not on the fused path) ---------
+// Cs[l][m][b][ri][c]  ->  out (B,C,L,Mfull) complex64 interleaved; zero where m > l or m >= mtr
+__global__ __launch_bounds__(256) void spec_to_torch_kernel(const float* __restrict__ Cs, float* __restrict__ out,
+                                                             int B, int C, int L, int mtr, int Mfull) {
+  const long total = (long)B * C * L * Mfull;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i % Mfull);
+    long r = i / Mfull;
+    const int l = (int)(r % L);
+    r /= L;
+    const int c = (int)(r % C);
+    const int b = (int)(r / C);
+    float re = 0.f, im = 0.f;
+    if (m < mtr && m <= l) {
+      const long o = (((long)l * mtr + m) * B + b) * (2L * C) + c;
+      re = Cs[o];
+      im = Cs[o + C];
+    }
+    out[2 * i] = re;
+    out[2 * i + 1] = im;
+  }
+}
+// in (B,C,L,Mfull) complex64 -> Cs[l][m][b][ri][c] (all m < mtr written, also m > l: the synthesis table is zero there)
+__global__ __launch_bounds__(256) void torch_to_spec_kernel(const float* __restrict__ in, float* __restrict__ Cs,
+                                                             int B, int C, int L, int mtr, int Mfull) {
+  const long total = (long)L * mtr * B * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int b = (int)(r % B);
+    r /= B;
+    const int m = (int)(r % mtr);
+    const int l = (int)(r / mtr);
+    const long src = ((((long)b * C + c) * L + l) * Mfull + m) * 2;
+    const long o = (((long)l * mtr + m) * B + b) * (2L * C) + c;
+    Cs[o] = in[src];
+    Cs[o + C] = in[src + 1];
+  }
+}
+
+}  // namespace
+
+int sdy_instnorm_coeffs_launch(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
+                               const float* ss, long ss_stride, float eps, float* a, float* d, hipStream_t stream) {
+  if (!x || !gamma || !beta || !a || !d || B <= 0 || C <= 0 || HW <= 0) return SDY_ERR_ARG;
+  if (HW & 3) return SDY_ERR_ALIGN;
+  hipLaunchKernelGGL(instnorm_coeffs_kernel, dim3(C, B), dim3(256), 0, stream, x, C, HW, gamma, beta, ss, ss_stride,
+                     eps, a, d);
+  return sdy_launch_status();
+}
+
+int sdy_concat_launch(const float* const* src, const int* chans, int nsrc, float* out, long out_bstride, int B, int HW,
+                      hipStream_t stream) {
+  if (!src || !chans || !out || nsrc < 1 || nsrc > 4 || B <= 0 || HW <= 0) return SDY_ERR_ARG;
+  if (HW & 3) return SDY_ERR_ALIGN;
+  ConcatArgs a;
+  int total = 0;
+  for (int i = 0; i < 4; ++i) {
+    a.src[i] = i < nsrc ? src[i] : nullptr;
+    a.chans[i] = i < nsrc ? chans[i] : 0;
+    if (i < nsrc) {
+      if (!src[i] || chans[i] <= 0) return SDY_ERR_ARG;
+      total += chans[i];
+    }
+  }
+  a.nsrc = nsrc;
+  const int HW4 = HW / 4;
+  hipLaunchKernelGGL(concat_kernel, dim3((HW4 + 255) / 256, total, B), dim3(256), 0, stream, a, out, out_bstride, HW4);
+  return sdy_launch_status();
+}
+
+int sdy_cold_update_launch(const float* xs, const float* xn, const float* xi, float* out, size_t n,
+                           hipStream_t stream) {
+  if (!xs || !xn || !out || n == 0) return SDY_ERR_ARG;
+  size_t blocks = ((n >> 2) + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cold_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, xs, xn, xi, out, n);
+  return sdy_launch_status();
+}
+
+int sdy_time_mlp_launch(const SdyTimeMlp& t, const float* time, int B, float* trep, float* ss, float* dp,
+                        const float* dp_keep_in, int enable_dropout, uint64_t seed, uint32_t call,
+                        uint32_t batch_offset, hipStream_t stream) {
+  const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
+  if (t.E > 0) {
+    if (!time) return SDY_ERR_ARG;
+    const size_t smem = (size_t)(t.E + 2 * t.T) * sizeof(float);
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(t.num_layers + 1, B), dim3(256), smem, stream, t, time, trep, ss, dp,
+                       dp_keep_in, enable_dropout, slo, shi, call, batch_offset);
+  } else if (dp) {
+    const int n = B * t.num_layers;
+    hipLaunchKernelGGL(droppath_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, t, dp, dp_keep_in, B, enable_dropout,
+                       slo, shi, call, batch_offset);
+  }
+  return sdy_launch_status();
+}
+
+int sdy_spec_to_torch_launch(const float* Cs, float* out, int B, int C, int L, int mtr, int Mfull, hipStream_t stream) {
+  hipLaunchKernelGGL(spec_to_torch_kernel, dim3(1024), dim3(256), 0, stream, Cs, out, B, C, L, mtr, Mfull);
+  return sdy_launch_status();
+}
+int sdy_torch_to_spec_launch(const float* in, float* Cs, int B, int C, int L, int mtr, int Mfull, hipStream_t stream) {
+  hipLaunchKernelGGL(torch_to_spec_kernel, dim3(1024), dim3(256), 0, stream, in, Cs, B, C, L, mtr, Mfull);
+  return sdy_launch_status();
+}

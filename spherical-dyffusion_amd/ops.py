@@ -1,0 +1,142 @@
+"""Operator-level host wrappers (one HIP launch each) mirroring the reference callables of the SFNO block.
+
+These exist for drop-in use at the reference's inner boundary and for the per-op parity tests; the network
+(`sfno.py`) does not go through them -- it calls the fused native forward.  torch is used for buffer ownership
+and layout views only; all arithmetic is in libsdy_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from ._lib import SdyConvArgs, check, current_stream, lib, ptr
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("sdy_amd ops run on the GPU only (no CPU fallback)")
+    return t.to(torch.float32).contiguous()
+
+
+def contract_dhconv(x: torch.Tensor, weight: torch.Tensor, separable: bool = False,
+                    operator_type: str = "dhconv") -> torch.Tensor:
+    """`_contract_dense_pytorch(x, weight, separable=False, operator_type="dhconv")`
+    (`src/models/sfno/factorizations.py:165-186` -> `contractions.py:159-169`):
+    x (B, Ci, L, M) complex64, weight (Ci, Co, L, 2) real -> (B, Co, L, M) complex64,
+    out[b,o,l,m] = sum_i x[b,i,l,m] * w[i,o,l].  Entries with m > l are treated as structurally zero
+    (they are for every SHT output) and returned as zero.
+    """
+    if separable or operator_type != "dhconv":
+        raise NotImplementedError("only the non-separable dhconv contraction is on the hot path")
+    B, Ci, L, M = x.shape
+    Co = weight.shape[1]
+    assert weight.shape == (Ci, Co, L, 2), f"weight shape {tuple(weight.shape)}"
+    mtr = min(M, L)
+    xr = torch.view_as_real(x.to(torch.complex64).contiguous())          # (B,Ci,L,M,2)
+    cs_in = xr[:, :, :, :mtr].permute(2, 3, 0, 4, 1).contiguous()         # [l][m][b][ri][c]
+    cs_out = torch.zeros(L, mtr, B, 2, Co, dtype=torch.float32, device=x.device)
+    wp = torch.empty(L * 2 * Ci * Co, dtype=torch.float32, device=x.device)
+    w_host = weight.detach().to(torch.float32).cpu().contiguous()
+    with torch.cuda.device(x.device):
+        check(lib.sdy_dhconv_pack_weight(ptr(w_host), Ci, Co, L, ptr(wp), current_stream()), "sdy_dhconv_pack_weight")
+        check(lib.sdy_dhconv(ptr(cs_in), ptr(wp), ptr(cs_out), L, mtr, B, Ci, Co, current_stream()), "sdy_dhconv")
+    out = torch.zeros(B, Co, L, M, 2, dtype=torch.float32, device=x.device)
+    out[:, :, :, :mtr] = cs_out.permute(2, 4, 0, 1, 3)
+    tri = (torch.arange(M, device=x.device)[None, :] <= torch.arange(L, device=x.device)[:, None])
+    out = out * tri[None, None, :, :, None]
+    return torch.view_as_complex(out.contiguous())
+
+
+def instnorm_coeffs(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                    scale_shift: Optional[torch.Tensor] = None, eps: float = 1e-6):
+    """Per-(b,c) coefficients (a, d) with InstanceNorm2d(x)*(1+scale)+shift == a*x+d
+    (`src/models/sfno/sfnonet.py:280-299,641-648`).  scale_shift: (B, 2C) = (scale | shift) or None."""
+    x = _f32c(x)
+    B, Cc, H, W = x.shape
+    a = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    d = torch.empty_like(a)
+    g, b_ = _f32c(gamma), _f32c(beta)
+    ss = _f32c(scale_shift) if scale_shift is not None else None
+    with torch.cuda.device(x.device):
+        check(lib.sdy_instnorm_coeffs(ptr(x), B, Cc, H * W, ptr(g), ptr(b_), ptr(ss), 2 * Cc, eps, ptr(a), ptr(d),
+                                      current_stream()), "sdy_instnorm_coeffs")
+    return a, d
+
+
+def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+            pre_affine=None, add: Optional[torch.Tensor] = None, add_mode: int = 0, gelu: bool = False,
+            drop_p: float = 0.0, keep_mask: Optional[torch.Tensor] = None, seed: int = 0, call: int = 0,
+            stream_id: int = 0, batch_offset: int = 0, batch_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Conv2d(kernel_size=1) with the block's fused prologue/epilogue (see include/sdy_amd.h, sdy_conv1x1).
+    x (B,Cin,H,W), weight (Cout,Cin[,1,1])."""
+    x = _f32c(x)
+    B, Cin, H, W = x.shape
+    w2 = weight.detach().to(torch.float32).reshape(weight.shape[0], -1)
+    Cout = w2.shape[0]
+    assert w2.shape[1] == Cin
+    ldw = (Cout + 3) // 4 * 4
+    wt = torch.zeros(Cin, ldw, dtype=torch.float32, device=x.device)
+    wt[:, :Cout] = w2.t().to(x.device)
+    out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    a = SdyConvArgs()
+    a.x, a.x_bstride = ptr(x), Cin * H * W
+    a.wt, a.ldw = ptr(wt), ldw
+    a.out, a.out_bstride = ptr(out), Cout * H * W
+    a.B, a.Cin, a.Cout, a.HW = B, Cin, Cout, H * W
+    keep = [x, wt, out]
+    if pre_affine is not None:
+        pa, pd = _f32c(pre_affine[0]), _f32c(pre_affine[1])
+        a.pa, a.pd = ptr(pa), ptr(pd)
+        keep += [pa, pd]
+    if bias is not None:
+        bb = _f32c(bias)
+        a.bias = ptr(bb)
+        keep.append(bb)
+    if add is not None:
+        ad = _f32c(add)
+        a.add = ptr(ad)
+        a.add_bstride = 0 if ad.shape[0] == 1 and B > 1 else Cout * H * W
+        a.add_mode = add_mode
+        keep.append(ad)
+    a.act = 1 if gelu else 0
+    a.drop_p = drop_p
+    if keep_mask is not None:
+        km = _f32c(keep_mask)
+        a.keep_mask = ptr(km)
+        keep.append(km)
+    a.seed, a.call, a.stream_id, a.batch_offset = seed, call, stream_id, batch_offset
+    if batch_scale is not None:
+        bs = _f32c(batch_scale)
+        a.batch_scale = ptr(bs)
+        keep.append(bs)
+    with torch.cuda.device(x.device):
+        check(lib.sdy_conv1x1(C.byref(a), current_stream()), "sdy_conv1x1")
+    return out
+
+
+def cold_update(x_s: torch.Tensor, x_ip_next: torch.Tensor, x_ip_s: Optional[torch.Tensor]) -> torch.Tensor:
+    """x_s + (x_ip_next - x_ip_s)  (`src/diffusion/dyffusion.py:517-519`); x_ip_s None means x_ip_s == x_s."""
+    a, b = _f32c(x_s), _f32c(x_ip_next)
+    c = _f32c(x_ip_s) if x_ip_s is not None else None
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        check(lib.sdy_cold_update(ptr(a), ptr(b), ptr(c), ptr(out), a.numel(), current_stream()), "sdy_cold_update")
+    return out
+
+
+def concat_channels(tensors) -> torch.Tensor:
+    """torch.cat(tensors, dim=1) for up to 4 NCHW float32 tensors (`src/diffusion/dyffusion.py:655-661`)."""
+    ts = [_f32c(t) for t in tensors]
+    if len(ts) == 1:
+        return ts[0]
+    assert 1 <= len(ts) <= 4
+    B, _, H, W = ts[0].shape
+    chans = [t.shape[1] for t in ts]
+    out = torch.empty(B, sum(chans), H, W, dtype=torch.float32, device=ts[0].device)
+    srcs = (C.c_void_p * len(ts))(*[ptr(t) for t in ts])
+    ch = (C.c_int * len(ts))(*chans)
+    with torch.cuda.device(out.device):
+        check(lib.sdy_concat_channels(srcs, ch, len(ts), ptr(out), B, H * W, current_stream()), "sdy_concat_channels")
+    return out

@@ -1,0 +1,324 @@
+"""`SphericalFourierNeuralOperatorNet` on the MI355X-native library.
+
+Drop-in for the reference network (`src/models/sfno/sfnonet.py:340-841`) in the configuration its shipped YAML
+selects (`src/configs/model/sfno.yaml`): same constructor keywords (the ones that matter for inference), same
+`state_dict` names and shapes, same `forward(inputs, time=, condition=, static_condition=)`
+and `predict_forward`, same inference-dropout toggles (`src/models/_base_model.py:273-295`).  The whole forward is
+ONE native call (`sdy_sfno_forward`) that enqueues every HIP kernel on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from contextlib import contextmanager
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import SdySfnoConfig, SdySfnoFwdArgs, check, current_stream, lib, ptr
+
+
+class SphericalFourierNeuralOperatorNet(nn.Module):
+    def __init__(
+        self,
+        num_input_channels: int,
+        num_output_channels: int,
+        num_conditional_channels: int = 0,
+        spatial_shape_in=(180, 360),
+        spectral_transform: str = "sht",
+        filter_type: str = "linear",
+        operator_type: str = "dhconv",
+        scale_factor: int = 1,
+        embed_dim: int = 256,
+        num_layers: int = 8,
+        use_mlp: bool = True,
+        mlp_ratio: float = 2.0,
+        activation_function: str = "gelu",
+        encoder_layers: int = 1,
+        pos_embed: bool = True,
+        dropout_mlp: float = 0.0,
+        drop_path_rate: float = 0.0,
+        normalization_layer: str = "instance_norm",
+        hard_thresholding_fraction: float = 1.0,
+        big_skip: bool = True,
+        factorization=None,
+        separable: bool = False,
+        with_time_emb: bool = False,
+        time_dim_mult: int = 2,
+        time_rescale: bool = False,
+        time_scale_shift_before_filter: bool = True,
+        data_grid: str = "equiangular",
+        seed: int = 0,
+        **unused,
+    ):
+        super().__init__()
+        unsupported = []
+        if spectral_transform != "sht": unsupported.append(f"spectral_transform={spectral_transform}")
+        if filter_type != "linear": unsupported.append(f"filter_type={filter_type}")
+        if operator_type != "dhconv": unsupported.append(f"operator_type={operator_type}")
+        if scale_factor != 1: unsupported.append(f"scale_factor={scale_factor}")
+        if not use_mlp: unsupported.append("use_mlp=False")
+        if activation_function != "gelu": unsupported.append(f"activation_function={activation_function}")
+        if encoder_layers != 1: unsupported.append(f"encoder_layers={encoder_layers}")
+        if normalization_layer != "instance_norm": unsupported.append(f"normalization_layer={normalization_layer}")
+        if factorization is not None or separable: unsupported.append("factorized/separable weights")
+        if time_rescale: unsupported.append("time_rescale=True")
+        if with_time_emb and not time_scale_shift_before_filter: unsupported.append("time_scale_shift_before_filter=False")
+        if unsupported:
+            raise NotImplementedError("outside the hot-path scope (SURVEY.md section 8): " + ", ".join(unsupported))
+
+        self.num_input_channels = num_input_channels
+        self.num_output_channels = num_output_channels
+        self.num_conditional_channels = num_conditional_channels
+        self.img_shape = tuple(spatial_shape_in)
+        self.in_chans = num_input_channels + num_conditional_channels     # sfnonet.py:486-490
+        self.out_chans = num_output_channels
+        self.embed_dim = embed_dim
+        self.num_layers = num_layers
+        self.mlp_hidden = int(embed_dim * mlp_ratio)
+        self.dropout_mlp = float(dropout_mlp)
+        self.drop_path_rate = float(drop_path_rate)
+        self.big_skip = bool(big_skip)
+        self.use_pos_embed = bool(pos_embed)
+        self.with_time_emb = bool(with_time_emb)
+        self.time_dim = embed_dim * time_dim_mult if with_time_emb else 0
+        self.data_grid = data_grid
+        nlat, nlon = self.img_shape
+        self.h, self.w = nlat // scale_factor, nlon // scale_factor
+        self.modes_lat = int(self.h * hard_thresholding_fraction)           # sfnonet.py:526-527
+        self.modes_lon = int((self.w // 2 + 1) * hard_thresholding_fraction)
+        self.min_time: Optional[float] = None
+        self.max_time: Optional[float] = None
+        self.inference_dropout = False
+        self.seed = int(seed)
+        self.batch_offset = 0           # global index of the first trajectory this rank owns
+        self._call = 0                  # advances the dropout stream on every forward
+
+        E, T, H, Cin, L = embed_dim, self.time_dim, self.mlp_hidden, self.in_chans, self.modes_lat
+        P = lambda *s: nn.Parameter(torch.zeros(*s), requires_grad=False)  # noqa: E731
+        self.encoder = nn.ModuleDict()  # names below reproduce nn.Sequential indices of the reference
+        self._params: Dict[str, nn.Parameter] = {}
+
+        def reg(name, *shape):
+            p = P(*shape)
+            self.register_parameter(name.replace(".", "__"), p)
+            self._params[name] = p
+            return p
+
+        reg("encoder.0.weight", E, Cin, 1, 1); reg("encoder.0.bias", E); reg("encoder.2.weight", E, E, 1, 1)
+        if self.use_pos_embed:
+            reg("pos_embed", 1, E, nlat, nlon)
+        if with_time_emb:
+            reg("time_emb_mlp.1.weight", T, E); reg("time_emb_mlp.1.bias", T)
+            reg("time_emb_mlp.3.weight", T, T); reg("time_emb_mlp.3.bias", T)
+        self._fc2 = "mlp.fwd.3" if self.dropout_mlp > 0.0 else "mlp.fwd.2"    # layers.py:76-80
+        for i in range(num_layers):
+            p = f"blocks.{i}."
+            reg(p + "norm0.weight", E); reg(p + "norm0.bias", E)
+            if with_time_emb:
+                reg(p + "time_mlp.1.weight", 2 * E, T); reg(p + "time_mlp.1.bias", 2 * E)
+            reg(p + "filter.filter.weight", E, E, L, 2); reg(p + "filter.filter.bias", 1, E, 1, 1)
+            reg(p + "inner_skip.weight", E, E, 1, 1); reg(p + "inner_skip.bias", E)
+            reg(p + "norm1.weight", E); reg(p + "norm1.bias", E)
+            reg(p + "mlp.fwd.0.weight", H, E, 1, 1); reg(p + "mlp.fwd.0.bias", H)
+            reg(p + self._fc2 + ".weight", E, H, 1, 1); reg(p + self._fc2 + ".bias", E)
+        dec_in = E + (Cin if big_skip else 0)
+        reg("decoder.0.weight", E, dec_in, 1, 1); reg("decoder.0.bias", E); reg("decoder.2.weight", self.out_chans, E, 1, 1)
+        # nn.InstanceNorm2d default init
+        for i in range(num_layers):
+            for nme in ("norm0", "norm1"):
+                self._params[f"blocks.{i}.{nme}.weight"].data.fill_(1.0)
+
+        self._native: Dict[int, C.c_void_p] = {}   # device index -> sdy_sfno*
+        self._native_dirty = True
+        self._ws: Dict[tuple, torch.Tensor] = {}
+
+    # ---- state_dict with the reference's names ------------------------------------------------------------
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = destination if destination is not None else {}
+        for k, v in self._params.items():
+            out[prefix + k] = v if keep_vars else v.detach()
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        missing, unexpected = [], []
+        for k, p in self._params.items():
+            if k in state_dict:
+                v = state_dict[k]
+                if tuple(v.shape) != tuple(p.shape):
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(p.shape)}")
+                p.data.copy_(v.detach().to(torch.float32))
+            else:
+                missing.append(k)
+        for k in state_dict:
+            if k not in self._params:
+                if ".weights" in k or ".pct" in k:   # persistent SHT buffers of old torch-harmonics (Appendix A.5)
+                    continue
+                unexpected.append(k)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing={missing[:5]}... unexpected={unexpected[:5]}...")
+        self._native_dirty = True
+        return missing, unexpected
+
+    # ---- reference helpers ----------------------------------------------------------------------------------
+    def set_min_max_time(self, min_time: float, max_time: float):     # sfnonet.py:761-773
+        self.min_time, self.max_time = float(min_time), float(max_time)
+
+    def enable_inference_dropout(self):                               # _base_model.py:288-290
+        self.inference_dropout = True
+
+    def disable_inference_dropout(self):                              # _base_model.py:292-294
+        self.inference_dropout = False
+
+    @contextmanager
+    def inference_dropout_scope(self, condition: bool, context=None):  # _base_model.py:273-286
+        assert isinstance(condition, bool), f"Condition must be a boolean, got {condition}"
+        if condition:
+            self.enable_inference_dropout()
+        try:
+            yield None
+        finally:
+            if condition:
+                self.disable_inference_dropout()
+
+    # ---- native object --------------------------------------------------------------------------------------
+    def _cfg(self) -> SdySfnoConfig:
+        c = SdySfnoConfig()
+        c.nlat, c.nlon = self.img_shape
+        c.in_chans, c.out_chans = self.in_chans, self.out_chans
+        c.embed_dim, c.num_layers, c.mlp_hidden = self.embed_dim, self.num_layers, self.mlp_hidden
+        c.lmax, c.mmax = self.modes_lat, self.modes_lon
+        c.data_grid = _lib.SDY_GRID[self.data_grid]
+        c.with_time_emb, c.time_dim = int(self.with_time_emb), self.time_dim
+        c.dropout_mlp, c.drop_path_rate = self.dropout_mlp, self.drop_path_rate
+        c.big_skip, c.pos_embed = int(self.big_skip), int(self.use_pos_embed)
+        return c
+
+    def _get_native(self, device: torch.device) -> C.c_void_p:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self._native_dirty:
+            for h in self._native.values():
+                lib.sdy_sfno_destroy(h)
+            self._native.clear()
+            self._native_dirty = False
+        if idx not in self._native:
+            with torch.cuda.device(idx):
+                h = C.c_void_p()
+                cfg = self._cfg()
+                check(lib.sdy_sfno_create(C.byref(cfg), C.byref(h)), "sdy_sfno_create")
+                for name, p in self._params.items():
+                    t = p.detach().to("cpu", torch.float32).contiguous()
+                    check(lib.sdy_sfno_set_param(h, name.encode(), ptr(t), t.numel()), f"sdy_sfno_set_param({name})")
+                if self.with_time_emb:   # exactly the table SinusoidalPosEmb builds (misc.py:26-29)
+                    half = self.embed_dim // 2
+                    f = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).contiguous()
+                    check(lib.sdy_sfno_set_param(h, b"@time_freq", ptr(f), half))
+                dpr = torch.linspace(0, self.drop_path_rate, self.num_layers).to(torch.float32).contiguous()  # sfnonet.py:622
+                check(lib.sdy_sfno_set_param(h, b"@drop_path_rates", ptr(dpr), self.num_layers))
+                rc = lib.sdy_sfno_ready(h)
+                if rc != 0:
+                    raise _lib.SdyError(f"native SFNO not ready, missing {lib.sdy_sfno_missing(h).decode()}")
+                self._native[idx] = h
+        return self._native[idx]
+
+    def _workspace(self, h, device, B):
+        key = (device.index, B)
+        if key not in self._ws:
+            n = lib.sdy_sfno_workspace_floats(h, B)
+            self._ws[key] = torch.empty(n, dtype=torch.float32, device=device)
+        return self._ws[key]
+
+    def __del__(self):
+        try:
+            for h in self._native.values():
+                lib.sdy_sfno_destroy(h)
+        except Exception:
+            pass
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    def forward(self, inputs, time=None, condition=None, static_condition=None, return_time_emb: bool = False,
+                keep_masks=None, drop_path_keep=None, **kwargs):
+        if return_time_emb:
+            raise NotImplementedError("return_time_emb is a training-path feature")
+        if not inputs.is_cuda:
+            raise RuntimeError("sdy_amd SFNO runs on the GPU only (no CPU fallback); move inputs to cuda")
+        dev = inputs.device
+        # concat_condition_if_needed (_base_model.py:166-192): same checks, concat happens inside the native call
+        if self.num_conditional_channels > 0:
+            if condition is None and static_condition is None:
+                raise ValueError(f"condition and static_condition are both None but num_conditional_channels is "
+                                 f"{self.num_conditional_channels}")
+        else:
+            assert condition is None, "condition is not None but num_conditional_channels is 0"
+            assert static_condition is None, "static_condition is not None but num_conditional_channels is 0"
+        pieces = [t.to(torch.float32).contiguous() for t in (inputs, condition, static_condition) if t is not None]
+        B = inputs.shape[0]
+        nlat, nlon = self.img_shape
+        for t in pieces:
+            assert t.shape[0] == B and tuple(t.shape[-2:]) == (nlat, nlon), f"bad input shape {tuple(t.shape)}"
+        if sum(t.shape[1] for t in pieces) != self.in_chans:
+            raise RuntimeError(f"inputs.shape: {tuple(inputs.shape)}, expected {self.in_chans} channels in total, got "
+                               f"{[t.shape[1] for t in pieces]}")
+        tt = None
+        if self.with_time_emb:
+            assert self.min_time is not None and self.max_time is not None, \
+                "min_time and max_time must be set before using time embedding"          # sfnonet.py:777-779
+            assert time is not None, "time is required when with_time_emb=True"
+            tt = torch.as_tensor(time, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+            if tt.numel() == 1 and B > 1:
+                tt = tt.expand(B).contiguous()
+            assert tt.numel() == B
+            if isinstance(time, (int, float)) or not torch.is_tensor(time) or not time.is_cuda:
+                # host-side range check (the reference's device assert at sfnonet.py:780-782 forces a sync;
+                # device-resident times are range-checked by the sampler, which builds them on the host)
+                tv = torch.as_tensor(time, dtype=torch.float32).reshape(-1)
+                assert (self.min_time <= tv).all() and (tv <= self.max_time).all(), \
+                    f"time must be in [{self.min_time}, {self.max_time}], but time is {tv}"
+
+        h = self._get_native(dev)
+        ws = self._workspace(h, dev, B)
+        out = torch.empty(B, self.out_chans, nlat, nlon, dtype=torch.float32, device=dev)
+        a = SdySfnoFwdArgs()
+        for i in range(3):
+            a.in_[i] = ptr(pieces[i]) if i < len(pieces) else None
+            a.in_chans[i] = pieces[i].shape[1] if i < len(pieces) else 0
+        a.time, a.out, a.B = ptr(tt), ptr(out), B
+        a.enable_dropout = int(self.inference_dropout)
+        a.seed, a.call, a.batch_offset = self.seed, self._call & 0xFFFFFFFF, self.batch_offset
+        keep = []
+        if keep_masks is not None:
+            arr = (C.c_void_p * (2 * self.num_layers))()
+            for j, m in enumerate(keep_masks):
+                if m is not None:
+                    mm = m.to(dev, torch.float32).contiguous()
+                    keep.append(mm)
+                    arr[j] = ptr(mm)
+            a.keep_masks = C.cast(arr, C.POINTER(C.c_void_p))
+            keep.append(arr)
+        if drop_path_keep is not None:   # (num_layers, B) keep flags
+            dk = drop_path_keep.to(dev, torch.float32).contiguous()
+            assert dk.shape == (self.num_layers, B)
+            keep.append(dk)
+            a.drop_path_keep = ptr(dk)
+        a.ws, a.ws_floats = ptr(ws), ws.numel()
+        with torch.cuda.device(dev):
+            check(lib.sdy_sfno_forward(h, C.byref(a), current_stream()), "sdy_sfno_forward")
+        self._call += 1
+        return out
+
+    def predict_forward(self, *inputs, metadata=None, **kwargs):      # _base_model.py:265-270
+        return self(*inputs, **kwargs)
+
+    def time_embedding(self, time: torch.Tensor):
+        """(t_repr (B,T), scale_shift (B, L, 2E)) exactly as the fused forward computes them (parity tap)."""
+        dev = time.device
+        h = self._get_native(dev)
+        B = time.numel()
+        tt = time.to(torch.float32).contiguous()
+        trep = torch.empty(B, self.time_dim, dtype=torch.float32, device=dev)
+        ss = torch.empty(B, self.num_layers, 2 * self.embed_dim, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.sdy_sfno_time_embed(h, ptr(tt), B, ptr(trep), ptr(ss), current_stream()), "sdy_sfno_time_embed")
+        return trep, ss

@@ -1,0 +1,97 @@
+"""Sampler-level parity: DYffusion.sample / get_preds_at_t_for_batch vs the oracle restatement of sample_loop."""
+import pytest
+import torch
+
+from conftest import rel_l2
+from helpers import PhiloxMasks, make_pair
+from oracle.dyffusion import OracleDYffusion
+from oracle.sfno import SFNOConfig
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _build(hack=False, dropout=True, nlat=32, nlon=64, E=16, L=2, C=6, n_forc=2, horizon=6, seed_f=11, seed_i=22):
+    import sdy_amd
+
+    cs = C + (1 if hack else 0)   # state channels carried by the sampler
+    fcfg = SFNOConfig(in_chans=cs + n_forc, out_chans=C, nlat=nlat, nlon=nlon, embed_dim=E, num_layers=L,
+                      with_time_emb=True, min_time=0.0, max_time=float(horizon - 1))
+    icfg = SFNOConfig(in_chans=2 * cs + n_forc, out_chans=C, nlat=nlat, nlon=nlon, embed_dim=E, num_layers=L,
+                      with_time_emb=True, dropout_mlp=0.1 if dropout else 0.0, drop_path_rate=0.1 if dropout else 0.0,
+                      min_time=1.0, max_time=float(horizon - 1))
+    fnet, fora, _ = make_pair(fcfg, cs, n_forc, seed=seed_f)
+    inet, iora, _ = make_pair(icfg, 2 * cs, n_forc, seed=seed_i, net_seed=4242)
+    ipol = sdy_amd.InterpolationExperiment(inet, horizon=horizon)
+    exp = sdy_amd.MultiHorizonForecastingDYffusion(
+        fnet, ipol, horizon=horizon,
+        diffusion_config=dict(hack_for_imprecise_interpolation=hack, enable_interpolator_dropout=dropout))
+    masks = PhiloxMasks(icfg, seed=4242)
+    calls = {"n": 0}
+
+    def ora_f(x, time, condition=None, static_condition=None):
+        return fora(x, time=time, condition=condition, static_condition=static_condition)
+
+    def ora_i(x, time, condition=None, static_condition=None):
+        masks.call = calls["n"]
+        calls["n"] += 1
+        return iora(x, time=time, condition=condition, static_condition=static_condition,
+                    mask_fn=masks if dropout else None)
+
+    oracle = OracleDYffusion(ora_f, ora_i, timesteps=horizon, hack_for_imprecise_interpolation=hack)
+    return exp, oracle, cs, n_forc
+
+
+@pytest.mark.parametrize("hack", [False, True])
+def test_sample_matches_oracle(hack):
+    exp, oracle, cs, n_forc = _build(hack=hack)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    B = 2
+    x0 = torch.randn(B, cs, 32, 64, generator=g)
+    if hack:   # run_inference path: forcings arrive as static_condition (stepper_multistep.py:383-384)
+        kw = {"static_condition": torch.randn(B, n_forc, 32, 64, generator=g)}
+    else:      # Lightning path: dynamical_condition (B, T+1, Cc, H, W)
+        kw = {"dynamical_condition": torch.randn(B, 7, n_forc, 32, 64, generator=g)}
+    ref = oracle.sample(x0, **kw)
+    got = exp.model.sample(x0.cuda(), **{k: v.cuda() for k, v in kw.items()})
+    assert sorted(got.keys()) == sorted(ref.keys()) == [f"t{i}_preds" for i in range(1, 7)]
+    for k in ref:
+        err = rel_l2(got[k], ref[k])
+        assert got[k].shape == ref[k].shape
+        assert err < TOL, f"{k} (hack={hack}): rel L2 {err:.3e}"
+
+
+def test_get_preds_at_t_for_batch_surface():
+    """The stepper's call pattern (stepper_multistep.py:365-427): horizon 1 computes, 2..6 pop the cache."""
+    exp, oracle, cs, n_forc = _build(hack=True)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x0 = torch.randn(1, cs, 32, 64, generator=g)
+    sc = torch.randn(1, n_forc, 32, 64, generator=g)
+    ref = oracle.sample(x0, static_condition=sc)
+    for h in range(1, 7):
+        batch = {"dynamics": x0.cuda(), "static_condition": sc.cuda()}
+        with exp.ema_scope(), exp.inference_dropout_scope():
+            out = exp.get_preds_at_t_for_batch(batch, horizon=h, split="predict", is_autoregressive=False,
+                                               prepare_inputs=False, ensemble=False, num_predictions=1)
+        assert list(out.keys()) == [f"t{h}_preds_normed"]
+        err = rel_l2(out[f"t{h}_preds_normed"], ref[f"t{h}_preds"])
+        assert err < TOL, f"h={h}: rel L2 {err:.3e}"
+    assert exp._current_preds is None
+    with pytest.raises(AssertionError):
+        exp.get_preds_at_t_for_batch({"dynamics": x0.cuda()}, horizon=7, split="predict", prepare_inputs=False)
+
+
+def test_call_trace_is_16_forwards():
+    """6 forecaster + 10 interpolator calls per horizon-6 pass, in the reference's order."""
+    exp, _, cs, n_forc = _build(hack=False, dropout=False)
+    trace = []
+    f_net, i_net = exp.model.model, exp.model.interpolator.model
+    f_orig, i_orig = f_net.forward, i_net.forward
+    f_net.forward = lambda *a, **k: (trace.append(("F", float(k["time"][0]))), f_orig(*a, **k))[1]
+    i_net.forward = lambda *a, **k: (trace.append(("I", float(k["time"][0]))), i_orig(*a, **k))[1]
+    x0 = torch.randn(1, cs, 32, 64).cuda()
+    exp.model.sample(x0, dynamical_condition=torch.randn(1, 7, n_forc, 32, 64).cuda())
+    expect = [("F", 0.0), ("I", 1.0), ("F", 1.0), ("I", 2.0), ("I", 1.0), ("F", 2.0), ("I", 3.0), ("I", 2.0),
+              ("F", 3.0), ("I", 4.0), ("I", 3.0), ("F", 4.0), ("I", 5.0), ("I", 4.0), ("F", 5.0), ("I", 5.0)]
+    assert trace == expect

@@ -1,0 +1,187 @@
+"""Per-op parity of the HIP kernels against the CPU oracle (all through the C ABI via the host wrappers).
+
+Tolerances (fp32 path; north_star bound is 1e-4 relative L2 end to end):
+  single op      : 2e-6 relative L2  (fp32 FMA-chain GEMMs / FFT vs torch CPU fp32)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_OP = 2e-6
+GRIDS = [(32, 64), (180, 360)]
+
+
+@pytest.fixture(scope="module")
+def sdy():
+    import sdy_amd
+
+    return sdy_amd
+
+
+def _gen(seed):
+    return torch.Generator(device="cpu").manual_seed(seed)
+
+
+@pytest.mark.parametrize("grid", ["equiangular", "legendre-gauss"])
+@pytest.mark.parametrize("nlat,nlon", GRIDS)
+def test_real_sht_forward(sdy, nlat, nlon, grid):
+    from oracle.sht import RealSHT as ORef
+
+    C = 8 if nlat > 64 else 12
+    x = torch.randn(2, C, nlat, nlon, generator=_gen(1))
+    ref = ORef(nlat, nlon, lmax=nlat, mmax=nlon // 2 + 1, grid=grid).float()(x)
+    got = sdy.RealSHT(nlat, nlon, lmax=nlat, mmax=nlon // 2 + 1, grid=grid).float()(x.cuda())
+    assert got.shape == ref.shape and got.dtype == torch.complex64
+    err = rel_l2(got, ref)
+    assert err < TOL_OP, f"RealSHT {nlat}x{nlon} {grid}: rel L2 {err:.3e}"
+    # structural zeros (m > l) must be exact zeros
+    l = torch.arange(nlat)[:, None]
+    m = torch.arange(nlon // 2 + 1)[None, :]
+    assert (got.cpu()[..., (m > l)] == 0).all()
+
+
+@pytest.mark.parametrize("grid", ["equiangular", "legendre-gauss"])
+@pytest.mark.parametrize("nlat,nlon", GRIDS)
+def test_inverse_real_sht(sdy, nlat, nlon, grid):
+    from oracle.sht import InverseRealSHT as ORef
+
+    C = 8 if nlat > 64 else 12
+    L, M = nlat, nlon // 2 + 1
+    c = torch.randn(2, C, L, M, dtype=torch.complex64, generator=_gen(2))  # dense, incl. m > l and imag of m = 0
+    ref = ORef(nlat, nlon, lmax=L, mmax=M, grid=grid).float()(c)
+    got = sdy.InverseRealSHT(nlat, nlon, lmax=L, mmax=M, grid=grid).float()(c.cuda())
+    err = rel_l2(got, ref)
+    assert err < TOL_OP, f"InverseRealSHT {nlat}x{nlon} {grid}: rel L2 {err:.3e}"
+
+
+def test_sht_roundtrip_bandlimited(sdy):
+    """size-independent property at the full grid: SHT(ISHT(c)) == c for band-limited c on the Gauss grid."""
+    nlat, nlon = 180, 360
+    L, M = nlat, nlon // 2 + 1
+    c = torch.randn(1, 4, L, M, dtype=torch.complex64, generator=_gen(3))
+    l = torch.arange(L)[:, None]
+    m = torch.arange(M)[None, :]
+    c = c * (m <= l)
+    c[..., 0] = c[..., 0].real + 0j
+    isht = sdy.InverseRealSHT(nlat, nlon, lmax=L, mmax=M, grid="legendre-gauss")
+    sht = sdy.RealSHT(nlat, nlon, lmax=L, mmax=M, grid="legendre-gauss")
+    c2 = sht(isht(c.cuda()))
+    err = rel_l2(c2, c)
+    assert err < 2e-5, f"round trip rel L2 {err:.3e}"
+
+
+@pytest.mark.parametrize("B,E,L,M", [(2, 8, 32, 33), (1, 256, 180, 181), (3, 16, 20, 11)])
+def test_dhconv(sdy, B, E, L, M):
+    g = _gen(4)
+    x = torch.randn(B, E, L, M, dtype=torch.complex64, generator=g)
+    l = torch.arange(L)[:, None]
+    m = torch.arange(M)[None, :]
+    x = x * (m <= l)
+    w = torch.randn(E, E, L, 2, generator=g) / np.sqrt(E)
+    ref = torch.einsum("bixy,iox->boxy", x, torch.view_as_complex(w))
+    got = sdy.ops.contract_dhconv(x.cuda(), w.cuda())
+    err = rel_l2(got, ref)
+    assert err < TOL_OP, f"dhconv rel L2 {err:.3e}"
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 32, 64), (1, 16, 180, 360)])
+def test_instnorm_coeffs(sdy, B, C, H, W):
+    g = _gen(5)
+    x = torch.randn(B, C, H, W, generator=g) * 3 + 1.5
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    ss = 0.3 * torch.randn(B, 2 * C, generator=g)
+    xn = torch.nn.functional.instance_norm(x, weight=gamma, bias=beta, eps=1e-6)
+    scale, shift = ss[:, :, None, None].chunk(2, dim=1)
+    ref = xn * (scale + 1) + shift
+    a, d = sdy.ops.instnorm_coeffs(x.cuda(), gamma.cuda(), beta.cuda(), ss.cuda())
+    got = a.cpu()[:, :, None, None] * x + d.cpu()[:, :, None, None]
+    err = rel_l2(got, ref)
+    assert err < TOL_OP, f"instnorm rel L2 {err:.3e}"
+    a2, d2 = sdy.ops.instnorm_coeffs(x.cuda(), gamma.cuda(), beta.cuda(), None)
+    got2 = a2.cpu()[:, :, None, None] * x + d2.cpu()[:, :, None, None]
+    assert rel_l2(got2, xn) < TOL_OP
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 8, 16, 32, 64), (1, 70, 256, 180, 360), (2, 256, 34, 32, 64),
+                                            (1, 36, 130, 20, 12)])
+def test_conv1x1_plain_and_epilogues(sdy, B, Cin, Cout, H, W):
+    g = _gen(6)
+    F = torch.nn.functional
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = 0.1 * torch.randn(Cout, generator=g)
+    add = torch.randn(B, Cout, H, W, generator=g)
+    pa = 1 + 0.2 * torch.randn(B, Cin, generator=g)
+    pd = 0.2 * torch.randn(B, Cin, generator=g)
+    bs = torch.tensor([0.0, 1.25][:B]) if B == 2 else torch.tensor([1.25])
+    xc = x.cuda()
+    # plain
+    err = rel_l2(sdy.ops.conv1x1(xc, w), F.conv2d(x, w))
+    assert err < TOL_OP, f"plain {err:.3e}"
+    # bias + GELU
+    err = rel_l2(sdy.ops.conv1x1(xc, w, b, gelu=True), F.gelu(F.conv2d(x, w, b)))
+    assert err < TOL_OP, f"bias+gelu {err:.3e}"
+    # pre-activation add (inner skip): GELU(conv + bias + add)
+    err = rel_l2(sdy.ops.conv1x1(xc, w, b, add=add.cuda(), add_mode=1, gelu=True), F.gelu(F.conv2d(x, w, b) + add))
+    assert err < TOL_OP, f"add_pre {err:.3e}"
+    # prologue affine + batch scale + post add (fc2 / residual)
+    xa = x * pa[:, :, None, None] + pd[:, :, None, None]
+    ref = F.conv2d(xa, w, b) * bs[:, None, None, None] + add
+    got = sdy.ops.conv1x1(xc, w, b, pre_affine=(pa.cuda(), pd.cuda()), add=add.cuda(), add_mode=2, batch_scale=bs.cuda())
+    err = rel_l2(got, ref)
+    assert err < TOL_OP, f"affine+scale+add_post {err:.3e}"
+    # broadcast add (pos_embed)
+    pe = torch.randn(1, Cout, H, W, generator=g)
+    if B > 1:
+        err = rel_l2(sdy.ops.conv1x1(xc, w, add=pe.cuda(), add_mode=2), F.conv2d(x, w) + pe)
+        assert err < TOL_OP, f"pos_embed add {err:.3e}"
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 8, 16, 32, 64), (1, 256, 512, 45, 64)])
+def test_conv1x1_dropout_matches_philox_oracle(sdy, B, Cin, Cout, H, W):
+    from oracle.philox import element_keep_mask
+
+    g = _gen(7)
+    F = torch.nn.functional
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = 0.1 * torch.randn(Cout, generator=g)
+    p, seed, call, layer, kind, boff = 0.1, 0x1234567887654321, 7, 3, 1, 5
+    keep = torch.from_numpy(element_keep_mask(seed, call, layer, kind, p, B, Cout, H, W, batch_offset=boff))
+    frac = float(keep.mean())
+    assert abs(frac - 0.9) < 0.01, f"keep fraction {frac}"
+    ref = F.gelu(F.conv2d(x, w, b)) * keep * (1.0 / (1.0 - p))
+    got = sdy.ops.conv1x1(x.cuda(), w, b, gelu=True, drop_p=p, seed=seed, call=call, stream_id=2 * layer + kind,
+                          batch_offset=boff)
+    zero_ref = (ref == 0)
+    zero_got = (got.cpu() == 0)
+    assert (zero_ref == zero_got).all(), f"mask mismatch on {int((zero_ref != zero_got).sum())} elements"
+    assert rel_l2(got, ref) < TOL_OP
+    # injected mask path
+    km = (torch.rand(B, Cout, H, W, generator=g) > 0.3).float()
+    got2 = sdy.ops.conv1x1(x.cuda(), w, b, gelu=True, drop_p=0.3, keep_mask=km.cuda())
+    ref2 = F.gelu(F.conv2d(x, w, b)) * km * (1.0 / (1.0 - 0.3))
+    assert rel_l2(got2, ref2) < TOL_OP
+
+
+def test_cold_update_and_concat(sdy):
+    g = _gen(8)
+    a, b, c = (torch.randn(2, 5, 18, 36, generator=g) for _ in range(3))
+    got = sdy.ops.cold_update(a.cuda(), b.cuda(), c.cuda()).cpu()
+    assert torch.equal(got, a + (b - c))
+    got0 = sdy.ops.cold_update(a.cuda(), b.cuda(), None).cpu()
+    assert torch.equal(got0, a + (b - a))
+    cat = sdy.ops.concat_channels([a.cuda(), b.cuda()[:, :1], c.cuda()]).cpu()
+    assert torch.equal(cat, torch.cat([a, b[:, :1], c], 1))
+
+
+def test_errors_are_reported(sdy):
+    with pytest.raises(sdy.SdyError):
+        sdy.RealSHT(30, 62, grid="equiangular")(torch.zeros(1, 4, 30, 62).cuda())  # nlon % 4 != 0
+    with pytest.raises(RuntimeError):
+        sdy.RealSHT(32, 64)(torch.zeros(1, 4, 32, 64))  # CPU tensor: no fallback

@@ -1,0 +1,134 @@
+"""Network-level parity: the native SFNO forward vs the CPU oracle on identical weights and inputs.
+
+Tolerance: north_star's bound, 1e-4 relative L2 for the full network in fp32 (measured errors are ~1e-6).
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+from helpers import PhiloxMasks, make_pair
+from oracle.sfno import SFNOConfig
+
+pytestmark = pytest.mark.gpu
+
+TOL_NET = 1e-4     # north_star bound
+TOL_TIGHT = 2e-5   # what fp32 MFMA actually achieves, with margin
+
+
+def _inputs(cfg, n_in, n_cond, B, seed=1234):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(B, n_in, cfg.nlat, cfg.nlon, generator=g)
+    cond = torch.randn(B, n_cond, cfg.nlat, cfg.nlon, generator=g) if n_cond else None
+    return x, cond
+
+
+def test_c1_single_block_32x64_e8():
+    """BASELINE.json configs[0]: one SFNO block, 32x64 grid, 8 channels (block 0 == last block: equiangular both ways)."""
+    cfg = SFNOConfig(in_chans=8, out_chans=8, nlat=32, nlon=64, embed_dim=8, num_layers=1, with_time_emb=True,
+                     min_time=0.0, max_time=5.0)
+    net, ora, _ = make_pair(cfg, 8, 0)
+    x, _ = _inputs(cfg, 8, 0, 2)
+    t = torch.tensor([1.0, 4.0])
+    ref = ora(x, time=t)
+    got = net(x.cuda(), time=t.cuda())
+    err = rel_l2(got, ref)
+    assert err < TOL_TIGHT, f"C1 rel L2 {err:.3e}"
+
+
+@pytest.mark.parametrize("data_grid", ["equiangular", "legendre-gauss"])
+def test_tiny_sfno_with_condition_and_time(data_grid):
+    cfg = SFNOConfig(in_chans=10, out_chans=6, nlat=32, nlon=64, embed_dim=16, num_layers=3, with_time_emb=True,
+                     data_grid=data_grid, min_time=0.0, max_time=5.0)
+    net, ora, _ = make_pair(cfg, 8, 2)
+    x, cond = _inputs(cfg, 8, 2, 3)
+    t = torch.tensor([0.0, 2.0, 5.0])
+    ref = ora(x, time=t, condition=cond)
+    got = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
+    err = rel_l2(got, ref)
+    assert err < TOL_TIGHT, f"tiny SFNO ({data_grid}) rel L2 {err:.3e}"
+    # static_condition is the other way the reference feeds forcings (stepper_multistep.py:383-384)
+    got2 = net(x.cuda(), time=t.cuda(), static_condition=cond.cuda())
+    assert torch.equal(got, got2)
+    # time embedding tap
+    trep, ss = net.time_embedding(t.cuda())
+    assert rel_l2(trep, ora.time_repr(t)) < 2e-6
+
+
+def test_tiny_sfno_no_time_no_skip():
+    cfg = SFNOConfig(in_chans=4, out_chans=4, nlat=32, nlon=64, embed_dim=8, num_layers=2, with_time_emb=False,
+                     big_skip=False, pos_embed=False)
+    net, ora, _ = make_pair(cfg, 4, 0)
+    x, _ = _inputs(cfg, 4, 0, 2)
+    err = rel_l2(net(x.cuda()), ora(x))
+    assert err < TOL_TIGHT, f"rel L2 {err:.3e}"
+
+
+def test_tiny_sfno_dropout_stream_matches_oracle():
+    """Interpolator configuration: dropout + drop path ON at inference (dyffusion.py:226-235).  The oracle replays the
+    device Philox stream, so the comparison is exact-mask, not statistical."""
+    cfg = SFNOConfig(in_chans=18, out_chans=8, nlat=32, nlon=64, embed_dim=16, num_layers=4, with_time_emb=True,
+                     dropout_mlp=0.1, drop_path_rate=0.5, min_time=1.0, max_time=5.0)
+    net, ora, _ = make_pair(cfg, 16, 2, net_seed=777)
+    net.batch_offset = 3
+    x, cond = _inputs(cfg, 16, 2, 4)
+    t = torch.tensor([1.0, 2.0, 3.0, 5.0])
+    masks = PhiloxMasks(cfg, seed=777, batch_offset=3)
+    net.enable_inference_dropout()
+    outs = []
+    for call in range(2):   # two calls: the stream must advance
+        masks.call = call
+        ref = ora(x, time=t, condition=cond, mask_fn=masks)
+        got = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
+        err = rel_l2(got, ref)
+        assert err < TOL_TIGHT, f"dropout call {call}: rel L2 {err:.3e}"
+        outs.append(got)
+    assert not torch.equal(outs[0], outs[1]), "dropout stream did not advance between calls"
+    net.disable_inference_dropout()
+    ref_off = ora(x, time=t, condition=cond)
+    assert rel_l2(net(x.cuda(), time=t.cuda(), condition=cond.cuda()), ref_off) < TOL_TIGHT
+
+
+def test_injected_masks():
+    cfg = SFNOConfig(in_chans=8, out_chans=8, nlat=32, nlon=64, embed_dim=8, num_layers=2, with_time_emb=True,
+                     dropout_mlp=0.2, drop_path_rate=0.3, min_time=1.0, max_time=5.0)
+    net, ora, _ = make_pair(cfg, 8, 0)
+    B = 2
+    x, _ = _inputs(cfg, 8, 0, B)
+    t = torch.tensor([1.0, 2.0])
+    g = torch.Generator(device="cpu").manual_seed(5)
+    hid = int(cfg.embed_dim * cfg.mlp_ratio)
+    km = []
+    for i in range(cfg.num_layers):
+        km.append((torch.rand(B, hid, 32, 64, generator=g) > 0.2).float())
+        km.append((torch.rand(B, cfg.embed_dim, 32, 64, generator=g) > 0.2).float())
+    dpk = torch.tensor([[1.0, 1.0], [0.0, 1.0]])   # [layer][b]
+
+    def mask_fn(kind, layer, shape):
+        if kind == "drop_path":
+            return dpk[layer].reshape(-1, 1, 1, 1)
+        return km[2 * layer + (0 if kind == "mlp_hidden" else 1)]
+
+    ref = ora(x, time=t, mask_fn=mask_fn)
+    net.enable_inference_dropout()
+    got = net(x.cuda(), time=t.cuda(), keep_masks=km, drop_path_keep=dpk)
+    err = rel_l2(got, ref)
+    assert err < TOL_TIGHT, f"injected masks rel L2 {err:.3e}"
+
+
+def test_c2_full_size_interpolator_forward():
+    """BASELINE.json configs[1]: interpolator SFNO single step, 180x360, E=256, 8 layers, 68+2 -> 34 channels, B=1."""
+    cfg = SFNOConfig(in_chans=70, out_chans=34, nlat=180, nlon=360, embed_dim=256, num_layers=8, with_time_emb=True,
+                     dropout_mlp=0.1, drop_path_rate=0.1, min_time=1.0, max_time=5.0)
+    net, ora, _ = make_pair(cfg, 68, 2)
+    x, cond = _inputs(cfg, 68, 2, 1)
+    t = torch.tensor([3.0])
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref = ora(x, time=t, condition=cond)                       # dropout off: exact comparison
+    got = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
+    err = rel_l2(got, ref)
+    assert err < TOL_NET, f"C2 full-size rel L2 {err:.3e} (bound 1e-4)"
+    assert err < TOL_TIGHT, f"C2 full-size rel L2 {err:.3e} (fp32-MFMA expectation)"
+    # linearity-free, size-independent sanity at full size: batch consistency (B=2 rows equal B=1 results)
+    x2 = torch.cat([x, x.flip(0)], 0).cuda()
+    got2 = net(x2, time=torch.tensor([3.0, 3.0]).cuda(), condition=torch.cat([cond, cond], 0).cuda())
+    assert torch.equal(got2[0], got[0]) and torch.equal(got2[1], got[0])
