@@ -20,6 +20,11 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.float32).contiguous()
 
 
+def _aux(t: torch.Tensor, dev) -> torch.Tensor:
+    """small side inputs (weights, biases, coefficients) may arrive on the host; move them next to x"""
+    return t.detach().to(dev, torch.float32).contiguous()
+
+
 def contract_dhconv(x: torch.Tensor, weight: torch.Tensor, separable: bool = False,
                     operator_type: str = "dhconv") -> torch.Tensor:
     """`_contract_dense_pytorch(x, weight, separable=False, operator_type="dhconv")`
@@ -57,8 +62,8 @@ def instnorm_coeffs(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
     B, Cc, H, W = x.shape
     a = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
     d = torch.empty_like(a)
-    g, b_ = _f32c(gamma), _f32c(beta)
-    ss = _f32c(scale_shift) if scale_shift is not None else None
+    g, b_ = _aux(gamma, x.device), _aux(beta, x.device)
+    ss = _aux(scale_shift, x.device) if scale_shift is not None else None
     with torch.cuda.device(x.device):
         check(lib.sdy_instnorm_coeffs(ptr(x), B, Cc, H * W, ptr(g), ptr(b_), ptr(ss), 2 * Cc, eps, ptr(a), ptr(d),
                                       current_stream()), "sdy_instnorm_coeffs")
@@ -87,15 +92,15 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     a.B, a.Cin, a.Cout, a.HW = B, Cin, Cout, H * W
     keep = [x, wt, out]
     if pre_affine is not None:
-        pa, pd = _f32c(pre_affine[0]), _f32c(pre_affine[1])
+        pa, pd = _aux(pre_affine[0], x.device), _aux(pre_affine[1], x.device)
         a.pa, a.pd = ptr(pa), ptr(pd)
         keep += [pa, pd]
     if bias is not None:
-        bb = _f32c(bias)
+        bb = _aux(bias, x.device)
         a.bias = ptr(bb)
         keep.append(bb)
     if add is not None:
-        ad = _f32c(add)
+        ad = _aux(add, x.device)
         a.add = ptr(ad)
         a.add_bstride = 0 if ad.shape[0] == 1 and B > 1 else Cout * H * W
         a.add_mode = add_mode
@@ -103,12 +108,12 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     a.act = 1 if gelu else 0
     a.drop_p = drop_p
     if keep_mask is not None:
-        km = _f32c(keep_mask)
+        km = _aux(keep_mask, x.device)
         a.keep_mask = ptr(km)
         keep.append(km)
     a.seed, a.call, a.stream_id, a.batch_offset = seed, call, stream_id, batch_offset
     if batch_scale is not None:
-        bs = _f32c(batch_scale)
+        bs = _aux(batch_scale, x.device)
         a.batch_scale = ptr(bs)
         keep.append(bs)
     with torch.cuda.device(x.device):
