@@ -130,6 +130,8 @@ typedef struct sdy_conv_args {
   const float* keep_mask;            /* dev (B,Cout,HW) 0/1 injected mask (tests) or NULL = Philox stream */
   uint64_t seed; uint32_t call; uint32_t stream_id; uint32_t batch_offset;
   const float* batch_scale;          /* dev [B] or NULL (drop-path scale) */
+  int kernel_tag;                    /* 0 generic; 1 = MLP fc1, 2 = MLP fc2, 3 = inner skip: identical code under a
+                                        distinct symbol name so profilers attribute time per use */
 } sdy_conv_args;
 int sdy_conv1x1(const sdy_conv_args* args, void* stream);
 

@@ -34,6 +34,7 @@ class SdyConvArgs(C.Structure):
         ("keep_mask", C.c_void_p),
         ("seed", C.c_uint64), ("call", C.c_uint32), ("stream_id", C.c_uint32), ("batch_offset", C.c_uint32),
         ("batch_scale", C.c_void_p),
+        ("kernel_tag", C.c_int),
     ]
 
 

@@ -238,6 +238,7 @@ extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
   g.C = a->out; g.ldc = a->HW; g.sC = a->out_bstride;
   g.M = round_up(a->Cout, 4); g.M_store = a->Cout; g.N = a->HW; g.K = a->Cin; g.nbatch = a->B;
   g.tile = a->Cout > 64 ? SDY_TILE_128x128 : SDY_TILE_64x128;
+  g.tag = (a->kernel_tag >= 1 && a->kernel_tag <= 3) ? a->kernel_tag : 0;
   g.pa = a->pa; g.pd = a->pd; g.p_bstride = a->Cin;
   g.bias = a->bias;
   g.add = a->add_mode ? a->add : nullptr; g.sAdd = a->add_bstride; g.ldadd = a->HW; g.add_mode = a->add_mode;
@@ -628,7 +629,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
     conv_reset();
     cv.x = xn; cv.x_bstride = (long)E * HW; cv.wt = bw.skw.p; cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
-    cv.Cin = E; cv.Cout = E; cv.bias = bw.skb.p; cv.add = y; cv.add_bstride = (long)E * HW; cv.add_mode = 1; cv.act = 1;
+    cv.Cin = E; cv.Cout = E; cv.bias = bw.skb.p; cv.add = y; cv.add_bstride = (long)E * HW; cv.add_mode = 1; cv.act = 1; cv.kernel_tag = 3;
     SDY_TRY(sdy_conv1x1(&cv, stream));
     // norm1 (sfnonet.py:313-320) folded into the fc1 prologue
     SDY_TRY(sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca, cd, stream));
@@ -636,7 +637,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     const float pm = (drop && c.dropout_mlp > 0.f) ? c.dropout_mlp : 0.f;
     conv_reset();
     cv.x = y; cv.x_bstride = (long)E * HW; cv.wt = bw.w1.p; cv.ldw = Hd; cv.out = hid; cv.out_bstride = (long)Hd * HW;
-    cv.Cin = E; cv.Cout = Hd; cv.pa = ca; cv.pd = cd; cv.bias = bw.b1.p; cv.act = 1;
+    cv.Cin = E; cv.Cout = Hd; cv.pa = ca; cv.pd = cd; cv.bias = bw.b1.p; cv.act = 1; cv.kernel_tag = 1;
     cv.drop_p = pm; cv.stream_id = 2u * i; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i] : nullptr;
     SDY_TRY(sdy_conv1x1(&cv, stream));
     // fc2 + dropout, DropPath, + residual (sfnonet.py:325-335)
@@ -644,7 +645,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;
     conv_reset();
     cv.x = hid; cv.x_bstride = (long)Hd * HW; cv.wt = bw.w2.p; cv.ldw = E; cv.out = dst; cv.out_bstride = dst_bs;
-    cv.Cin = Hd; cv.Cout = E; cv.bias = bw.b2.p;
+    cv.Cin = Hd; cv.Cout = E; cv.bias = bw.b2.p; cv.kernel_tag = 2;
     cv.drop_p = pm; cv.stream_id = 2u * i + 1u; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i + 1] : nullptr;
     if (drop && n->tm.dp_rate[i] > 0.f) cv.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
     cv.add = xn; cv.add_bstride = (long)E * HW; cv.add_mode = 2;

@@ -73,6 +73,7 @@ struct GemmParams {
   int cplx_Ei, cplx_Eo;
   int tri_mode, tri_B;
   int tile;
+  int tag;             // profiler label only (see gemm.hip)
   // prologue affine on B rows
   const float* pa; const float* pd; long p_bstride;
   // epilogue
