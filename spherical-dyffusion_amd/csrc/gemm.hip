@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   const float* __restrict__ pd = p.pd ? p.pd + (long)z * p.p_bstride : nullptr;
 
   f32x4 ra[NA], rb[NB];
+  float pa_r[NB], pd_r[NB];  // prologue affine of each staged B row, applied at LDS-store time so that the
+                             // global loads stay in flight under the MFMAs (no dependent math in load_tile)
   f32x16 acc[WM][WN];
 #pragma unroll
   for (int i = 0; i < WM; ++i)
@@ -84,12 +86,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
       const int row = idx / (BN / 4), c4 = idx % (BN / 4);
       const int gk = k0 + row, gn = n0 + c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      pa_r[i] = 0.f;
+      pd_r[i] = 0.f;
       if (gk >= k_lo && gk < k_hi && gn < p.N) {
         if constexpr (!B_CPLX) {
           v = *reinterpret_cast<const f32x4*>(Bg + (long)gk * p.ldb + gn);
           if (pa) {
-            const float a = pa[gk], d = pd[gk];
-            v = v * a + d;
+            pa_r[i] = pa[gk];
+            pd_r[i] = pd[gk];
           }
         } else {
           // expanded real form of the complex weight: rows (ri_in, i), cols (ri_out, o):
@@ -125,7 +129,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     for (int i = 0; i < NB; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (BN / 4), c4 = idx % (BN / 4);
-      *reinterpret_cast<f32x4*>(bs + row * LDB_S + c4 * 4) = rb[i];
+      f32x4 v = rb[i];
+      if constexpr (!B_CPLX) {
+        if (pa) v = v * pa_r[i] + pd_r[i];
+      }
+      *reinterpret_cast<f32x4*>(bs + row * LDB_S + c4 * 4) = v;
     }
   };
 
@@ -145,17 +153,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 
     const float* as = As + buf * A_TILE + wr * (32 * WM) + l31;
     const float* bs = Bs + buf * B_TILE + wc * (32 * WN) + l31;
+    // software-pipelined fragment reads: the ds_reads of k-pair kp+1 are issued before the MFMAs of k-pair kp
+    float a_cur[WM], b_cur[WN], a_nxt[WM], b_nxt[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a_cur[i] = as[h * LDA_S + i * 32];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b_cur[j] = bs[h * LDB_S + j * 32];
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
-      float a[WM], b[WN];
+      if (kp + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = as[(2 * kp + h) * LDA_S + i * 32];
+        for (int i = 0; i < WM; ++i) a_nxt[i] = as[(2 * kp + 2 + h) * LDA_S + i * 32];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = bs[(2 * kp + h) * LDB_S + j * 32];
+        for (int j = 0; j < WN; ++j) b_nxt[j] = bs[(2 * kp + 2 + h) * LDB_S + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks it behind them)
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kp + 1 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b_cur[j] = b_nxt[j];
+      }
     }
 
     if (more) store_tile(buf ^ 1);
@@ -170,36 +194,53 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   const bool do_drop = p.drop_thr != 0u;
   const uint32_t c1_base = (uint32_t)(((uint64_t)(z + p.batch_offset) * (uint64_t)(p.M_store >> 2)) & 0xFFFFFFFFu);
 
+  // Two-phase per 32x32 tile: first every bias / addend load of the tile (16 independent loads in flight), then the
+  // arithmetic and the stores.  (Interleaving them lets the possible add == C aliasing serialise each element behind a
+  // full memory round trip: 128 dependent L2 latencies per lane.)
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
+    const int row0 = m0 + wr * (32 * WM) + i * 32 + 4 * h;  // row of reg r: row0 + (r & 3) + 8 * (r >> 2)
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gm = row0 + (r & 3) + 8 * (r >> 2);
+      bias_r[r] = (p.bias && gm < M_store) ? p.bias[gm] : 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int gn = n0 + wc * (32 * WN) + j * 32 + l31;
+      const bool col_ok = gn < p.N;
+      float add_r[16], keep_r[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = row0 + (r & 3) + 8 * (r >> 2);
+        const bool ok = col_ok && gm < M_store;
+        add_r[r] = (p.add_mode != 0 && ok) ? addg[(long)gm * p.ldadd + gn] : 0.0f;
+        keep_r[r] = (maskg && ok) ? maskg[(long)gm * p.N + gn] : 1.0f;
+      }
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int row_base = m0 + wr * (32 * WM) + i * 32 + 8 * rg + 4 * h;
-        if (row_base >= M_store || gn >= p.N) continue;
+        const int row_base = row0 + 8 * rg;
         uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (do_drop && !maskg) {
+        if (do_drop && !maskg && col_ok && row_base < M_store) {
           const philox4 w = philox4x32_10((uint32_t)gn, c1_base + (uint32_t)(row_base >> 2), p.stream_id, p.call,
                                           p.seed_lo, p.seed_hi);
           words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
+          const int r = rg * 4 + r4;
           const int gm = row_base + r4;
-          if (gm >= M_store) continue;
-          float v = acc[i][j][rg * 4 + r4];
-          if (p.bias) v += p.bias[gm];
-          if (p.add_mode == 1) v += addg[(long)gm * p.ldadd + gn];
+          float v = acc[i][j][r] + bias_r[r];
+          if (p.add_mode == 1) v += add_r[r];
           if (p.act == 1) v = gelu_erf(v);
           if (do_drop) {
-            const bool keep = maskg ? (maskg[(long)gm * p.N + gn] != 0.0f) : (words[r4] >= p.drop_thr);
+            const bool keep = maskg ? (keep_r[r] != 0.0f) : (words[r4] >= p.drop_thr);
             v = keep ? v * p.drop_scale : 0.0f;
           }
           v *= bscale;
-          if (p.add_mode == 2) v += addg[(long)gm * p.ldadd + gn];
-          Cg[(long)gm * p.ldc + gn] = v;
+          if (p.add_mode == 2) v += add_r[r];
+          if (col_ok && gm < M_store) Cg[(long)gm * p.ldc + gn] = v;
         }
       }
     }

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const SdyTimeMlp t, const
   for (int o = threadIdx.x; o < T; o += 256) {
     float acc = t.b1[o];
     for (int i = 0; i < E; ++i) acc += t.w1t[(long)i * T + o] * emb[i];
-    h1[o] = gelu_erf(acc);
+    h1[o] = gelu_erf_exact(acc);
   }
   __syncthreads();
   for (int o = threadIdx.x; o < T; o += 256) {
