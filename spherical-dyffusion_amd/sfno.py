@@ -95,10 +95,10 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         self.seed = int(seed)
         self.batch_offset = 0           # global index of the first trajectory this rank owns
         self._call = 0                  # advances the dropout stream on every forward
+        self.mask_injector = None       # tests: callable(call_index) -> (keep_masks, drop_path_keep) replacing Philox
 
         E, T, H, Cin, L = embed_dim, self.time_dim, self.mlp_hidden, self.in_chans, self.modes_lat
         P = lambda *s: nn.Parameter(torch.zeros(*s), requires_grad=False)  # noqa: E731
-        self.encoder = nn.ModuleDict()  # names below reproduce nn.Sequential indices of the reference
         self._params: Dict[str, nn.Parameter] = {}
 
         def reg(name, *shape):
@@ -288,6 +288,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         a.enable_dropout = int(self.inference_dropout)
         a.seed, a.call, a.batch_offset = self.seed, self._call & 0xFFFFFFFF, self.batch_offset
         keep = []
+        if keep_masks is None and drop_path_keep is None and self.mask_injector is not None and self.inference_dropout:
+            keep_masks, drop_path_keep = self.mask_injector(self._call)
         if keep_masks is not None:
             arr = (C.c_void_p * (2 * self.num_layers))()
             for j, m in enumerate(keep_masks):

@@ -1,0 +1,90 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol the header declares, host-only entry points
+agree with the oracle, and argument validation returns the documented error codes before touching the device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sdy():
+    import sdy_amd
+
+    return sdy_amd
+
+
+def test_header_symbols_are_exported_and_bound(sdy):
+    hdr = open(os.path.join(ROOT, "include", "sdy_amd.h")).read()
+    declared = set(re.findall(r"\b(sdy_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = C.CDLL(sdy.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/sdy_amd.h but not exported"
+    from sdy_amd import _lib
+
+    assert declared == set(_lib.SIGNATURES), sorted(declared ^ set(_lib.SIGNATURES))
+    assert sdy.lib.sdy_version() >= 100
+
+
+@pytest.mark.parametrize("grid,gid", [("equiangular", 0), ("legendre-gauss", 1)])
+@pytest.mark.parametrize("nlat,nlon", [(32, 64), (180, 360)])
+def test_host_tables_match_oracle(sdy, grid, gid, nlat, nlon):
+    from oracle.sht import quadrature, sht_tables
+
+    L, M = nlat, nlon // 2 + 1
+    pct = np.zeros((M, L, nlat))
+    w = np.zeros(nlat)
+    th = np.zeros(nlat)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert sdy.lib.sdy_sht_tables_host(nlat, nlon, L, M, gid, vp(pct), vp(w), vp(th)) == 0
+    p_ref, wq_ref, _, _ = sht_tables(nlat, nlon, L, M, grid)
+    th_ref, w_ref = quadrature(nlat, grid)
+    assert np.abs(th - th_ref).max() < 1e-14 and np.abs(w - w_ref).max() < 1e-14
+    assert np.abs(pct - p_ref).max() < 1e-12
+    # what the device sees: fp32 casts of pct and pct*w are identical to the oracle's
+    assert (pct.astype(np.float32) == p_ref.astype(np.float32)).mean() > 0.9999
+    assert np.abs((pct * w).astype(np.float32) - wq_ref.astype(np.float32)).max() < 1e-9
+
+
+def test_error_codes_without_gpu(sdy):
+    lib = sdy.lib
+    assert lib.sdy_sht_tables_host(1, 64, 4, 4, 0, None, None, None) == -1          # SDY_ERR_ARG
+    assert lib.sdy_sht_tables_host(16, 32, 16, 17, 7, None, None, None) == -1       # bad grid
+    h = C.c_void_p()
+    assert lib.sdy_sht_plan_create(30, 62, 30, 32, 0, C.byref(h)) == -3             # nlon % 4 -> SDY_ERR_ALIGN
+    assert lib.sdy_sht_plan_create(32, 64, 32, 40, 0, C.byref(h)) == -1             # mmax > nlon/2+1
+    assert lib.sdy_sht_plan_create(32, 4 * 7, 32, 15, 0, C.byref(h)) == -2          # nlon/2 = 14 has a factor 7
+    assert lib.sdy_cold_update(None, None, None, None, 8, None) == -1
+    assert lib.sdy_sfno_workspace_floats(None, 4) == 0
+    assert b"multiple of 4" in lib.sdy_error_string(-3)
+    with pytest.raises(sdy.SdyError):
+        sdy._lib.check(-2, "x")
+
+
+def test_no_cpu_fallback(sdy):
+    import torch
+
+    with pytest.raises(RuntimeError, match="GPU only"):
+        sdy.RealSHT(32, 64)(torch.zeros(1, 4, 32, 64))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        sdy.ops.cold_update(torch.zeros(4), torch.zeros(4), None)
+    net = sdy.SphericalFourierNeuralOperatorNet(4, 4, spatial_shape_in=(32, 64), embed_dim=8, num_layers=1)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        net(torch.zeros(1, 4, 32, 64))
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for Philox4x32-10 (the dropout stream's generator)."""
+    from oracle.philox import philox4x32_10
+
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+            (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+    for ctr, key, exp in kat:
+        got = tuple(int(x) for x in philox4x32_10(*ctr, *key))
+        assert got == exp

@@ -1,0 +1,112 @@
+"""Host-side logic of the drop-in surface that needs no GPU: schedule maths, the stateful prediction cache, state_dict
+contract, sharding."""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+
+
+@pytest.fixture(scope="module")
+def sdy():
+    import sdy_amd
+
+    return sdy_amd
+
+
+class _FakeIpol:
+    window, true_horizon = 1, 6
+
+
+def _sampler(sdy, **kw):
+    return sdy.DYffusion(model=None, interpolator=_FakeIpol(), timesteps=6, **kw)
+
+
+def test_schedule_maths_matches_reference_semantics(sdy):
+    d = _sampler(sdy)
+    assert d.num_timesteps == 6 and d.sampling_schedule == [0, 1, 2, 3, 4, 5]
+    assert [d.diffusion_step_to_interpolation_step(i) for i in range(6)] == [0, 1, 2, 3, 4, 5]
+    assert d.valid_time_range_for_backbone_model == [0, 1, 2, 3, 4, 5]
+    # k = 2 artificial steps before t1 (dyffusion.py:155-169): d1 -> 1/3, d2 -> 2/3, d3 -> 1, ...
+    d2 = _sampler(sdy, additional_interpolation_steps=2)
+    assert d2.num_timesteps == 8
+    got = [d2.diffusion_step_to_interpolation_step(i) for i in range(8)]
+    assert got[0] == 0 and abs(got[1] - 1 / 3) < 1e-12 and abs(got[2] - 2 / 3) < 1e-12 and got[3:] == [1, 2, 3, 4, 5]
+    assert d2.dynamical_steps == {3: 1, 4: 2, 5: 3, 6: 4, 7: 5}
+    d2.sampling_schedule = "only_dynamics"
+    assert d2.sampling_schedule == [0, 3, 4, 5, 6, 7]
+    d2.sampling_schedule = "every2"
+    assert d2.sampling_schedule == [0, 1, 3, 4, 5, 6, 7]
+    with pytest.raises(AssertionError):
+        d.diffusion_step_to_interpolation_step(6)
+    with pytest.raises(ValueError):
+        sdy.DYffusion(model=None, interpolator=_FakeIpol(), timesteps=5)     # horizon mismatch (dyffusion.py:634-640)
+    with pytest.raises(NotImplementedError):
+        _sampler(sdy, schedule="linear")
+
+
+def test_prediction_cache_surface(sdy):
+    """get_preds_at_t_for_batch: horizon 1 computes, later horizons pop the cache, the last one clears it
+    (forecasting_multi_horizon.py:347-380)."""
+    class FakeNet:
+        def set_min_max_time(self, **kw): self.rng = kw
+        def enable_inference_dropout(self): pass
+        def disable_inference_dropout(self): pass
+
+    net = FakeNet()
+    ipol = sdy.InterpolationExperiment(FakeNet(), horizon=6)
+    assert ipol.horizon_range == [1, 2, 3, 4, 5] and ipol.model.rng == {"min_time": 1, "max_time": 5}
+    exp = sdy.MultiHorizonForecastingDYffusion(net, ipol, horizon=6)
+    assert net.rng == {"min_time": 0, "max_time": 5} and exp.true_horizon == 6
+    calls = []
+
+    def fake_predict_forward(x, **kw):
+        calls.append(sorted(kw))
+        return {f"t{h}_preds": x + h for h in range(1, 7)}
+
+    exp.model.predict_forward = fake_predict_forward
+    x = torch.zeros(2, 3, 4, 8)
+    for h in range(1, 7):
+        out = exp.get_preds_at_t_for_batch({"dynamics": x, "static_condition": x}, horizon=h, split="predict",
+                                           prepare_inputs=False, num_predictions=1)
+        assert list(out) == [f"t{h}_preds_normed"] and float(out[f"t{h}_preds_normed"].mean()) == h
+    assert calls == [["static_condition"]] and exp._current_preds is None
+    with pytest.raises(AssertionError):
+        exp.get_preds_at_t_for_batch({"dynamics": x}, horizon=0, split="predict", prepare_inputs=False)
+    with pytest.raises(AssertionError):   # horizon 2 before horizon 1
+        exp.get_preds_at_t_for_batch({"dynamics": x}, horizon=2, split="predict", prepare_inputs=False)
+
+
+def test_state_dict_contract_matches_reference_fixture(sdy):
+    """Names and shapes of the product network == the reference network's state_dict (fixture from the real class)."""
+    z = gu.load("fx_sfno_tiny")
+    cfg, n_in, n_cond = gu.cfg_from(z)
+    ref_sd = gu.state_dict(z)
+    net = sdy.SphericalFourierNeuralOperatorNet(
+        num_input_channels=n_in, num_output_channels=cfg.out_chans, num_conditional_channels=n_cond,
+        spatial_shape_in=(cfg.nlat, cfg.nlon), embed_dim=cfg.embed_dim, num_layers=cfg.num_layers,
+        dropout_mlp=cfg.dropout_mlp, drop_path_rate=cfg.drop_path_rate, with_time_emb=True)
+    mine = net.state_dict()
+    assert set(mine) == set(ref_sd)
+    for k in ref_sd:
+        assert tuple(mine[k].shape) == tuple(ref_sd[k].shape), k
+    net.load_state_dict(ref_sd, strict=True)
+    with pytest.raises(RuntimeError):
+        net.load_state_dict({**ref_sd, "bogus": torch.zeros(1)}, strict=True)
+    # dropout = 0 moves fc2 to index 2 of the Sequential (layers.py:76-80)
+    net0 = sdy.SphericalFourierNeuralOperatorNet(4, 4, spatial_shape_in=(32, 64), embed_dim=8, num_layers=1)
+    assert "blocks.0.mlp.fwd.2.weight" in net0.state_dict() and "blocks.0.mlp.fwd.3.weight" not in net0.state_dict()
+    with pytest.raises(NotImplementedError):
+        sdy.SphericalFourierNeuralOperatorNet(4, 4, operator_type="diagonal")
+
+
+def test_partition(sdy):
+    from sdy_amd import ensemble
+
+    assert [c for _, c in ensemble.partition(25, 8)] == [4, 3, 3, 3, 3, 3, 3, 3]
+    parts = ensemble.partition(100, 8)
+    assert sum(c for _, c in parts) == 100 and parts[0] == (0, 13) and parts[-1] == (88, 12)
+    units = [u for r in range(8) for u in ensemble.rank_units(4, 25, r, 8)]
+    assert units == [(ic, m) for ic in range(4) for m in range(25)]
+    assert [len(b) for b in ensemble.batches(ensemble.rank_units(4, 25, 0, 8), 5)] == [5, 5, 3]
+    assert ensemble.partition(3, 8)[5] == (3, 0)

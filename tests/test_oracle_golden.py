@@ -1,0 +1,100 @@
+"""Pins the CPU oracle against golden vectors produced by the REFERENCE'S OWN classes (tools/gen_golden.py)."""
+import json
+import os
+
+import pytest
+import torch
+
+import golden_utils as gu
+from conftest import rel_l2
+from oracle.dyffusion import OracleDYffusion
+from oracle.sfno import OracleSFNO, SFNOConfig
+
+TOL = 2e-6   # oracle and reference run the same torch CPU ops; differences are summation-order level
+
+
+def _t(z, k):
+    return torch.from_numpy(z[k]) if k in z.files else None
+
+
+@pytest.mark.parametrize("name", ["fx_block_c1", "fx_sfno_tiny", "fx_sfno_tiny_lg"])
+def test_network_matches_reference(name):
+    z = gu.load(name)
+    cfg, n_in, n_cond = gu.cfg_from(z)
+    net = OracleSFNO(cfg, gu.state_dict(z))
+    y = net(_t(z, "x"), time=_t(z, "time"), condition=_t(z, "cond"))
+    err = rel_l2(y, _t(z, "y"))
+    assert err < TOL, f"{name}: rel L2 {err:.3e}"
+    if "t_repr" in z.files:
+        assert rel_l2(net.time_repr(_t(z, "time")), _t(z, "t_repr")) < TOL
+
+
+def test_block_matches_reference():
+    """FourierNeuralOperatorBlock.forward in isolation (sfnonet.py:289-337): input/output captured by a hook."""
+    z = gu.load("fx_block_c1")
+    cfg, _, _ = gu.cfg_from(z)
+    net = OracleSFNO(cfg, gu.state_dict(z))
+    t_repr = net.time_repr(_t(z, "time"))
+    y = net.block(0, _t(z, "block0_in"), t_repr, None)
+    err = rel_l2(y, _t(z, "block0_out"))
+    assert err < TOL, f"block: rel L2 {err:.3e}"
+
+
+def test_network_with_recorded_dropout_masks():
+    z = gu.load("fx_sfno_tiny")
+    cfg, _, _ = gu.cfg_from(z)
+    net = OracleSFNO(cfg, gu.state_dict(z))
+    fwd = gu.masks_per_forward(gu.recorded_masks(z), cfg)
+    assert len(fwd) == 1
+    # block 0 has no DropPath (rate 0 -> nn.Identity, sfnonet.py:252)
+    assert ("drop_path", 0) not in fwd[0] and ("drop_path", 1) in fwd[0]
+    y = net(_t(z, "x"), time=_t(z, "time"), condition=_t(z, "cond"), mask_fn=gu.mask_fn_from(fwd[0]))
+    err = rel_l2(y, _t(z, "y_dropout"))
+    assert err < TOL, f"dropout: rel L2 {err:.3e}"
+    assert rel_l2(_t(z, "y_dropout"), _t(z, "y")) > 1e-2   # the masks matter
+
+
+def _sampler(z, masks=None):
+    fcfg = SFNOConfig(**json.loads(str(z["fcfg"])))
+    icfg = SFNOConfig(**json.loads(str(z["icfg"])))
+    fnet = OracleSFNO(fcfg, gu.state_dict(z, "f::"))
+    inet = OracleSFNO(icfg, gu.state_dict(z, "i::"))
+    per_fwd = gu.masks_per_forward(masks, icfg) if masks is not None else None
+    n = {"i": 0}
+    trace = []
+
+    def f(x, time, condition=None, static_condition=None):
+        trace.append(["F", float(time[0])])
+        return fnet(x, time=time, condition=condition, static_condition=static_condition)
+
+    def i(x, time, condition=None, static_condition=None):
+        trace.append(["I", float(time[0])])
+        mf = gu.mask_fn_from(per_fwd[n["i"]]) if per_fwd is not None else None
+        n["i"] += 1
+        return inet(x, time=time, condition=condition, static_condition=static_condition, mask_fn=mf)
+
+    return OracleDYffusion(f, i, timesteps=6, hack_for_imprecise_interpolation=bool(int(z["hack"]))), trace
+
+
+@pytest.mark.parametrize("name", ["fx_sample_tiny", "fx_sample_tiny_hack", "fx_sample_tiny_masks"])
+def test_sampler_matches_reference(name):
+    z = gu.load(name)
+    masks = gu.recorded_masks(z) if int(z["dropout"]) else None
+    smp, trace = _sampler(z, masks)
+    kw = {k: _t(z, k) for k in ("dynamical_condition", "static_condition") if k in z.files}
+    out = smp.sample(_t(z, "x0"), **kw)
+    ref = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out::")}
+    assert sorted(out) == sorted(ref)
+    for k in ref:
+        err = rel_l2(out[k], ref[k])
+        assert err < 5e-6, f"{name}/{k}: rel L2 {err:.3e}"
+    assert trace == json.loads(str(z["trace"]))
+    if masks is not None:
+        assert len(gu.masks_per_forward(masks, SFNOConfig(**json.loads(str(z["icfg"]))))) == 10
+
+
+def test_call_trace_fixture():
+    with open(os.path.join(gu.GOLDEN, "fx_trace.json")) as f:
+        tr = json.load(f)
+    assert [c for c, _ in tr].count("F") == 6 and [c for c, _ in tr].count("I") == 10
+    assert tr[:5] == [["F", 0.0], ["I", 1.0], ["F", 1.0], ["I", 2.0], ["I", 1.0]]

@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE'S OWN CLASSES on CPU (build container only).
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz (+ fx_trace.json)
+
+The reference is imported from /root/reference through tools/ref_shims.py (stubs for the packages this image lacks;
+`torch_harmonics` is supplied by oracle/sht.py -- see the shim header).  Nothing here is needed at test time: the
+fixtures are plain data (inputs, weights, expected outputs, recorded dropout masks).
+
+Weights are "trained-like" (oracle.sfno.make_state_dict) and are loaded into the reference network with
+strict=True, which also pins the state_dict contract (names + shapes) of SURVEY.md Appendix B.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+from ref_shims import AttrDict  # noqa: E402
+
+from oracle.sfno import SFNOConfig, make_state_dict  # noqa: E402
+from src.models.modules.drop_path import DropPath  # noqa: E402
+from src.models.sfno.sfnonet import SphericalFourierNeuralOperatorNet as RefSFNO  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def np_sd(sd):
+    return {"sd::" + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def pack(mask: torch.Tensor) -> np.ndarray:
+    return np.packbits(mask.detach().cpu().numpy().astype(bool).reshape(-1))
+
+
+def ref_net(cfg: SFNOConfig, n_in: int, n_cond: int, seed: int):
+    net = RefSFNO(
+        num_input_channels=n_in, num_output_channels=cfg.out_chans, num_conditional_channels=n_cond,
+        spatial_shape_in=(cfg.nlat, cfg.nlon), spatial_shape_out=(cfg.nlat, cfg.nlon), loss_function=None,
+        embed_dim=cfg.embed_dim, num_layers=cfg.num_layers, operator_type="dhconv", filter_type="linear",
+        scale_factor=1, use_mlp=True, mlp_ratio=cfg.mlp_ratio, dropout_mlp=cfg.dropout_mlp,
+        drop_path_rate=cfg.drop_path_rate, normalization_layer="instance_norm", with_time_emb=cfg.with_time_emb,
+        data_grid=cfg.data_grid, big_skip=cfg.big_skip, pos_embed=cfg.pos_embed, verbose=False,
+    )
+    sd = make_state_dict(cfg, seed=seed)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    # non-persistent SHT buffers are the only thing allowed to be absent
+    assert not unexpected, unexpected
+    assert all(".weights" in k or ".pct" in k for k in missing), missing
+    ref_keys = {k for k in net.state_dict().keys() if ".weights" not in k and ".pct" not in k}
+    assert ref_keys == set(sd.keys()), (sorted(ref_keys ^ set(sd.keys())))
+    if cfg.with_time_emb:
+        net.set_min_max_time(cfg.min_time, cfg.max_time)
+    net.eval()
+    return net, sd
+
+
+class MaskRecorder:
+    """Records the keep-masks the reference's nn.Dropout / DropPath layers actually drew (out != 0)."""
+
+    def __init__(self, net):
+        self.records = []
+        self.handles = []
+        for name, m in net.named_modules():
+            if isinstance(m, torch.nn.Dropout):
+                self.handles.append(m.register_forward_hook(self._hook(name, "elem")))
+            elif isinstance(m, DropPath):
+                self.handles.append(m.register_forward_hook(self._hook(name, "path")))
+
+    def _hook(self, name, kind):
+        def fn(mod, inp, out):
+            if not mod.training:
+                return
+            if kind == "elem":
+                self.records.append((name, (out != 0) | (inp[0] == 0)))
+            else:
+                keep = (out.flatten(1) != 0).any(dim=1) | (inp[0].flatten(1) == 0).all(dim=1)
+                self.records.append((name, keep))
+        return fn
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+
+
+def gen_sfno(tag, cfg, n_in, n_cond, B, times, seed, with_masks):
+    net, sd = ref_net(cfg, n_in, n_cond, seed)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = torch.randn(B, n_in, cfg.nlat, cfg.nlon, generator=g)
+    cond = torch.randn(B, n_cond, cfg.nlat, cfg.nlon, generator=g) if n_cond else None
+    t = torch.tensor(times, dtype=torch.float32) if cfg.with_time_emb else None
+    blk_io = {}
+    h = net.blocks[0].register_forward_hook(
+        lambda m, i, o: blk_io.update(x=i[0].detach().clone(), y=o.detach().clone()))
+    with torch.no_grad():
+        y, trepr = net(x, time=t, condition=cond, return_time_emb=True)
+    h.remove()
+    out = dict(np_sd(sd), x=x.numpy(), y=y.numpy(), block0_in=blk_io["x"].numpy(), block0_out=blk_io["y"].numpy(),
+               cfg=json.dumps({**cfg.__dict__, "n_in": n_in, "n_cond": n_cond}))
+    if cond is not None:
+        out["cond"] = cond.numpy()
+    if t is not None:
+        out["time"] = t.numpy()
+        out["t_repr"] = trepr.numpy()
+    if with_masks:
+        net.enable_inference_dropout()       # _base_model.py:288-290 -> utils.enable_inference_dropout
+        rec = MaskRecorder(net)
+        torch.manual_seed(777)
+        with torch.no_grad():
+            yd = net(x, time=t, condition=cond)
+        rec.remove()
+        net.disable_inference_dropout()
+        out["y_dropout"] = yd.numpy()
+        out["mask_names"] = json.dumps([n for n, _ in rec.records])
+        for i, (_, m) in enumerate(rec.records):
+            out[f"mask{i}"] = pack(m)
+            out[f"mask{i}_shape"] = np.array(m.shape)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"{tag}: y std {float(y.std()):.4f}, saved")
+
+
+def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i):
+    import src.experiment_types._base_experiment as be
+    from src.experiment_types.forecasting_multi_horizon import MultiHorizonForecastingDYffusion
+    from src.experiment_types.interpolation import InterpolationExperiment
+
+    be.get_dims_of_dataset = lambda dc: {"input": len(dc.in_names), "output": len(dc.out_names), "spatial_in": (H, W),
+                                          "spatial_out": (H, W), "conditional": len(dc.forcing_names)}
+    cs = C + (1 if hack else 0)
+    dm = AttrDict(_target_="src.datamodules.fv3gfs_ensemble.FV3GFSEnsembleDataModule",
+                  in_names=[f"v{i}" for i in range(cs)], out_names=[f"v{i}" for i in range(cs - C, cs)],
+                  forcing_names=[f"f{i}" for i in range(n_forc)], window=1, horizon=6)
+
+    def mcfg(**kw):
+        return AttrDict(_target_="src.models.sfno.sfnonet.SphericalFourierNeuralOperatorNet", embed_dim=E, num_layers=L,
+                        operator_type="dhconv", filter_type="linear", scale_factor=1, use_mlp=True, mlp_ratio=2.0,
+                        normalization_layer="instance_norm", with_time_emb=True, data_grid="equiangular",
+                        loss_function=None, verbose=False, **kw)
+
+    ipol = InterpolationExperiment(model_config=mcfg(dropout_mlp=0.1 if dropout else 0.0,
+                                                     drop_path_rate=0.1 if dropout else 0.0),
+                                   datamodule_config=dm, enable_inference_dropout=True, verbose=False)
+    icfg = SFNOConfig(in_chans=2 * cs + n_forc, out_chans=C, nlat=H, nlon=W, embed_dim=E, num_layers=L,
+                      with_time_emb=True, dropout_mlp=0.1 if dropout else 0.0, drop_path_rate=0.1 if dropout else 0.0,
+                      min_time=1.0, max_time=5.0)
+    assert ipol.model.in_chans == icfg.in_chans and ipol.model.out_chans == C
+    isd = make_state_dict(icfg, seed=seed_i)
+    ipol.model.load_state_dict(isd, strict=False)
+    dcfg = AttrDict(_target_="src.diffusion.dyffusion.DYffusion", timesteps=6, forward_conditioning="none",
+                    interpolator=ipol, interpolator_local_checkpoint_path=None, time_encoding="dynamics",
+                    hack_for_imprecise_interpolation=hack, enable_interpolator_dropout=bool(dropout))
+    fc = MultiHorizonForecastingDYffusion(model_config=mcfg(), datamodule_config=dm, diffusion_config=dcfg,
+                                          verbose=False)
+    fcfg = SFNOConfig(in_chans=cs + n_forc, out_chans=C, nlat=H, nlon=W, embed_dim=E, num_layers=L,
+                      with_time_emb=True, min_time=0.0, max_time=5.0)
+    assert fc.model.model.in_chans == fcfg.in_chans
+    fsd = make_state_dict(fcfg, seed=seed_f)
+    fc.model.model.load_state_dict(fsd, strict=False)
+    fc.eval()
+    ipol.eval()
+    return fc, ipol, fcfg, icfg, fsd, isd, cs
+
+
+def gen_sample(tag, hack, dropout):
+    C, n_forc, H, W, E, L = 6, 2, 32, 64, 16, 2
+    fc, ipol, fcfg, icfg, fsd, isd, cs = build_experiments(C, n_forc, H, W, E, L, hack, dropout, 11, 22)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    B = 2
+    x0 = torch.randn(B, cs, H, W, generator=g)
+    if hack:
+        kw = {"static_condition": torch.randn(B, n_forc, H, W, generator=g)}
+    else:
+        kw = {"dynamical_condition": torch.randn(B, 7, n_forc, H, W, generator=g)}
+    trace = []
+    f_net, i_net = fc.model.model, ipol.model
+    hf = f_net.register_forward_pre_hook(lambda m, a, k: trace.append(["F", float(k["time"][0])]), with_kwargs=True)
+    hi = i_net.register_forward_pre_hook(lambda m, a, k: trace.append(["I", float(k["time"][0])]), with_kwargs=True)
+    rec = MaskRecorder(i_net) if dropout else None
+    torch.manual_seed(4242)
+    res = fc.model.sample(x0, **kw)     # DYffusion.sample (dyffusion.py:569-572)
+    hf.remove()
+    hi.remove()
+    out = dict(x0=x0.numpy(), hack=np.array(int(hack)), dropout=np.array(int(dropout)),
+               fcfg=json.dumps(fcfg.__dict__), icfg=json.dumps(icfg.__dict__), trace=json.dumps(trace))
+    out.update({"f::" + k: v.numpy() for k, v in fsd.items()})
+    out.update({"i::" + k: v.numpy() for k, v in isd.items()})
+    for k, v in kw.items():
+        out[k] = v.numpy()
+    for k, v in res.items():
+        out["out::" + k] = v.numpy()
+    if rec is not None:
+        rec.remove()
+        out["mask_names"] = json.dumps([n for n, _ in rec.records])
+        for i, (_, m) in enumerate(rec.records):
+            out[f"mask{i}"] = pack(m)
+            out[f"mask{i}_shape"] = np.array(m.shape)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"{tag}: keys {sorted(res.keys())}, {len(trace)} network calls, saved")
+    return trace
+
+    # also exercise the stepper-facing surface once (get_preds_at_t_for_batch), results must equal sample()
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    # C1: one block, 32x64, 8 channels (BASELINE.json configs[0])
+    gen_sfno("fx_block_c1", SFNOConfig(in_chans=8, out_chans=8, nlat=32, nlon=64, embed_dim=8, num_layers=1,
+                                       with_time_emb=True, min_time=0.0, max_time=5.0), 8, 0, 2, [1.0, 4.0], 4321, False)
+    # tiny full network with conditioning, time embedding, dropout + drop path (interpolator-like)
+    gen_sfno("fx_sfno_tiny", SFNOConfig(in_chans=10, out_chans=6, nlat=32, nlon=64, embed_dim=16, num_layers=3,
+                                        with_time_emb=True, dropout_mlp=0.1, drop_path_rate=0.3, min_time=0.0,
+                                        max_time=5.0), 8, 2, 3, [0.0, 2.0, 5.0], 4321, True)
+    gen_sfno("fx_sfno_tiny_lg", SFNOConfig(in_chans=4, out_chans=4, nlat=32, nlon=64, embed_dim=8, num_layers=2,
+                                           with_time_emb=False, data_grid="legendre-gauss", big_skip=False,
+                                           pos_embed=False), 4, 0, 2, None, 99, False)
+    t1 = gen_sample("fx_sample_tiny", hack=False, dropout=False)
+    gen_sample("fx_sample_tiny_hack", hack=True, dropout=False)
+    gen_sample("fx_sample_tiny_masks", hack=True, dropout=True)
+    with open(os.path.join(OUT, "fx_trace.json"), "w") as f:
+        json.dump(t1, f)
+    sizes = {n: os.path.getsize(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT))}
+    print(sizes)
