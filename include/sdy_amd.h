@@ -132,8 +132,17 @@ typedef struct sdy_conv_args {
   const float* batch_scale;          /* dev [B] or NULL (drop-path scale) */
   int kernel_tag;                    /* 0 generic; 1 = MLP fc1, 2 = MLP fc2, 3 = inner skip: identical code under a
                                         distinct symbol name so profilers attribute time per use */
+  const void* w_h3;                  /* dev, optional: weight packed by sdy_h3_pack_weight -> the GEMM runs on the f16
+                                        matrix cores in split precision (3 passes, fp32-class accuracy); wt may be NULL */
+  float w_h3_scale;                  /* scale returned by sdy_h3_pack_weight */
 } sdy_conv_args;
 int sdy_conv1x1(const sdy_conv_args* args, void* stream);
+
+/* Split-precision weight packing for sdy_conv1x1 (w_h3): host (Cout, Cin) row-major fp32 -> dev fp16 hi|lo planes,
+ * [Mpad][Kpad] each (Mpad = Cout rounded up to 128, Kpad = Cin rounded up to 64), multiplied by a power of two
+ * (*scale) chosen so that max|w|*scale is in [2^12, 2^13). */
+size_t sdy_h3_pack_bytes(int Cout, int Cin);
+int sdy_h3_pack_weight(const float* w_host, int Cout, int Cin, void* packed_dev, float* scale);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Whole network.  Replaces SphericalFourierNeuralOperatorNet.__init__/forward
@@ -154,6 +163,8 @@ typedef struct sdy_sfno_config {
   float dropout_mlp;   /* MLP dropout rate (active only when a forward call enables dropout) */
   float drop_path_rate;
   int big_skip, pos_embed;
+  int gemm_mode;       /* 0: fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere; 1: the 1x1 convolutions run as split-fp16
+                          3-pass MFMA GEMMs (fp32-class accuracy at the f16 matrix rate) */
 } sdy_sfno_config;
 
 typedef struct sdy_sfno sdy_sfno;

@@ -35,6 +35,8 @@ class SdyConvArgs(C.Structure):
         ("seed", C.c_uint64), ("call", C.c_uint32), ("stream_id", C.c_uint32), ("batch_offset", C.c_uint32),
         ("batch_scale", C.c_void_p),
         ("kernel_tag", C.c_int),
+        ("w_h3", C.c_void_p),
+        ("w_h3_scale", C.c_float),
     ]
 
 
@@ -48,6 +50,7 @@ class SdySfnoConfig(C.Structure):
         ("with_time_emb", C.c_int), ("time_dim", C.c_int),
         ("dropout_mlp", C.c_float), ("drop_path_rate", C.c_float),
         ("big_skip", C.c_int), ("pos_embed", C.c_int),
+        ("gemm_mode", C.c_int),
     ]
 
 
@@ -85,6 +88,8 @@ SIGNATURES = {
     "sdy_instnorm_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_conv1x1": (C.c_int, [C.POINTER(SdyConvArgs), C.c_void_p]),
+    "sdy_h3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sdy_h3_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "sdy_sfno_create": (C.c_int, [C.POINTER(SdySfnoConfig), C.POINTER(C.c_void_p)]),
     "sdy_sfno_destroy": (None, [C.c_void_p]),
     "sdy_sfno_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),

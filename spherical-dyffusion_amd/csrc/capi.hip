@@ -225,12 +225,47 @@ extern "C" int sdy_instnorm_coeffs(const float* x, int B, int C, int HW, const f
   return sdy_instnorm_coeffs_launch(x, B, C, HW, gamma, beta, scale_shift, ss_stride, eps, a, d, (hipStream_t)stream);
 }
 
+static inline int h3_mpad(int Cout) { return round_up(Cout, 128); }
+static inline int h3_kpad(int Cin) { return round_up(Cin, 64); }
+
+extern "C" size_t sdy_h3_pack_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return 0;
+  return (size_t)2 * h3_mpad(Cout) * h3_kpad(Cin) * sizeof(_Float16);
+}
+
+extern "C" int sdy_h3_pack_weight(const float* w, int Cout, int Cin, void* packed_dev, float* scale) {
+  if (!w || !packed_dev || !scale || Cout <= 0 || Cin <= 0) return SDY_ERR_ARG;
+  const int Mp = h3_mpad(Cout), Kp = h3_kpad(Cin);
+  float mx = 0.f;
+  for (size_t i = 0; i < (size_t)Cout * Cin; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+  float s = 1.0f;
+  if (mx > 0.f && std::isfinite(mx)) {
+    int e;
+    std::frexp(mx, &e);            // mx = f * 2^e, f in [0.5, 1)
+    s = std::ldexp(1.0f, 13 - e);  // mx * s in [2^12, 2^13)
+  }
+  std::vector<_Float16> buf((size_t)2 * Mp * Kp, (_Float16)0.0f);
+  _Float16* hi = buf.data();
+  _Float16* lo = hi + (size_t)Mp * Kp;
+  for (int o = 0; o < Cout; ++o)
+    for (int i = 0; i < Cin; ++i) {
+      const float v = w[(size_t)o * Cin + i] * s;
+      const _Float16 hv = (_Float16)v;
+      hi[(size_t)o * Kp + i] = hv;
+      lo[(size_t)o * Kp + i] = (_Float16)(v - (float)hv);
+    }
+  SDY_HIP_TRY(hipMemcpy(packed_dev, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  *scale = s;
+  return SDY_OK;
+}
+
 extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
-  if (!a || !a->x || !a->wt || !a->out) return SDY_ERR_ARG;
-  if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->HW <= 0 || a->ldw < a->Cout) return SDY_ERR_ARG;
+  if (!a || !a->x || (!a->wt && !a->w_h3) || !a->out) return SDY_ERR_ARG;
+  if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->HW <= 0) return SDY_ERR_ARG;
+  if (!a->w_h3 && a->ldw < a->Cout) return SDY_ERR_ARG;
   if ((a->pa == nullptr) != (a->pd == nullptr)) return SDY_ERR_ARG;
   if (a->add_mode != 0 && !a->add) return SDY_ERR_ARG;
-  if ((a->ldw & 3) || (a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3)) return SDY_ERR_ALIGN;
+  if ((!a->w_h3 && (a->ldw & 3)) || (a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3)) return SDY_ERR_ALIGN;
   if (a->drop_p < 0.0f || a->drop_p >= 1.0f) return SDY_ERR_ARG;
   GemmParams g{};
   g.A = a->wt; g.lda = a->ldw; g.sA = 0;
@@ -252,6 +287,8 @@ extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
   g.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFu); g.seed_hi = (uint32_t)(a->seed >> 32);
   g.stream_id = a->stream_id; g.call = a->call; g.batch_offset = a->batch_offset;
   g.batch_scale = a->batch_scale;
+  if (a->w_h3)
+    return sdy_gemm_h3_launch(g, a->w_h3, h3_mpad(a->Cout), h3_kpad(a->Cin), a->w_h3_scale, (hipStream_t)stream);
   return sdy_gemm_launch(g, (hipStream_t)stream);
 }
 
@@ -277,6 +314,9 @@ struct DevBuf {
   float* p = nullptr;
   size_t n = 0;
   bool set = false;
+  // split-fp16 copy of a conv weight (gemm_mode 1)
+  void* h3 = nullptr;
+  float h3_scale = 1.0f;
 };
 
 struct BlockW {
@@ -325,8 +365,21 @@ static int dev_upload_T(DevBuf& b, const float* host, int out, int in, int ld) {
 }
 static void dev_free(DevBuf& b) {
   if (b.p) (void)hipFree(b.p);
+  if (b.h3) (void)hipFree(b.h3);
   b.p = nullptr;
+  b.h3 = nullptr;
   b.set = false;
+}
+// conv weight: fp32 transposed copy (gemm_mode 0 path, also kept for reference) + split-fp16 pack (gemm_mode 1)
+static int dev_upload_conv(DevBuf& b, const float* host, int out, int in, int ld, bool want_h3) {
+  SDY_TRY(dev_upload_T(b, host, out, in, ld));
+  if (want_h3) {
+    if (b.h3) (void)hipFree(b.h3);
+    b.h3 = nullptr;
+    SDY_HIP_TRY(hipMalloc(&b.h3, sdy_h3_pack_bytes(out, in)));
+    SDY_TRY(sdy_h3_pack_weight(host, out, in, b.h3, &b.h3_scale));
+  }
+  return SDY_OK;
 }
 
 extern "C" int sdy_sfno_create(const sdy_sfno_config* c, sdy_sfno** out) {
@@ -399,6 +452,7 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
   const sdy_sfno_config& c = n->cfg;
   const int E = c.embed_dim, T = c.time_dim, L = c.num_layers, H = c.mlp_hidden, Cin = c.in_chans;
   const std::string name(name_c);
+  const bool h3 = c.gemm_mode == 1;
   // non-persistent SHT buffers of older torch-harmonics releases: accepted, ignored
   if (name.find("trans") != std::string::npos && (name.find(".weights") != std::string::npos ||
                                                    name.find(".pct") != std::string::npos))
@@ -414,14 +468,14 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
     return SDY_OK;
   }
   if (name == "pos_embed") { EXPECT_NUMEL((size_t)E * n->HW); return dev_upload(n->pos, host, numel); }
-  if (name == "encoder.0.weight") { EXPECT_NUMEL((size_t)E * Cin); return dev_upload_T(n->e0w, host, E, Cin, E); }
+  if (name == "encoder.0.weight") { EXPECT_NUMEL((size_t)E * Cin); return dev_upload_conv(n->e0w, host, E, Cin, E, h3); }
   if (name == "encoder.0.bias") { EXPECT_NUMEL(E); return dev_upload(n->e0b, host, numel); }
-  if (name == "encoder.2.weight") { EXPECT_NUMEL((size_t)E * E); return dev_upload_T(n->e2w, host, E, E, E); }
-  if (name == "decoder.0.weight") { EXPECT_NUMEL((size_t)E * n->decC); return dev_upload_T(n->d0w, host, E, n->decC, E); }
+  if (name == "encoder.2.weight") { EXPECT_NUMEL((size_t)E * E); return dev_upload_conv(n->e2w, host, E, E, E, h3); }
+  if (name == "decoder.0.weight") { EXPECT_NUMEL((size_t)E * n->decC); return dev_upload_conv(n->d0w, host, E, n->decC, E, h3); }
   if (name == "decoder.0.bias") { EXPECT_NUMEL(E); return dev_upload(n->d0b, host, numel); }
   if (name == "decoder.2.weight") {
     EXPECT_NUMEL((size_t)c.out_chans * E);
-    return dev_upload_T(n->d2w, host, c.out_chans, E, n->ldo);
+    return dev_upload_conv(n->d2w, host, c.out_chans, E, n->ldo, h3);
   }
   if (c.with_time_emb) {
     if (name == "time_emb_mlp.1.weight") { EXPECT_NUMEL((size_t)T * E); return dev_upload_T(n->t1w, host, T, E, T); }
@@ -463,14 +517,14 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
       return SDY_OK;
     }
     if (rest == "filter.filter.bias") { EXPECT_NUMEL(E); return dev_upload(w.fb, host, numel); }
-    if (rest == "inner_skip.weight") { EXPECT_NUMEL((size_t)E * E); return dev_upload_T(w.skw, host, E, E, E); }
+    if (rest == "inner_skip.weight") { EXPECT_NUMEL((size_t)E * E); return dev_upload_conv(w.skw, host, E, E, E, h3); }
     if (rest == "inner_skip.bias") { EXPECT_NUMEL(E); return dev_upload(w.skb, host, numel); }
-    if (rest == "mlp.fwd.0.weight") { EXPECT_NUMEL((size_t)H * E); return dev_upload_T(w.w1, host, H, E, H); }
+    if (rest == "mlp.fwd.0.weight") { EXPECT_NUMEL((size_t)H * E); return dev_upload_conv(w.w1, host, H, E, H, h3); }
     if (rest == "mlp.fwd.0.bias") { EXPECT_NUMEL(H); return dev_upload(w.b1, host, numel); }
     // layers.py:76-80: fc2 is index 3 of the Sequential when dropout > 0, else index 2
     if (rest == "mlp.fwd.2.weight" || rest == "mlp.fwd.3.weight") {
       EXPECT_NUMEL((size_t)E * H);
-      return dev_upload_T(w.w2, host, E, H, E);
+      return dev_upload_conv(w.w2, host, E, H, E, h3);
     }
     if (rest == "mlp.fwd.2.bias" || rest == "mlp.fwd.3.bias") { EXPECT_NUMEL(E); return dev_upload(w.b2, host, numel); }
   }
@@ -590,6 +644,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
                               a->batch_offset, stream));
 
   sdy_conv_args cv;
+  auto use_w = [&](const DevBuf& b) { cv.wt = b.p; if (c.gemm_mode == 1) { cv.w_h3 = b.h3; cv.w_h3_scale = b.h3_scale; } };
   auto conv_reset = [&]() {
     std::memset(&cv, 0, sizeof(cv));
     cv.B = B; cv.HW = HW; cv.seed = a->seed; cv.call = a->call; cv.batch_offset = a->batch_offset;
@@ -597,11 +652,11 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
 
   // ---- encoder (sfnonet.py:609-618,810,824): conv+bias -> GELU -> conv (no bias) -> + pos_embed
   conv_reset();
-  cv.x = cat_in; cv.x_bstride = cat_bs; cv.wt = n->e0w.p; cv.ldw = E; cv.out = xa; cv.out_bstride = (long)E * HW;
+  cv.x = cat_in; cv.x_bstride = cat_bs; use_w(n->e0w); cv.ldw = E; cv.out = xa; cv.out_bstride = (long)E * HW;
   cv.Cin = Cin; cv.Cout = E; cv.bias = n->e0b.p; cv.act = 1;
   SDY_TRY(sdy_conv1x1(&cv, stream));
   conv_reset();
-  cv.x = xa; cv.x_bstride = (long)E * HW; cv.wt = n->e2w.p; cv.ldw = E; cv.out = xb; cv.out_bstride = (long)E * HW;
+  cv.x = xa; cv.x_bstride = (long)E * HW; use_w(n->e2w); cv.ldw = E; cv.out = xb; cv.out_bstride = (long)E * HW;
   cv.Cin = E; cv.Cout = E;
   if (c.pos_embed) { cv.add = n->pos.p; cv.add_bstride = 0; cv.add_mode = 2; }
   SDY_TRY(sdy_conv1x1(&cv, stream));
@@ -628,7 +683,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
     conv_reset();
-    cv.x = xn; cv.x_bstride = (long)E * HW; cv.wt = bw.skw.p; cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
+    cv.x = xn; cv.x_bstride = (long)E * HW; use_w(bw.skw); cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
     cv.Cin = E; cv.Cout = E; cv.bias = bw.skb.p; cv.add = y; cv.add_bstride = (long)E * HW; cv.add_mode = 1; cv.act = 1; cv.kernel_tag = 3;
     SDY_TRY(sdy_conv1x1(&cv, stream));
     // norm1 (sfnonet.py:313-320) folded into the fc1 prologue
@@ -636,7 +691,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     // MLP (layers.py:73-80): fc1 + GELU + dropout
     const float pm = (drop && c.dropout_mlp > 0.f) ? c.dropout_mlp : 0.f;
     conv_reset();
-    cv.x = y; cv.x_bstride = (long)E * HW; cv.wt = bw.w1.p; cv.ldw = Hd; cv.out = hid; cv.out_bstride = (long)Hd * HW;
+    cv.x = y; cv.x_bstride = (long)E * HW; use_w(bw.w1); cv.ldw = Hd; cv.out = hid; cv.out_bstride = (long)Hd * HW;
     cv.Cin = E; cv.Cout = Hd; cv.pa = ca; cv.pd = cd; cv.bias = bw.b1.p; cv.act = 1; cv.kernel_tag = 1;
     cv.drop_p = pm; cv.stream_id = 2u * i; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i] : nullptr;
     SDY_TRY(sdy_conv1x1(&cv, stream));
@@ -644,7 +699,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     float* dst = (i == L - 1) ? cat : nxt;
     const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;
     conv_reset();
-    cv.x = hid; cv.x_bstride = (long)Hd * HW; cv.wt = bw.w2.p; cv.ldw = E; cv.out = dst; cv.out_bstride = dst_bs;
+    cv.x = hid; cv.x_bstride = (long)Hd * HW; use_w(bw.w2); cv.ldw = E; cv.out = dst; cv.out_bstride = dst_bs;
     cv.Cin = Hd; cv.Cout = E; cv.bias = bw.b2.p; cv.kernel_tag = 2;
     cv.drop_p = pm; cv.stream_id = 2u * i + 1u; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i + 1] : nullptr;
     if (drop && n->tm.dp_rate[i] > 0.f) cv.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
@@ -657,11 +712,11 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   // ---- decoder (sfnonet.py:734-744,831-837)
   float* dh = xa;
   conv_reset();
-  cv.x = cat; cv.x_bstride = cat_bs; cv.wt = n->d0w.p; cv.ldw = E;
+  cv.x = cat; cv.x_bstride = cat_bs; use_w(n->d0w); cv.ldw = E;
   cv.out = dh; cv.out_bstride = (long)E * HW; cv.Cin = n->decC; cv.Cout = E; cv.bias = n->d0b.p; cv.act = 1;
   SDY_TRY(sdy_conv1x1(&cv, stream));
   conv_reset();
-  cv.x = dh; cv.x_bstride = (long)E * HW; cv.wt = n->d2w.p; cv.ldw = n->ldo; cv.out = a->out;
+  cv.x = dh; cv.x_bstride = (long)E * HW; use_w(n->d2w); cv.ldw = n->ldo; cv.out = a->out;
   cv.out_bstride = (long)c.out_chans * HW; cv.Cin = E; cv.Cout = c.out_chans;
   SDY_TRY(sdy_conv1x1(&cv, stream));
   return SDY_OK;

@@ -99,6 +99,8 @@ struct GemmParams {
   const float* batch_scale;
 };
 int sdy_gemm_launch(const GemmParams& p, hipStream_t stream);
+// split-fp16 (3-pass) conv GEMM, gemm_h3.hip; packed = fp16 [Mpad][Kpad] hi then lo, scaled by w_scale
+int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int Mpad, int Kpad, float w_scale, hipStream_t stream);
 
 // ---- host tables (tables.cpp) --------------------------------------------------------------------------
 int sdy_factor_radices(int n, int* radices, int* nstages);  // n = prod(radices), radices in {4,2,3,5}

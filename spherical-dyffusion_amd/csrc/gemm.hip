@@ -12,6 +12,7 @@
 //   C/D: col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
 // LDS images are k-major (As[k][m], Bs[k][n]) so one ds_read_b32 per operand is bank-conflict free.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -33,7 +34,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   const int wr = wave >> 1, wc = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
   const int z = blockIdx.z;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // conv mode (no triangular structure): XCD-aware tile order -- the M-tiles sharing one activation tile get ids L,
+  // L+8, ... so they run back to back on one XCD and re-read the tile from its L2 (see gemm_h3.hip); batched
+  // Legendre / dhconv keep the plain (n fastest) order
+  int m0, n0;
+  if (p.tri_mode == SDY_TRI_NONE) {
+    const int MT = gridDim.x, NT = gridDim.y;
+    const int L = blockIdx.x + MT * blockIdx.y;
+    const int full = (NT / 8) * 8 * MT;
+    int mt, nt;
+    if (L < full) {
+      const int xcd = L & 7, slot = L >> 3;
+      nt = (slot / MT) * 8 + xcd;
+      mt = slot % MT;
+    } else {
+      const int r = L - full;
+      nt = (NT / 8) * 8 + r / MT;
+      mt = r % MT;
+    }
+    m0 = mt * BM;
+    n0 = nt * BN;
+  } else {
+    m0 = blockIdx.y * BM;
+    n0 = blockIdx.x * BN;
+  }
 
   int M_valid = p.M, k_lo = 0;
   const int k_hi = p.K;
@@ -186,65 +210,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------------------
-  float* __restrict__ Cg = p.C + (long)z * p.sC;
-  const float* __restrict__ addg = p.add ? p.add + (long)z * p.sAdd : nullptr;
-  const float* __restrict__ maskg = p.keep_mask ? p.keep_mask + (long)z * p.M_store * p.N : nullptr;
-  const float bscale = p.batch_scale ? p.batch_scale[z] : 1.0f;
-  const bool do_drop = p.drop_thr != 0u;
-  const uint32_t c1_base = (uint32_t)(((uint64_t)(z + p.batch_offset) * (uint64_t)(p.M_store >> 2)) & 0xFFFFFFFFu);
-
-  // Two-phase per 32x32 tile: first every bias / addend load of the tile (16 independent loads in flight), then the
-  // arithmetic and the stores.  (Interleaving them lets the possible add == C aliasing serialise each element behind a
-  // full memory round trip: 128 dependent L2 latencies per lane.)
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    const int row0 = m0 + wr * (32 * WM) + i * 32 + 4 * h;  // row of reg r: row0 + (r & 3) + 8 * (r >> 2)
-    float bias_r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int gm = row0 + (r & 3) + 8 * (r >> 2);
-      bias_r[r] = (p.bias && gm < M_store) ? p.bias[gm] : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int gn = n0 + wc * (32 * WN) + j * 32 + l31;
-      const bool col_ok = gn < p.N;
-      float add_r[16], keep_r[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gm = row0 + (r & 3) + 8 * (r >> 2);
-        const bool ok = col_ok && gm < M_store;
-        add_r[r] = (p.add_mode != 0 && ok) ? addg[(long)gm * p.ldadd + gn] : 0.0f;
-        keep_r[r] = (maskg && ok) ? maskg[(long)gm * p.N + gn] : 1.0f;
-      }
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int row_base = row0 + 8 * rg;
-        uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (do_drop && !maskg && col_ok && row_base < M_store) {
-          const philox4 w = philox4x32_10((uint32_t)gn, c1_base + (uint32_t)(row_base >> 2), p.stream_id, p.call,
-                                          p.seed_lo, p.seed_hi);
-          words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
-        }
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int r = rg * 4 + r4;
-          const int gm = row_base + r4;
-          float v = acc[i][j][r] + bias_r[r];
-          if (p.add_mode == 1) v += add_r[r];
-          if (p.act == 1) v = gelu_erf(v);
-          if (do_drop) {
-            const bool keep = maskg ? (keep_r[r] != 0.0f) : (words[r4] >= p.drop_thr);
-            v = keep ? v * p.drop_scale : 0.0f;
-          }
-          v *= bscale;
-          if (p.add_mode == 2) v += add_r[r];
-          if (col_ok && gm < M_store) Cg[(long)gm * p.ldc + gn] = v;
-        }
-      }
-    }
-  }
+  gemm_epilogue<WM, WN>(acc, p, z, m0, n0, M_store, 1.0f);
 }
 
 template <int WM, int WN, bool A_KCONTIG, bool B_CPLX, int TAG = 0>
@@ -260,7 +226,8 @@ int launch_inst(const GemmParams& p, hipStream_t stream) {
     }
     attr_done = true;
   }
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nbatch);
+  const unsigned gn = (p.N + BN - 1) / BN, gm = (p.M + BM - 1) / BM;
+  dim3 grid(p.tri_mode == SDY_TRI_NONE ? gm : gn, p.tri_mode == SDY_TRI_NONE ? gn : gm, p.nbatch);
   hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, A_KCONTIG, B_CPLX, TAG>), grid, dim3(256), smem, stream, p);
   return sdy_launch_status();
 }

@@ -74,7 +74,8 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
             pre_affine=None, add: Optional[torch.Tensor] = None, add_mode: int = 0, gelu: bool = False,
             drop_p: float = 0.0, keep_mask: Optional[torch.Tensor] = None, seed: int = 0, call: int = 0,
             stream_id: int = 0, batch_offset: int = 0, batch_scale: Optional[torch.Tensor] = None,
-            kernel_tag: int = 0, out: Optional[torch.Tensor] = None, wt_prepared=None) -> torch.Tensor:
+            kernel_tag: int = 0, out: Optional[torch.Tensor] = None, wt_prepared=None, h3: bool = False,
+            h3_prepared=None) -> torch.Tensor:
     """nn.Conv2d(kernel_size=1) with the block's fused prologue/epilogue (see include/sdy_amd.h, sdy_conv1x1).
     x (B,Cin,H,W), weight (Cout,Cin[,1,1])."""
     x = _f32c(x)
@@ -96,6 +97,11 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     a.out, a.out_bstride = ptr(out), Cout * H * W
     a.B, a.Cin, a.Cout, a.HW = B, Cin, Cout, H * W
     keep = [x, wt, out]
+    if h3 or h3_prepared is not None:     # split-fp16 3-pass MFMA path (include/sdy_amd.h, sdy_h3_pack_weight)
+        if h3_prepared is None:
+            h3_prepared = pack_h3(w2, x.device)
+        a.w_h3, a.w_h3_scale = ptr(h3_prepared[0]), h3_prepared[1]
+        keep.append(h3_prepared[0])
     if pre_affine is not None:
         pa, pd = _aux(pre_affine[0], x.device), _aux(pre_affine[1], x.device)
         a.pa, a.pd = ptr(pa), ptr(pd)
@@ -125,6 +131,18 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     with torch.cuda.device(x.device):
         check(lib.sdy_conv1x1(C.byref(a), current_stream()), "sdy_conv1x1")
     return out
+
+
+def pack_h3(weight: torch.Tensor, device):
+    """(Cout, Cin) fp32 weight -> (device buffer, scale) for the split-fp16 conv path."""
+    w = weight.detach().to("cpu", torch.float32).reshape(weight.shape[0], -1).contiguous()
+    Cout, Cin = w.shape
+    nbytes = lib.sdy_h3_pack_bytes(Cout, Cin)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    sc = C.c_float()
+    with torch.cuda.device(device):
+        check(lib.sdy_h3_pack_weight(ptr(w), Cout, Cin, ptr(buf), C.byref(sc)), "sdy_h3_pack_weight")
+    return buf, sc.value
 
 
 def cold_update(x_s: torch.Tensor, x_ip_next: torch.Tensor, x_ip_s: Optional[torch.Tensor]) -> torch.Tensor:

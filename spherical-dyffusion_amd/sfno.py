@@ -51,6 +51,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         time_scale_shift_before_filter: bool = True,
         data_grid: str = "equiangular",
         seed: int = 0,
+        gemm_mode: Optional[str] = None,   # "f32" (fp32 MFMA) | "h3" (split-fp16 3-pass MFMA); default $SDY_GEMM_MODE or "f32"
         **unused,
     ):
         super().__init__()
@@ -93,6 +94,10 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         self.max_time: Optional[float] = None
         self.inference_dropout = False
         self.seed = int(seed)
+        import os as _os
+        self.gemm_mode = gemm_mode or _os.environ.get("SDY_GEMM_MODE", "h3")
+        if self.gemm_mode not in ("f32", "h3"):
+            raise ValueError(f"gemm_mode must be 'f32' or 'h3', got {self.gemm_mode!r}")
         self.batch_offset = 0           # global index of the first trajectory this rank owns
         self._call = 0                  # advances the dropout stream on every forward
         self.mask_injector = None       # tests: callable(call_index) -> (keep_masks, drop_path_keep) replacing Philox
@@ -194,6 +199,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         c.with_time_emb, c.time_dim = int(self.with_time_emb), self.time_dim
         c.dropout_mlp, c.drop_path_rate = self.dropout_mlp, self.drop_path_rate
         c.big_skip, c.pos_embed = int(self.big_skip), int(self.use_pos_embed)
+        c.gemm_mode = 1 if self.gemm_mode == "h3" else 0
         return c
 
     def _get_native(self, device: torch.device) -> C.c_void_p:

@@ -186,3 +186,32 @@ def test_errors_are_reported(sdy):
         sdy.RealSHT(30, 62, grid="equiangular")(torch.zeros(1, 4, 30, 62).cuda())  # nlon % 4 != 0
     with pytest.raises(RuntimeError):
         sdy.RealSHT(32, 64)(torch.zeros(1, 4, 32, 64))  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 8, 16, 32, 64), (1, 70, 256, 45, 64), (2, 256, 34, 32, 64),
+                                            (1, 512, 256, 45, 64), (1, 36, 130, 20, 12)])
+def test_conv1x1_split_fp16_mode(sdy, B, Cin, Cout, H, W):
+    """gemm_mode "h3": 3-pass split-fp16 MFMA must hold the same per-op tolerance as the fp32-MFMA kernel."""
+    g = _gen(9)
+    F = torch.nn.functional
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.7 + 0.3
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = 0.1 * torch.randn(Cout, generator=g)
+    add = torch.randn(B, Cout, H, W, generator=g)
+    pa = 1 + 0.2 * torch.randn(B, Cin, generator=g)
+    pd = 0.2 * torch.randn(B, Cin, generator=g)
+    xd = x.double() * pa.double()[:, :, None, None] + pd.double()[:, :, None, None]
+    ref64 = F.conv2d(xd, w.double(), b.double())
+    got = sdy.ops.conv1x1(x.cuda(), w, b, pre_affine=(pa.cuda(), pd.cuda()), h3=True)
+    got32 = sdy.ops.conv1x1(x.cuda(), w, b, pre_affine=(pa.cuda(), pd.cuda()))
+    e_h3, e_f32 = rel_l2(got, ref64), rel_l2(got32, ref64)
+    assert e_h3 < TOL_OP, f"h3 vs fp64: {e_h3:.3e} (fp32 kernel: {e_f32:.3e})"
+    assert e_h3 < 4 * e_f32 + 2e-7, f"h3 {e_h3:.3e} much worse than fp32 kernel {e_f32:.3e}"
+    ref = F.gelu(F.conv2d(x * pa[:, :, None, None] + pd[:, :, None, None], w, b) + add)
+    got = sdy.ops.conv1x1(x.cuda(), w, b, pre_affine=(pa.cuda(), pd.cuda()), add=add.cuda(), add_mode=1, gelu=True, h3=True)
+    assert rel_l2(got, ref) < TOL_OP
+    # tiny and large magnitudes (lo parts in the fp16 subnormal range / hi parts near the top of the range)
+    for s in (1e-3, 50.0):
+        got = sdy.ops.conv1x1((x * s).cuda(), w, None, h3=True)
+        err = rel_l2(got, F.conv2d(x.double() * s, w.double()))
+        assert err < 5e-6, f"scale {s}: {err:.3e}"

@@ -21,6 +21,8 @@ def run(name, B, Cin, Cout, reps=5, **kw):
     if kw.pop("addpost", False):
         extra["add"] = torch.randn(B, Cout, H, W, device=dev); extra["add_mode"] = 2
     extra.update(kw)
+    if extra.pop('h3', False):
+        extra['h3_prepared'] = sdy_amd.ops.pack_h3(w, dev)
     f = lambda: sdy_amd.ops.conv1x1(x, w, bias, out=out, wt_prepared=wt, **extra)
     f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,4 +43,10 @@ run("fc1: +dropout(philox)", B, 256, 512, affine=True, gelu=True, kernel_tag=1, 
 run("fc2: bias+addpost", B, 512, 256, addpost=True, kernel_tag=2)
 run("fc2: +dropout(philox)", B, 512, 256, addpost=True, kernel_tag=2, drop_p=0.1, seed=1, call=1)
 run("enc 65->256 gelu", B, 65, 256, gelu=True)
+for nm, ci, co, kw in [("h3 plain 256->256", 256, 256, {}), ("h3 plain 256->512", 256, 512, {}), ("h3 plain 512->256", 512, 256, {}),
+                       ("h3 skip", 256, 256, dict(addpre=True, gelu=True, kernel_tag=3)),
+                       ("h3 fc1 +dropout", 256, 512, dict(affine=True, gelu=True, kernel_tag=1, drop_p=0.1, seed=1, call=1)),
+                       ("h3 fc2 +dropout", 512, 256, dict(addpost=True, kernel_tag=2, drop_p=0.1, seed=1, call=1)),
+                       ("h3 enc 65->256", 65, 256, dict(gelu=True)), ("h3 dec 256->63", 256, 63, {})]:
+    run(nm, B, ci, co, h3=True, **kw)
 run("dec 256->63", B, 256, 63)
