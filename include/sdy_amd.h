@@ -64,6 +64,9 @@ typedef struct sdy_sht_plan sdy_sht_plan;
 int sdy_sht_tables_host(int nlat, int nlon, int lmax, int mmax, int grid, double* pct, double* w, double* theta);
 
 int sdy_sht_plan_create(int nlat, int nlon, int lmax, int mmax, int grid, sdy_sht_plan** out);
+/* gemm_mode: 0 = Legendre GEMMs on fp32 MFMA; 1 = split-fp16 3-pass MFMA (fp32-class accuracy, see sdy_sfno_config).
+ * sdy_sht_plan_create uses $SDY_GEMM_MODE ("f32" -> 0, otherwise 1). */
+int sdy_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, int grid, int gemm_mode, sdy_sht_plan** out);
 void sdy_sht_plan_destroy(sdy_sht_plan* plan);
 /* dims[0..5] = nlat, nlon, lmax, mmax, mtr, grid */
 int sdy_sht_plan_dims(const sdy_sht_plan* plan, int dims[6]);
@@ -100,6 +103,12 @@ int sdy_irfft_lon(const sdy_sht_plan* plan, const float* Yf, const float* bias, 
 int sdy_dhconv_pack_weight(const float* w_host, int Ci, int Co, int L, float* w_packed_dev, void* stream);
 int sdy_dhconv(const float* Cs_in, const float* w_packed, float* Cs_out, int L, int mtr, int B, int Ci, int Co,
                void* stream);
+/* Same contraction on the f16 matrix cores in split precision (3 passes, fp32-class accuracy): the weight is expanded to
+ * its real 2Ci x 2Co form, transposed and split into fp16 hi | lo on the host. */
+size_t sdy_dhconv_h3_pack_bytes(int Ci, int Co, int L);
+int sdy_dhconv_h3_pack_weight(const float* w_host, int Ci, int Co, int L, void* packed_dev, float* scale);
+int sdy_dhconv_h3(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B, int Ci,
+                  int Co, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * nn.InstanceNorm2d(C, eps, affine=True, track_running_stats=False) statistics folded with the block's time

@@ -74,6 +74,7 @@ SIGNATURES = {
     "sdy_error_string": (C.c_char_p, [C.c_int]),
     "sdy_sht_tables_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_sht_plan_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sdy_sht_plan_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sdy_sht_plan_destroy": (None, [C.c_void_p]),
     "sdy_sht_plan_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int * 6)]),
     "sdy_sht_workspace_floats": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
@@ -85,6 +86,10 @@ SIGNATURES = {
     "sdy_irfft_lon": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sdy_dhconv_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sdy_dhconv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sdy_dhconv_h3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "sdy_dhconv_h3_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "sdy_dhconv_h3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p]),
     "sdy_instnorm_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_conv1x1": (C.c_int, [C.POINTER(SdyConvArgs), C.c_void_p]),
@@ -119,6 +124,14 @@ def _load():
 
 
 lib = _load()
+
+
+def default_gemm_mode() -> str:
+    """"h3" (split-fp16 3-pass MFMA, the default) or "f32" (fp32-input MFMA); both hold the same parity tolerances."""
+    m = os.environ.get("SDY_GEMM_MODE", "h3")
+    if m not in ("h3", "f32"):
+        raise ValueError(f"SDY_GEMM_MODE must be 'h3' or 'f32', got {m!r}")
+    return m
 
 
 def check(rc: int, what: str = "") -> None:

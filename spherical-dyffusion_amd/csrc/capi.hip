@@ -2,6 +2,7 @@
 // the sampler arithmetic.  Host orchestration only -- every kernel lives in gemm.hip / fft.hip / pointwise.hip.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +13,38 @@
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// Generic host-side splitter: value(b, r, k) -> fp16 hi | lo planes [nb][rows_pad][Kpad], scaled by a power of two so
+// that max|v|*scale is in [2^12, 2^13) (hi stays far below the fp16 maximum, lo parts stay out of the subnormals).
+template <class F>
+static float h3_pack_host(std::vector<_Float16>& buf, int nb, int rows, int K, int rows_pad, int Kpad, F value) {
+  float mx = 0.f;
+  for (int b = 0; b < nb; ++b)
+    for (int r = 0; r < rows; ++r)
+      for (int k = 0; k < K; ++k) mx = std::fmax(mx, std::fabs(value(b, r, k)));
+  float s = 1.0f;
+  if (mx > 0.f && std::isfinite(mx)) {
+    int e;
+    std::frexp(mx, &e);            // mx = f * 2^e, f in [0.5, 1)
+    s = std::ldexp(1.0f, 13 - e);
+  }
+  const size_t plane = (size_t)nb * rows_pad * Kpad;
+  buf.assign(2 * plane, (_Float16)0.0f);
+  _Float16* hi = buf.data();
+  _Float16* lo = hi + plane;
+  for (int b = 0; b < nb; ++b)
+    for (int r = 0; r < rows; ++r) {
+      const size_t base = ((size_t)b * rows_pad + r) * Kpad;
+      for (int k = 0; k < K; ++k) {
+        const float v = value(b, r, k) * s;
+        const _Float16 hv = (_Float16)v;
+        hi[base + k] = hv;
+        lo[base + k] = (_Float16)(v - (float)hv);
+      }
+    }
+  return s;
+}
+
 
 extern "C" int sdy_version(void) { return 100; }
 
@@ -40,9 +73,26 @@ struct sdy_sht_plan {
   float* d_tw = nullptr;
   float* d_pw = nullptr;
   SdyFftDesc fft;
+  // gemm_mode 1: split-fp16 copies of the two tables, [mtr][rows_pad][Kpad] hi | lo (gemm_h3.hip)
+  int gemm_mode = 0;
+  void* d_wq_h3 = nullptr;   // analysis: rows l, k = latitude
+  void* d_pct_h3 = nullptr;  // synthesis: rows = latitude, k = l
+  float s_wq = 1.f, s_pct = 1.f;
+  int h3_rows_fwd = 0, h3_k_fwd = 0, h3_rows_inv = 0, h3_k_inv = 0;
 };
 
+static int env_gemm_mode() {
+  const char* e = std::getenv("SDY_GEMM_MODE");
+  return (e && std::string(e) == "f32") ? 0 : 1;
+}
+
 extern "C" int sdy_sht_plan_create(int nlat, int nlon, int lmax, int mmax, int grid, sdy_sht_plan** out) {
+  return sdy_sht_plan_create_ex(nlat, nlon, lmax, mmax, grid, env_gemm_mode(), out);
+}
+
+extern "C" int sdy_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, int grid, int gemm_mode,
+                                      sdy_sht_plan** out) {
+  if (gemm_mode != 0 && gemm_mode != 1) return SDY_ERR_ARG;
   if (!out || nlat < 2 || nlon < 4 || lmax < 1 || mmax < 1) return SDY_ERR_ARG;
   if (nlon % 4) return SDY_ERR_ALIGN;
   if (mmax > nlon / 2 + 1) return SDY_ERR_ARG;
@@ -94,6 +144,25 @@ extern "C" int sdy_sht_plan_create(int nlat, int nlon, int lmax, int mmax, int g
   PLAN_UP(p->d_tw, tw)
   PLAN_UP(p->d_pw, pw)
 #undef PLAN_UP
+  p->gemm_mode = gemm_mode;
+  if (gemm_mode == 1) {
+    // the fp32 tables (exactly what the reference's `.float()` buffers hold) split into fp16 hi + lo
+    std::vector<_Float16> buf;
+    p->h3_rows_fwd = round_up(lmax, 128); p->h3_k_fwd = round_up(nlat, 64);
+    p->s_wq = h3_pack_host(buf, mtr, lmax, nlat, p->h3_rows_fwd, p->h3_k_fwd, [&](int m, int l, int k) {
+      return wqT[((size_t)m * nlat + k) * p->Lpad4 + l];
+    });
+    e = hipMalloc(&p->d_wq_h3, buf.size() * sizeof(_Float16));
+    if (e == hipSuccess) e = hipMemcpy(p->d_wq_h3, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { sdy_sht_plan_destroy(p); return (int)e; }
+    p->h3_rows_inv = round_up(nlat, 128); p->h3_k_inv = round_up(lmax, 64);
+    p->s_pct = h3_pack_host(buf, mtr, nlat, lmax, p->h3_rows_inv, p->h3_k_inv, [&](int m, int k, int l) {
+      return pf[((size_t)m * lmax + l) * p->Kpad4 + k];
+    });
+    e = hipMalloc(&p->d_pct_h3, buf.size() * sizeof(_Float16));
+    if (e == hipSuccess) e = hipMemcpy(p->d_pct_h3, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { sdy_sht_plan_destroy(p); return (int)e; }
+  }
   p->fft.tw = p->d_tw;
   p->fft.pw = p->d_pw;
   *out = p;
@@ -106,6 +175,8 @@ extern "C" void sdy_sht_plan_destroy(sdy_sht_plan* p) {
   if (p->d_pct) (void)hipFree(p->d_pct);
   if (p->d_tw) (void)hipFree(p->d_tw);
   if (p->d_pw) (void)hipFree(p->d_pw);
+  if (p->d_wq_h3) (void)hipFree(p->d_wq_h3);
+  if (p->d_pct_h3) (void)hipFree(p->d_pct_h3);
   delete p;
 }
 
@@ -146,6 +217,9 @@ extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* C
   g.C = Cs; g.ldc = p->mtr * N; g.sC = N;
   g.M = p->Lpad4; g.M_store = p->lmax; g.N = N; g.K = p->nlat; g.nbatch = p->mtr;
   g.tri_mode = SDY_TRI_LEG_FWD; g.tile = SDY_TILE_64x128;
+  if (p->gemm_mode == 1)
+    return sdy_gemm_h3_launch(g, p->d_wq_h3, p->h3_rows_fwd, p->h3_k_fwd, (long)p->h3_rows_fwd * p->h3_k_fwd,
+                              (long)p->mtr * p->h3_rows_fwd * p->h3_k_fwd, p->s_wq, 0, (hipStream_t)stream);
   return sdy_gemm_launch(g, (hipStream_t)stream);
 }
 
@@ -159,6 +233,9 @@ extern "C" int sdy_legendre_inv(const sdy_sht_plan* p, const float* Cs, float* Y
   g.C = Yf; g.ldc = N; g.sC = (long)p->nlat * N;
   g.M = p->Kpad4; g.M_store = p->nlat; g.N = N; g.K = p->lmax; g.nbatch = p->mtr;
   g.tri_mode = SDY_TRI_LEG_INV; g.tile = SDY_TILE_64x128;
+  if (p->gemm_mode == 1)
+    return sdy_gemm_h3_launch(g, p->d_pct_h3, p->h3_rows_inv, p->h3_k_inv, (long)p->h3_rows_inv * p->h3_k_inv,
+                              (long)p->mtr * p->h3_rows_inv * p->h3_k_inv, p->s_pct, 0, (hipStream_t)stream);
   return sdy_gemm_launch(g, (hipStream_t)stream);
 }
 
@@ -216,6 +293,42 @@ extern "C" int sdy_dhconv(const float* Cs_in, const float* w_packed, float* Cs_o
   return sdy_gemm_launch(g, (hipStream_t)stream);
 }
 
+static inline int dh_npad(int Co) { return round_up(2 * Co, 128); }
+static inline int dh_kpad(int Ci) { return round_up(2 * Ci, 64); }
+
+extern "C" size_t sdy_dhconv_h3_pack_bytes(int Ci, int Co, int L) {
+  if (Ci <= 0 || Co <= 0 || L <= 0) return 0;
+  return (size_t)2 * L * dh_npad(Co) * dh_kpad(Ci) * sizeof(_Float16);
+}
+
+// (Ci, Co, L, 2) -> per l the TRANSPOSED expanded real matrix W'^T[o'][i'], W' = [[wr, wi], [-wi, wr]] with rows
+// i' = (ri_in, i) and columns o' = (ri_out, o), split into fp16 hi | lo
+extern "C" int sdy_dhconv_h3_pack_weight(const float* w, int Ci, int Co, int L, void* packed_dev, float* scale) {
+  if (!w || !packed_dev || !scale || Ci <= 0 || Co <= 0 || L <= 0) return SDY_ERR_ARG;
+  std::vector<_Float16> buf;
+  *scale = h3_pack_host(buf, L, 2 * Co, 2 * Ci, dh_npad(Co), dh_kpad(Ci), [&](int l, int op, int ip) {
+    const int ro = op >= Co, o = op - ro * Co, ri = ip >= Ci, i = ip - ri * Ci;
+    const float* e = w + (((size_t)i * Co + o) * L + l) * 2;
+    if (ri == ro) return e[0];
+    return ri ? -e[1] : e[1];
+  });
+  SDY_HIP_TRY(hipMemcpy(packed_dev, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  return SDY_OK;
+}
+
+extern "C" int sdy_dhconv_h3(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B,
+                             int Ci, int Co, void* stream) {
+  if (!Cs_in || !packed || !Cs_out || L <= 0 || mtr <= 0 || B <= 0 || Ci <= 0 || Co <= 0) return SDY_ERR_ARG;
+  if ((Ci & 3) || (Co & 3)) return SDY_ERR_ALIGN;
+  GemmParams g{};
+  g.A = Cs_in; g.lda = 2 * Ci; g.sA = (long)mtr * B * 2 * Ci;
+  g.C = Cs_out; g.ldc = 2 * Co; g.sC = (long)mtr * B * 2 * Co;
+  g.M = mtr * B; g.M_store = mtr * B; g.N = 2 * Co; g.K = 2 * Ci; g.nbatch = L;
+  g.tri_mode = SDY_TRI_DHCONV; g.tri_B = B;
+  const int Np = dh_npad(Co), Kp = dh_kpad(Ci);
+  return sdy_gemm_h3_launch(g, packed, Np, Kp, (long)Np * Kp, (long)L * Np * Kp, scale, 1, (hipStream_t)stream);
+}
+
 // =========================================================================================================
 // InstanceNorm coefficients, 1x1 conv, sampler arithmetic
 // =========================================================================================================
@@ -235,27 +348,10 @@ extern "C" size_t sdy_h3_pack_bytes(int Cout, int Cin) {
 
 extern "C" int sdy_h3_pack_weight(const float* w, int Cout, int Cin, void* packed_dev, float* scale) {
   if (!w || !packed_dev || !scale || Cout <= 0 || Cin <= 0) return SDY_ERR_ARG;
-  const int Mp = h3_mpad(Cout), Kp = h3_kpad(Cin);
-  float mx = 0.f;
-  for (size_t i = 0; i < (size_t)Cout * Cin; ++i) mx = std::fmax(mx, std::fabs(w[i]));
-  float s = 1.0f;
-  if (mx > 0.f && std::isfinite(mx)) {
-    int e;
-    std::frexp(mx, &e);            // mx = f * 2^e, f in [0.5, 1)
-    s = std::ldexp(1.0f, 13 - e);  // mx * s in [2^12, 2^13)
-  }
-  std::vector<_Float16> buf((size_t)2 * Mp * Kp, (_Float16)0.0f);
-  _Float16* hi = buf.data();
-  _Float16* lo = hi + (size_t)Mp * Kp;
-  for (int o = 0; o < Cout; ++o)
-    for (int i = 0; i < Cin; ++i) {
-      const float v = w[(size_t)o * Cin + i] * s;
-      const _Float16 hv = (_Float16)v;
-      hi[(size_t)o * Kp + i] = hv;
-      lo[(size_t)o * Kp + i] = (_Float16)(v - (float)hv);
-    }
+  std::vector<_Float16> buf;
+  *scale = h3_pack_host(buf, 1, Cout, Cin, h3_mpad(Cout), h3_kpad(Cin),
+                        [&](int, int o, int i) { return w[(size_t)o * Cin + i]; });
   SDY_HIP_TRY(hipMemcpy(packed_dev, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-  *scale = s;
   return SDY_OK;
 }
 
@@ -287,8 +383,10 @@ extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
   g.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFu); g.seed_hi = (uint32_t)(a->seed >> 32);
   g.stream_id = a->stream_id; g.call = a->call; g.batch_offset = a->batch_offset;
   g.batch_scale = a->batch_scale;
-  if (a->w_h3)
-    return sdy_gemm_h3_launch(g, a->w_h3, h3_mpad(a->Cout), h3_kpad(a->Cin), a->w_h3_scale, (hipStream_t)stream);
+  if (a->w_h3) {
+    const int Mp = h3_mpad(a->Cout), Kp = h3_kpad(a->Cin);
+    return sdy_gemm_h3_launch(g, a->w_h3, Mp, Kp, 0, (long)Mp * Kp, a->w_h3_scale, 0, (hipStream_t)stream);
+  }
   return sdy_gemm_launch(g, (hipStream_t)stream);
 }
 
@@ -398,12 +496,13 @@ extern "C" int sdy_sfno_create(const sdy_sfno_config* c, sdy_sfno** out) {
   n->decC = c->embed_dim + (c->big_skip ? c->in_chans : 0);  // what the decoder reads (sfnonet.py:736)
   n->ldo = round_up(c->out_chans, 4);
   n->blk.resize(c->num_layers);
-  int r = sdy_sht_plan_create(c->nlat, c->nlon, c->lmax, c->mmax, c->data_grid, &n->plan_data);
+  if (c->gemm_mode != 0 && c->gemm_mode != 1) { delete n; return SDY_ERR_ARG; }
+  int r = sdy_sht_plan_create_ex(c->nlat, c->nlon, c->lmax, c->mmax, c->data_grid, c->gemm_mode, &n->plan_data);
   if (r != SDY_OK) { delete n; return r; }
   if (c->data_grid == SDY_GRID_LEGENDRE_GAUSS) {
     n->plan_lg = n->plan_data;
   } else {
-    r = sdy_sht_plan_create(c->nlat, c->nlon, c->lmax, c->mmax, SDY_GRID_LEGENDRE_GAUSS, &n->plan_lg);
+    r = sdy_sht_plan_create_ex(c->nlat, c->nlon, c->lmax, c->mmax, SDY_GRID_LEGENDRE_GAUSS, c->gemm_mode, &n->plan_lg);
     if (r != SDY_OK) { sdy_sfno_destroy(n); return r; }
   }
   // defaults that a caller may override with "@time_freq" / "@drop_path_rates"
@@ -511,8 +610,15 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
     }
     if (rest == "filter.filter.weight") {
       EXPECT_NUMEL((size_t)E * E * c.lmax * 2);
-      SDY_TRY(dev_alloc(w.fw, numel));
-      SDY_TRY(sdy_dhconv_pack_weight(host, E, E, c.lmax, w.fw.p, nullptr));
+      if (h3) {
+        if (w.fw.h3) (void)hipFree(w.fw.h3);
+        w.fw.h3 = nullptr;
+        SDY_HIP_TRY(hipMalloc(&w.fw.h3, sdy_dhconv_h3_pack_bytes(E, E, c.lmax)));
+        SDY_TRY(sdy_dhconv_h3_pack_weight(host, E, E, c.lmax, w.fw.h3, &w.fw.h3_scale));
+      } else {
+        SDY_TRY(dev_alloc(w.fw, numel));
+        SDY_TRY(sdy_dhconv_pack_weight(host, E, E, c.lmax, w.fw.p, nullptr));
+      }
       w.fw.set = true;
       return SDY_OK;
     }
@@ -678,7 +784,10 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       SDY_TRY(sdy_legendre_inv(pout, Cs, Xf, B, E, stream));
       SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, stream));
     }
-    SDY_TRY(sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
+    if (c.gemm_mode == 1)
+      SDY_TRY(sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
+    else
+      SDY_TRY(sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     SDY_TRY(sdy_legendre_inv(pout, Cs2, Xf, B, E, stream));
     SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y

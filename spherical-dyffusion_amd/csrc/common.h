@@ -100,7 +100,9 @@ struct GemmParams {
 };
 int sdy_gemm_launch(const GemmParams& p, hipStream_t stream);
 // split-fp16 (3-pass) conv GEMM, gemm_h3.hip; packed = fp16 [Mpad][Kpad] hi then lo, scaled by w_scale
-int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int Mpad, int Kpad, float w_scale, hipStream_t stream);
+//   rows_mode 0: packed = A [M][K], p.B = fp32 [K][N];  rows_mode 1: p.A = fp32 [M][K] (k contiguous), packed = B [N][K]
+int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, int Kpad, long bstride, long plane_halfs,
+                       float w_scale, int rows_mode, hipStream_t stream);
 
 // ---- host tables (tables.cpp) --------------------------------------------------------------------------
 int sdy_factor_radices(int n, int* radices, int* nstages);  // n = prod(radices), radices in {4,2,3,5}

@@ -144,6 +144,48 @@ __device__ __forceinline__ void fft_rows(const SdyFftDesc& f, LdsView& L, int S,
   *res_im = sim;
 }
 
+// Compile-time variant: every stride / divisor is a constant, so hipcc folds the integer divisions of the generic path
+// (several per butterfly, ~25 VALU instructions each on CDNA) into multiply-shifts and fully unrolls the stage loop.
+template <int N_HALF>
+struct FftShape;
+template <>
+struct FftShape<180> {  // nlon = 360
+  static constexpr int nst = 4;
+  static constexpr int r[4] = {4, 3, 3, 5};
+};
+template <>
+struct FftShape<32> {   // nlon = 64 (test grids)
+  static constexpr int nst = 3;
+  static constexpr int r[4] = {4, 4, 2, 1};
+};
+
+template <int N_HALF, int ST, int NS>
+__device__ __forceinline__ void fft_stage_ct(float*& sre, float*& sim, float*& dre, float*& dim_, const float* twr,
+                                             const float* twi, int S, float s) {
+  if constexpr (ST < FftShape<N_HALF>::nst) {
+    constexpr int R = FftShape<N_HALF>::r[ST];
+    constexpr int nb = N_HALF / R;
+    constexpr int tstride = N_HALF / (NS * R);
+    for (int id = threadIdx.x; id < CB * nb; id += NT) {
+      const int r = id / nb, j = id - r * nb;
+      butterfly<R>(sre + r * S, sim + r * S, dre + r * S, dim_ + r * S, j, nb, NS, tstride, twr, twi, s);
+    }
+    __syncthreads();
+    float* t;
+    t = sre; sre = dre; dre = t;
+    t = sim; sim = dim_; dim_ = t;
+    fft_stage_ct<N_HALF, ST + 1, NS * R>(sre, sim, dre, dim_, twr, twi, S, s);
+  }
+}
+
+template <int N_HALF>
+__device__ __forceinline__ void fft_rows_ct(LdsView& L, int S, float s, float** res_re, float** res_im) {
+  float *sre = L.a_re, *sim = L.a_im, *dre = L.b_re, *dim_ = L.b_im;
+  fft_stage_ct<N_HALF, 0, 1>(sre, sim, dre, dim_, L.tw_re, L.tw_im, S, s);
+  *res_re = sre;
+  *res_im = sim;
+}
+
 __device__ __forceinline__ void load_tables(const SdyFftDesc& f, LdsView& L) {
   const int n = f.n;
   for (int i = threadIdx.x; i < n; i += NT) {
@@ -156,13 +198,14 @@ __device__ __forceinline__ void load_tables(const SdyFftDesc& f, LdsView& L) {
   }
 }
 
-// x (B,C,K,N) -> Xf[m][k][b][ri][c]
+// x (B,C,K,N) -> Xf[m][k][b][ri][c]      (NH = nlon/2 known at compile time, or 0 for the generic path)
+template <int NH>
 __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const float* __restrict__ x,
                                                        const float* __restrict__ pa, const float* __restrict__ pd,
                                                        float* __restrict__ xn_out, float* __restrict__ Xf, int B,
                                                        int C, int K, int mtr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int n = f.n, N = 2 * n, S = f.S;
+  const int n = NH ? NH : f.n, N = 2 * n, S = NH ? ((NH + 1) | 1) : f.S;
   LdsView L = carve(sm, S, n);
   const int c0 = blockIdx.x * CB, k = blockIdx.y, b = blockIdx.z;
   load_tables(f, L);
@@ -186,7 +229,10 @@ __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const 
   __syncthreads();
 
   float *zr, *zi;
-  fft_rows(f, L, S, -1.0f, &zr, &zi);
+  if constexpr (NH != 0)
+    fft_rows_ct<NH>(L, S, -1.0f, &zr, &zi);
+  else
+    fft_rows(f, L, S, -1.0f, &zr, &zi);
 
   // split step: X[m] = E + w^m O, X[n-m] = conj(E - w^m O); scaled by 2*pi/N
   const float scale = 6.28318530717958647692f / (float)N;
@@ -219,11 +265,12 @@ __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const 
 }
 
 // Yf[m][k][b][ri][c] -> y (B,C,K,N) (+ bias[c])
+template <int NH>
 __global__ __launch_bounds__(NT) void irfft_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
                                                     const float* __restrict__ bias, float* __restrict__ y, int B, int C,
                                                     int K, int mtr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int n = f.n, N = 2 * n, S = f.S;
+  const int n = NH ? NH : f.n, N = 2 * n, S = NH ? ((NH + 1) | 1) : f.S;
   LdsView L = carve(sm, S, n);
   const int c0 = blockIdx.x * CB, k = blockIdx.y, b = blockIdx.z;
   load_tables(f, L);
@@ -269,7 +316,10 @@ __global__ __launch_bounds__(NT) void irfft_kernel(const SdyFftDesc f, const flo
   __syncthreads();
 
   float *zr, *zi;
-  fft_rows(f, L, S, +1.0f, &zr, &zi);
+  if constexpr (NH != 0)
+    fft_rows_ct<NH>(L, S, +1.0f, &zr, &zi);
+  else
+    fft_rows(f, L, S, +1.0f, &zr, &zi);
 
   const int q4 = N / 4;
   for (int idx = threadIdx.x; idx < CB * q4; idx += NT) {
@@ -296,7 +346,12 @@ int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, cons
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   dim3 grid((C + CB - 1) / CB, K, B);
-  hipLaunchKernelGGL(rfft_fwd_kernel, grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  if (f.n == 180)
+    hipLaunchKernelGGL(rfft_fwd_kernel<180>, grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  else if (f.n == 32)
+    hipLaunchKernelGGL(rfft_fwd_kernel<32>, grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  else
+    hipLaunchKernelGGL(rfft_fwd_kernel<0>, grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
   return sdy_launch_status();
 }
 
@@ -305,6 +360,11 @@ int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, 
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   dim3 grid((C + CB - 1) / CB, K, B);
-  hipLaunchKernelGGL(irfft_kernel, grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+  if (f.n == 180)
+    hipLaunchKernelGGL(irfft_kernel<180>, grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+  else if (f.n == 32)
+    hipLaunchKernelGGL(irfft_kernel<32>, grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+  else
+    hipLaunchKernelGGL(irfft_kernel<0>, grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
   return sdy_launch_status();
 }

@@ -26,7 +26,7 @@ def _aux(t: torch.Tensor, dev) -> torch.Tensor:
 
 
 def contract_dhconv(x: torch.Tensor, weight: torch.Tensor, separable: bool = False,
-                    operator_type: str = "dhconv") -> torch.Tensor:
+                    operator_type: str = "dhconv", gemm_mode: Optional[str] = None) -> torch.Tensor:
     """`_contract_dense_pytorch(x, weight, separable=False, operator_type="dhconv")`
     (`src/models/sfno/factorizations.py:165-186` -> `contractions.py:159-169`):
     x (B, Ci, L, M) complex64, weight (Ci, Co, L, 2) real -> (B, Co, L, M) complex64,
@@ -42,11 +42,19 @@ def contract_dhconv(x: torch.Tensor, weight: torch.Tensor, separable: bool = Fal
     xr = torch.view_as_real(x.to(torch.complex64).contiguous())          # (B,Ci,L,M,2)
     cs_in = xr[:, :, :, :mtr].permute(2, 3, 0, 4, 1).contiguous()         # [l][m][b][ri][c]
     cs_out = torch.zeros(L, mtr, B, 2, Co, dtype=torch.float32, device=x.device)
-    wp = torch.empty(L * 2 * Ci * Co, dtype=torch.float32, device=x.device)
     w_host = weight.detach().to(torch.float32).cpu().contiguous()
+    from ._lib import default_gemm_mode
     with torch.cuda.device(x.device):
-        check(lib.sdy_dhconv_pack_weight(ptr(w_host), Ci, Co, L, ptr(wp), current_stream()), "sdy_dhconv_pack_weight")
-        check(lib.sdy_dhconv(ptr(cs_in), ptr(wp), ptr(cs_out), L, mtr, B, Ci, Co, current_stream()), "sdy_dhconv")
+        if (gemm_mode or default_gemm_mode()) == "h3":
+            wp = torch.empty(lib.sdy_dhconv_h3_pack_bytes(Ci, Co, L), dtype=torch.uint8, device=x.device)
+            sc = C.c_float()
+            check(lib.sdy_dhconv_h3_pack_weight(ptr(w_host), Ci, Co, L, ptr(wp), C.byref(sc)), "sdy_dhconv_h3_pack_weight")
+            check(lib.sdy_dhconv_h3(ptr(cs_in), ptr(wp), sc.value, ptr(cs_out), L, mtr, B, Ci, Co, current_stream()),
+                  "sdy_dhconv_h3")
+        else:
+            wp = torch.empty(L * 2 * Ci * Co, dtype=torch.float32, device=x.device)
+            check(lib.sdy_dhconv_pack_weight(ptr(w_host), Ci, Co, L, ptr(wp), current_stream()), "sdy_dhconv_pack_weight")
+            check(lib.sdy_dhconv(ptr(cs_in), ptr(wp), ptr(cs_out), L, mtr, B, Ci, Co, current_stream()), "sdy_dhconv")
     out = torch.zeros(B, Co, L, M, 2, dtype=torch.float32, device=x.device)
     out[:, :, :, :mtr] = cs_out.permute(2, 4, 0, 1, 3)
     tri = (torch.arange(M, device=x.device)[None, :] <= torch.arange(L, device=x.device)[:, None])

@@ -94,8 +94,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         self.max_time: Optional[float] = None
         self.inference_dropout = False
         self.seed = int(seed)
-        import os as _os
-        self.gemm_mode = gemm_mode or _os.environ.get("SDY_GEMM_MODE", "h3")
+        self.gemm_mode = gemm_mode or _lib.default_gemm_mode()
         if self.gemm_mode not in ("f32", "h3"):
             raise ValueError(f"gemm_mode must be 'f32' or 'h3', got {self.gemm_mode!r}")
         self.batch_offset = 0           # global index of the first trajectory this rank owns

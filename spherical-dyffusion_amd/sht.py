@@ -20,11 +20,12 @@ class ShtPlan:
 
     _cache = {}
 
-    def __init__(self, nlat, nlon, lmax, mmax, grid):
+    def __init__(self, nlat, nlon, lmax, mmax, grid, gemm_mode="h3"):
         if grid not in _lib.SDY_GRID:
             raise ValueError(f"unsupported grid {grid!r} (supported: {sorted(_lib.SDY_GRID)})")
         h = C.c_void_p()
-        check(lib.sdy_sht_plan_create(nlat, nlon, lmax, mmax, _lib.SDY_GRID[grid], C.byref(h)), "sdy_sht_plan_create")
+        check(lib.sdy_sht_plan_create_ex(nlat, nlon, lmax, mmax, _lib.SDY_GRID[grid], 1 if gemm_mode == "h3" else 0,
+                                         C.byref(h)), "sdy_sht_plan_create_ex")
         self.handle = h
         dims = (C.c_int * 6)()
         check(lib.sdy_sht_plan_dims(h, C.byref(dims)))
@@ -32,11 +33,12 @@ class ShtPlan:
         self.grid = grid
 
     @classmethod
-    def get(cls, nlat, nlon, lmax, mmax, grid, device_index):
-        key = (nlat, nlon, lmax, mmax, grid, device_index)
+    def get(cls, nlat, nlon, lmax, mmax, grid, device_index, gemm_mode=None):
+        gemm_mode = gemm_mode or _lib.default_gemm_mode()
+        key = (nlat, nlon, lmax, mmax, grid, device_index, gemm_mode)
         if key not in cls._cache:
             with torch.cuda.device(device_index):
-                cls._cache[key] = cls(nlat, nlon, lmax, mmax, grid)
+                cls._cache[key] = cls(nlat, nlon, lmax, mmax, grid, gemm_mode)
         return cls._cache[key]
 
     def __del__(self):
@@ -49,8 +51,10 @@ class ShtPlan:
 
 
 class _ShtBase(torch.nn.Module):
-    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="equiangular", norm="ortho", csphase=True):
+    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="equiangular", norm="ortho", csphase=True,
+                 gemm_mode=None):
         super().__init__()
+        self.gemm_mode = gemm_mode   # None -> $SDY_GEMM_MODE or "h3" (split-fp16 MFMA); "f32" = fp32 MFMA
         if norm != "ortho" or not csphase:
             raise NotImplementedError("only norm='ortho', csphase=True (what the reference uses) is implemented")
         self.nlat, self.nlon, self.grid = nlat, nlon, grid
@@ -64,7 +68,7 @@ class _ShtBase(torch.nn.Module):
 
     def _plan(self, device) -> ShtPlan:
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        return ShtPlan.get(self.nlat, self.nlon, self.lmax, self.mmax, self.grid, idx)
+        return ShtPlan.get(self.nlat, self.nlon, self.lmax, self.mmax, self.grid, idx, self.gemm_mode)
 
     @staticmethod
     def _require_gpu(x):

@@ -26,15 +26,19 @@ def _gen(seed):
     return torch.Generator(device="cpu").manual_seed(seed)
 
 
+MODES = ["f32", "h3"]   # fp32-input MFMA / split-fp16 3-pass MFMA: same tolerances
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("grid", ["equiangular", "legendre-gauss"])
 @pytest.mark.parametrize("nlat,nlon", GRIDS)
-def test_real_sht_forward(sdy, nlat, nlon, grid):
+def test_real_sht_forward(sdy, nlat, nlon, grid, mode):
     from oracle.sht import RealSHT as ORef
 
     C = 8 if nlat > 64 else 12
     x = torch.randn(2, C, nlat, nlon, generator=_gen(1))
     ref = ORef(nlat, nlon, lmax=nlat, mmax=nlon // 2 + 1, grid=grid).float()(x)
-    got = sdy.RealSHT(nlat, nlon, lmax=nlat, mmax=nlon // 2 + 1, grid=grid).float()(x.cuda())
+    got = sdy.RealSHT(nlat, nlon, lmax=nlat, mmax=nlon // 2 + 1, grid=grid, gemm_mode=mode).float()(x.cuda())
     assert got.shape == ref.shape and got.dtype == torch.complex64
     err = rel_l2(got, ref)
     assert err < TOL_OP, f"RealSHT {nlat}x{nlon} {grid}: rel L2 {err:.3e}"
@@ -44,16 +48,17 @@ def test_real_sht_forward(sdy, nlat, nlon, grid):
     assert (got.cpu()[..., (m > l)] == 0).all()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("grid", ["equiangular", "legendre-gauss"])
 @pytest.mark.parametrize("nlat,nlon", GRIDS)
-def test_inverse_real_sht(sdy, nlat, nlon, grid):
+def test_inverse_real_sht(sdy, nlat, nlon, grid, mode):
     from oracle.sht import InverseRealSHT as ORef
 
     C = 8 if nlat > 64 else 12
     L, M = nlat, nlon // 2 + 1
     c = torch.randn(2, C, L, M, dtype=torch.complex64, generator=_gen(2))  # dense, incl. m > l and imag of m = 0
     ref = ORef(nlat, nlon, lmax=L, mmax=M, grid=grid).float()(c)
-    got = sdy.InverseRealSHT(nlat, nlon, lmax=L, mmax=M, grid=grid).float()(c.cuda())
+    got = sdy.InverseRealSHT(nlat, nlon, lmax=L, mmax=M, grid=grid, gemm_mode=mode).float()(c.cuda())
     err = rel_l2(got, ref)
     assert err < TOL_OP, f"InverseRealSHT {nlat}x{nlon} {grid}: rel L2 {err:.3e}"
 
@@ -74,8 +79,9 @@ def test_sht_roundtrip_bandlimited(sdy):
     assert err < 2e-5, f"round trip rel L2 {err:.3e}"
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,E,L,M", [(2, 8, 32, 33), (1, 256, 180, 181), (3, 16, 20, 11)])
-def test_dhconv(sdy, B, E, L, M):
+def test_dhconv(sdy, B, E, L, M, mode):
     g = _gen(4)
     x = torch.randn(B, E, L, M, dtype=torch.complex64, generator=g)
     l = torch.arange(L)[:, None]
@@ -83,7 +89,7 @@ def test_dhconv(sdy, B, E, L, M):
     x = x * (m <= l)
     w = torch.randn(E, E, L, 2, generator=g) / np.sqrt(E)
     ref = torch.einsum("bixy,iox->boxy", x, torch.view_as_complex(w))
-    got = sdy.ops.contract_dhconv(x.cuda(), w.cuda())
+    got = sdy.ops.contract_dhconv(x.cuda(), w.cuda(), gemm_mode=mode)
     err = rel_l2(got, ref)
     assert err < TOL_OP, f"dhconv rel L2 {err:.3e}"
 
