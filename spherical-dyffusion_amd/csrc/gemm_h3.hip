@@ -15,7 +15,10 @@
 //        [n][k] -- the k-contiguous fragment the MFMA wants -- without a transposing kernel.
 //   MODE_ROWS (dhconv): activations A[M][K], k contiguous (rows (m,b) of the coefficient layout): split, no transpose;
 //        packed = B [N][K].
-// LDS rows are 64 halfs + 8 pad (144 B): ds_read_b128 fragment reads and ds_write_b64 staging writes are conflict free.
+// LDS rows are 32 halfs + 8 pad (80 B): ds_read_b128 fragment reads and ds_write_b64 staging writes are conflict free.
+// Global loads run TWO k-tiles ahead of the MFMAs (two register sets, loop unrolled by 2; hipcc's counted vmcnt waits
+// retire only the set that is about to be converted), because at f16 MFMA rates one tile of compute (~0.3 us) is far
+// shorter than a loaded memory round trip (~2 us): with one tile in flight the waves sat parked ~40 % of their life.
 // The accumulator layout equals gemm.hip's, so the fused epilogue (bias / add / GELU / Philox dropout / residual) is shared.
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -25,8 +28,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int HBK = 64;      // k-tile
-constexpr int HLD = 72;      // LDS row stride in halfs (64 + 8 pad)
+constexpr int HBK = 32;      // k-tile (two tiles are kept in flight, see the main loop)
+constexpr int HLD = 40;      // LDS row stride in halfs (32 + 8 pad = 80 B)
 constexpr int HCH = HBK / 8; // 16-byte chunks per packed row per k-tile
 constexpr int HKQ = HBK / 4; // 4-wide k groups per k-tile
 
@@ -49,7 +52,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& vh, f16x4& vl) {
 }
 
 template <int WM, int WN, int MODE, int TAG>
-__global__ __launch_bounds__(256) void gemm_h3_kernel(const GemmParams p, const H3Packed pk, float sx, float out_scale) {
+__global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, const H3Packed pk, float sx, float out_scale) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int PROWS = (MODE == MODE_COLS) ? BM : BN;   // rows of the packed operand per tile
   constexpr int FROWS = (MODE == MODE_COLS) ? BN : BM;   // rows (LDS rows) of the fp32 operand per tile
@@ -121,23 +124,26 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(const GemmParams p, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f32x4 rp_hi[NP], rp_lo[NP];                  // raw 16-byte chunks of the pre-split operand
-  f32x4 rb[MODE == MODE_COLS ? NBLK : 1][4];   // MODE_COLS: 4 k x 4 n
-  float ca[MODE == MODE_COLS ? NBLK : 1][4], cd[MODE == MODE_COLS ? NBLK : 1][4];
-  f32x4 rr[MODE == MODE_ROWS ? NR : 1];        // MODE_ROWS: 4 consecutive k of one row
+  struct Stage {
+    f32x4 rp_hi[NP], rp_lo[NP];                  // raw 16-byte chunks of the pre-split operand
+    f32x4 rb[MODE == MODE_COLS ? NBLK : 1][4];   // MODE_COLS: 4 k x 4 n
+    float ca[MODE == MODE_COLS ? NBLK : 1][4], cd[MODE == MODE_COLS ? NBLK : 1][4];
+    f32x4 rr[MODE == MODE_ROWS ? NR : 1];        // MODE_ROWS: 4 consecutive k of one row
+  };
+  Stage st0, st1;
 
   const int kq = tid % HKQ, pq = tid / HKQ;
   const int prow0 = (MODE == MODE_COLS) ? m0 : n0;   // first packed row of this tile
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](Stage& S, int kt) {
     const int k0 = kt * HBK;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int chunk = tid + i * 256;
       const int row = chunk / HCH, c = chunk % HCH;
       const long off = (long)(prow0 + row) * pk.Kpad + k0 + c * 8;   // rows / k are padded: no predicate
-      rp_hi[i] = *reinterpret_cast<const f32x4*>(Ph + off);
-      rp_lo[i] = *reinterpret_cast<const f32x4*>(Pl + off);
+      S.rp_hi[i] = *reinterpret_cast<const f32x4*>(Ph + off);
+      S.rp_lo[i] = *reinterpret_cast<const f32x4*>(Pl + off);
     }
     if constexpr (MODE == MODE_COLS) {
 #pragma unroll
@@ -156,9 +162,9 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(const GemmParams p, const 
               d = pd[gk];
             }
           }
-          rb[bi][kk] = v;
-          ca[bi][kk] = a;
-          cd[bi][kk] = d;
+          S.rb[bi][kk] = v;
+          S.ca[bi][kk] = a;
+          S.cd[bi][kk] = d;
         }
       }
     } else {
@@ -169,18 +175,18 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(const GemmParams p, const 
         const int gm = m0 + row, gk = k0 + q * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (gm < M_valid && gk < p.K) v = *reinterpret_cast<const f32x4*>(Fg + (long)gm * p.lda + gk);
-        rr[i] = v;
+        S.rr[i] = v;
       }
     }
   };
 
-  auto store_tile = [&]() {
+  auto store_tile = [&](const Stage& S) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int chunk = tid + i * 256;
       const int row = chunk / HCH, c = chunk % HCH;
-      *reinterpret_cast<f32x4*>(Ps_hi + row * HLD + c * 8) = rp_hi[i];
-      *reinterpret_cast<f32x4*>(Ps_lo + row * HLD + c * 8) = rp_lo[i];
+      *reinterpret_cast<f32x4*>(Ps_hi + row * HLD + c * 8) = S.rp_hi[i];
+      *reinterpret_cast<f32x4*>(Ps_lo + row * HLD + c * 8) = S.rp_lo[i];
     }
     if constexpr (MODE == MODE_COLS) {
 #pragma unroll
@@ -188,10 +194,10 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(const GemmParams p, const 
         _Float16 hi[4][4], lo[4][4];   // [k kk][n pp]
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const float a = ca[bi][kk] * sx, d = cd[bi][kk] * sx;
+          const float a = S.ca[bi][kk] * sx, d = S.cd[bi][kk] * sx;
 #pragma unroll
           for (int pp = 0; pp < 4; ++pp) {
-            const float v = fmaf(rb[bi][kk][pp], a, d);
+            const float v = fmaf(S.rb[bi][kk][pp], a, d);
             const _Float16 hv = (_Float16)v;
             hi[kk][pp] = hv;
             lo[kk][pp] = (_Float16)(v - (float)hv);
@@ -212,21 +218,14 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(const GemmParams p, const 
         const int idx = tid + i * 256;
         const int row = idx / HKQ, q = idx % HKQ;
         f16x4 vh, vl;
-        split4(rr[i] * sx, vh, vl);
+        split4(S.rr[i] * sx, vh, vl);
         *reinterpret_cast<f16x4*>(Fs_hi + row * HLD + q * 4) = vh;
         *reinterpret_cast<f16x4*>(Fs_lo + row * HLD + q * 4) = vl;
       }
     }
   };
 
-  const int kt_begin = k_lo / HBK;
-  const int kt_end = (p.K + HBK - 1) / HBK;
-  if (kt_begin < kt_end) load_tile(kt_begin);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < kt_end) load_tile(kt + 1);   // global loads in flight under the MFMAs
-
+  auto compute_tile = [&]() {
 #pragma unroll
     for (int s = 0; s < HBK / 16; ++s) {
       f16x8 ah[WM], al[WM], bh[WN], bl[WN];
@@ -251,7 +250,25 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(const GemmParams p, const 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
+  };
+
+  const int kt_begin = k_lo / HBK;
+  const int kt_end = (p.K + HBK - 1) / HBK;
+  if (kt_begin < kt_end) load_tile(st0, kt_begin);
+  if (kt_begin + 1 < kt_end) load_tile(st1, kt_begin + 1);
+  for (int kt = kt_begin; kt < kt_end; kt += 2) {
+    store_tile(st0);                                  // waits for set 0 only: set 1 stays in flight
     __syncthreads();
+    if (kt + 2 < kt_end) load_tile(st0, kt + 2);
+    compute_tile();
+    __syncthreads();
+    if (kt + 1 < kt_end) {
+      store_tile(st1);
+      __syncthreads();
+      if (kt + 3 < kt_end) load_tile(st1, kt + 3);
+      compute_tile();
+      __syncthreads();
+    }
   }
 
   gemm_epilogue<WM, WN>(acc, p, z, m0, n0, M_valid, out_scale);
@@ -281,7 +298,7 @@ int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, in
                        float w_scale, int rows_mode, hipStream_t stream) {
   if (!packed || !p.C) return SDY_ERR_ARG;
   if (p.M_store <= 0 || p.N <= 0 || p.K <= 0 || p.nbatch <= 0) return SDY_ERR_ARG;
-  if (Kpad % HBK || Kpad < p.K || rows_pad % 128) return SDY_ERR_ARG;
+  if (Kpad % 64 || Kpad < p.K || rows_pad % 128) return SDY_ERR_ARG;
   if (p.drop_thr != 0u && !p.keep_mask && (p.M_store & 3)) return SDY_ERR_ALIGN;
   H3Packed pk;
   pk.hi = reinterpret_cast<const _Float16*>(packed);
