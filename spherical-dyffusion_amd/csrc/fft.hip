@@ -253,13 +253,21 @@ __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const 
   }
   __syncthreads();
 
-  const int r = threadIdx.x % CB, mg = threadIdx.x / CB;
-  const int c = c0 + r;
+  // 16-byte stores: a thread owns 4 consecutive channels (C % 4 == 0) of one m; 4 lanes cover the workgroup's 64-byte
+  // run, 16 m's per wave instruction
+  const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
+  const int c = c0 + 4 * c4;
   if (c < C) {
-    for (int m = mg; m < mtr; m += NT / CB) {
+    for (int m = mg; m < mtr; m += NT / 4) {
       const long o = (((long)m * K + k) * B + b) * (2L * C) + c;
-      Xf[o] = zr[r * S + m];
-      Xf[o + C] = zi[r * S + m];
+      f32x4 vr, vi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vr[j] = zr[(4 * c4 + j) * S + m];
+        vi[j] = zi[(4 * c4 + j) * S + m];
+      }
+      *reinterpret_cast<f32x4*>(Xf + o) = vr;
+      *reinterpret_cast<f32x4*>(Xf + o + C) = vi;
     }
   }
 }
@@ -276,17 +284,20 @@ __global__ __launch_bounds__(NT) void irfft_kernel(const SdyFftDesc f, const flo
   load_tables(f, L);
 
   {
-    const int r = threadIdx.x % CB, mg = threadIdx.x / CB;
-    const int c = c0 + r;
-    for (int m = mg; m <= n; m += NT / CB) {
-      float vr = 0.f, vi = 0.f;
+    const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
+    const int c = c0 + 4 * c4;
+    for (int m = mg; m <= n; m += NT / 4) {
+      f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
       if (c < C && m < mtr) {
         const long o = (((long)m * K + k) * B + b) * (2L * C) + c;
-        vr = Yf[o];
-        vi = Yf[o + C];
+        vr = *reinterpret_cast<const f32x4*>(Yf + o);
+        vi = *reinterpret_cast<const f32x4*>(Yf + o + C);
       }
-      L.a_re[r * S + m] = vr;
-      L.a_im[r * S + m] = vi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        L.a_re[(4 * c4 + j) * S + m] = vr[j];
+        L.a_im[(4 * c4 + j) * S + m] = vi[j];
+      }
     }
   }
   __syncthreads();

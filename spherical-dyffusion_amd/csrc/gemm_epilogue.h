@@ -3,10 +3,12 @@
 #pragma once
 #include "common.h"
 
-// wm0 / wn0: global row / column of this WAVE's (32*WM) x (32*WN) output tile
-template <int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue_at(f32x16 (&acc)[WM][WN], const GemmParams& p, int z, int wm0, int wn0,
-                                                 int M_store, float acc_scale) {
+// wm0 / wn0: global row / column of this WAVE's (32*WM) x (32*WN) output tile.
+// FULL = the whole wave tile is inside the matrix (wave-uniform): no per-element predicates, and every address is one
+// 64-bit base per 32x32 tile plus a 32-bit offset (the predicated form spent ~2300 VALU instructions per wave).
+template <int WM, int WN, bool FULL>
+__device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[WM][WN], const GemmParams& p, int z, int wm0, int wn0,
+                                                   int M_store, float acc_scale) {
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5, l31 = lane & 31;
   float* __restrict__ Cg = p.C + (long)z * p.sC;
@@ -26,25 +28,29 @@ __device__ __forceinline__ void gemm_epilogue_at(f32x16 (&acc)[WM][WN], const Ge
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int gm = row0 + (r & 3) + 8 * (r >> 2);
-      bias_r[r] = (p.bias && gm < M_store) ? p.bias[gm] : 0.0f;
+      bias_r[r] = (p.bias && (FULL || gm < M_store)) ? p.bias[gm] : 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int gn = wn0 + j * 32 + l31;
-      const bool col_ok = gn < p.N;
+      const bool col_ok = FULL || gn < p.N;
       float add_r[16], keep_r[16];
+      // one 64-bit base per tile, 32-bit element offsets (row strides of the matrices involved are < 2^26 floats)
+      const float* add_t = addg ? addg + (long)row0 * p.ldadd + gn : nullptr;
+      const float* mask_t = maskg ? maskg + (long)row0 * p.N + gn : nullptr;
+      float* c_t = Cg + (long)row0 * p.ldc + gn;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int gm = row0 + (r & 3) + 8 * (r >> 2);
-        const bool ok = col_ok && gm < M_store;
-        add_r[r] = (p.add_mode != 0 && ok) ? addg[(long)gm * p.ldadd + gn] : 0.0f;
-        keep_r[r] = (maskg && ok) ? maskg[(long)gm * p.N + gn] : 1.0f;
+        const int dr = (r & 3) + 8 * (r >> 2);
+        const bool ok = FULL || (col_ok && row0 + dr < M_store);
+        add_r[r] = (p.add_mode != 0 && ok) ? add_t[dr * p.ldadd] : 0.0f;
+        keep_r[r] = (maskg && ok) ? mask_t[dr * p.N] : 1.0f;
       }
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int row_base = row0 + 8 * rg;
         uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (do_drop && !maskg && col_ok && row_base < M_store) {
+        if (do_drop && !maskg && (FULL || (col_ok && row_base < M_store))) {
           const philox4 w = philox4x32_10((uint32_t)gn, c1_base + (uint32_t)(row_base >> 2), p.stream_id, p.call,
                                           p.seed_lo, p.seed_hi);
           words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
@@ -62,11 +68,21 @@ __device__ __forceinline__ void gemm_epilogue_at(f32x16 (&acc)[WM][WN], const Ge
           }
           v *= bscale;
           if (p.add_mode == 2) v += add_r[r];
-          if (col_ok && gm < M_store) Cg[(long)gm * p.ldc + gn] = v;
+          if (FULL || (col_ok && gm < M_store)) c_t[(r4 + 8 * rg) * p.ldc] = v;
         }
       }
     }
   }
+}
+
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_at(f32x16 (&acc)[WM][WN], const GemmParams& p, int z, int wm0, int wn0,
+                                                 int M_store, float acc_scale) {
+  const bool full = (wm0 + 32 * WM <= M_store) && (wn0 + 32 * WN <= p.N);   // wave-uniform
+  if (full)
+    gemm_epilogue_impl<WM, WN, true>(acc, p, z, wm0, wn0, M_store, acc_scale);
+  else
+    gemm_epilogue_impl<WM, WN, false>(acc, p, z, wm0, wn0, M_store, acc_scale);
 }
 
 // workgroup of 4 waves arranged 2 x 2 (gemm.hip, gemm_h3.hip 128 x 128 kernel)
