@@ -148,7 +148,7 @@ typedef struct sdy_conv_args {
 int sdy_conv1x1(const sdy_conv_args* args, void* stream);
 
 /* Split-precision weight packing for sdy_conv1x1 (w_h3): host (Cout, Cin) row-major fp32 -> dev fp16 hi|lo planes,
- * [Mpad][Kpad] each (Mpad = Cout rounded up to 128, Kpad = Cin rounded up to 64), multiplied by a power of two
+ * [Mpad][Kpad] each (Mpad = 128 for Cout <= 128, else Cout rounded up to 256; Kpad = Cin rounded up to 64), multiplied by a power of two
  * (*scale) chosen so that max|w|*scale is in [2^12, 2^13). */
 size_t sdy_h3_pack_bytes(int Cout, int Cin);
 int sdy_h3_pack_weight(const float* w_host, int Cout, int Cin, void* packed_dev, float* scale);

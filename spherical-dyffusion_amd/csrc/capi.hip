@@ -148,14 +148,14 @@ extern "C" int sdy_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, in
   if (gemm_mode == 1) {
     // the fp32 tables (exactly what the reference's `.float()` buffers hold) split into fp16 hi + lo
     std::vector<_Float16> buf;
-    p->h3_rows_fwd = round_up(lmax, 128); p->h3_k_fwd = round_up(nlat, 64);
+    p->h3_rows_fwd = lmax > 128 ? round_up(lmax, 256) : 128; p->h3_k_fwd = round_up(nlat, 64);
     p->s_wq = h3_pack_host(buf, mtr, lmax, nlat, p->h3_rows_fwd, p->h3_k_fwd, [&](int m, int l, int k) {
       return wqT[((size_t)m * nlat + k) * p->Lpad4 + l];
     });
     e = hipMalloc(&p->d_wq_h3, buf.size() * sizeof(_Float16));
     if (e == hipSuccess) e = hipMemcpy(p->d_wq_h3, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     if (e != hipSuccess) { sdy_sht_plan_destroy(p); return (int)e; }
-    p->h3_rows_inv = round_up(nlat, 128); p->h3_k_inv = round_up(lmax, 64);
+    p->h3_rows_inv = nlat > 128 ? round_up(nlat, 256) : 128; p->h3_k_inv = round_up(lmax, 64);
     p->s_pct = h3_pack_host(buf, mtr, nlat, lmax, p->h3_rows_inv, p->h3_k_inv, [&](int m, int k, int l) {
       return pf[((size_t)m * lmax + l) * p->Kpad4 + k];
     });
@@ -338,7 +338,7 @@ extern "C" int sdy_instnorm_coeffs(const float* x, int B, int C, int HW, const f
   return sdy_instnorm_coeffs_launch(x, B, C, HW, gamma, beta, scale_shift, ss_stride, eps, a, d, (hipStream_t)stream);
 }
 
-static inline int h3_mpad(int Cout) { return round_up(Cout, 128); }
+static inline int h3_mpad(int Cout) { return Cout > 128 ? round_up(Cout, 256) : 128; }
 static inline int h3_kpad(int Cin) { return round_up(Cin, 64); }
 
 extern "C" size_t sdy_h3_pack_bytes(int Cout, int Cin) {

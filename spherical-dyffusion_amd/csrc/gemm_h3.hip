@@ -20,6 +20,8 @@
 // retire only the set that is about to be converted), because at f16 MFMA rates one tile of compute (~0.3 us) is far
 // shorter than a loaded memory round trip (~2 us): with one tile in flight the waves sat parked ~40 % of their life.
 // The accumulator layout equals gemm.hip's, so the fused epilogue (bias / add / GELU / Philox dropout / residual) is shared.
+#include <cstdlib>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -289,6 +291,168 @@ int launch_h3(const GemmParams& p, const H3Packed& pk, float sx, float out_scale
   return sdy_launch_status();
 }
 
+
+// ---- wide variant (MODE_COLS only): 512 threads, 256 x 128 x 64 tile, 8 waves as 4 (M) x 2 (N) ------------------------
+// One workgroup covers ALL rows of a <=256-row packed operand (256-wide conv layers, the 180-row Legendre tables), so the
+// activation tile is fetched, converted and split ONCE instead of once per 128-row M-tile.
+constexpr int WBK = 64, WLD = 72, WCH = WBK / 8, WKQ = WBK / 4;
+
+template <int TAG>
+__global__ __launch_bounds__(512) void gemm_h3_wide_kernel(const GemmParams p, const H3Packed pk, float sx,
+                                                            float out_scale) {
+  constexpr int BM = 256, BN = 128, WM = 2, WN = 2;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+  _Float16* As_hi = smem_h;
+  _Float16* As_lo = As_hi + BM * WLD;
+  _Float16* Bs_hi = As_lo + BM * WLD;
+  _Float16* Bs_lo = Bs_hi + BN * WLD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;   // 4 x 2
+  const int h = lane >> 5, l31 = lane & 31;
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  int k_lo = 0;
+  if (p.tri_mode == SDY_TRI_LEG_FWD) {
+    if (m0 + BM <= z) return;
+  } else if (p.tri_mode == SDY_TRI_LEG_INV) {
+    k_lo = z;
+  }
+  // rows of this wave that lie entirely below the diagonal of a Legendre analysis produce zeros that nobody reads
+  const bool wave_dead = (p.tri_mode == SDY_TRI_LEG_FWD) && (m0 + wr * 64 + 64 <= z);
+
+  const _Float16* __restrict__ Ph = pk.hi + (long)z * pk.bstride;
+  const _Float16* __restrict__ Pl = pk.lo + (long)z * pk.bstride;
+  const float* __restrict__ Fg = p.B + (long)z * p.sB;
+  const float* __restrict__ pa = p.pa ? p.pa + (long)z * p.p_bstride : nullptr;
+  const float* __restrict__ pd = p.pd ? p.pd + (long)z * p.p_bstride : nullptr;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  f32x4 rp_hi[4], rp_lo[4];
+  f32x4 rb[4];
+  float ca[4], cd[4];
+  const int kq = tid % WKQ, pq = tid / WKQ;   // 16 k-quads x 32 pixel quads = 64 k x 128 pixels
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * WBK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int chunk = tid + i * 512;
+      const int row = chunk / WCH, c = chunk % WCH;
+      const long off = (long)(m0 + row) * pk.Kpad + k0 + c * 8;
+      rp_hi[i] = *reinterpret_cast<const f32x4*>(Ph + off);
+      rp_lo[i] = *reinterpret_cast<const f32x4*>(Pl + off);
+    }
+    const int gn = n0 + pq * 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int gk = k0 + kq * 4 + kk;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      float a = 0.f, d = 0.f;
+      if (gk >= k_lo && gk < p.K && gn < p.N) {
+        v = *reinterpret_cast<const f32x4*>(Fg + (long)gk * p.ldb + gn);
+        a = 1.0f;
+        if (pa) {
+          a = pa[gk];
+          d = pd[gk];
+        }
+      }
+      rb[kk] = v;
+      ca[kk] = a;
+      cd[kk] = d;
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int chunk = tid + i * 512;
+      const int row = chunk / WCH, c = chunk % WCH;
+      *reinterpret_cast<f32x4*>(As_hi + row * WLD + c * 8) = rp_hi[i];
+      *reinterpret_cast<f32x4*>(As_lo + row * WLD + c * 8) = rp_lo[i];
+    }
+    _Float16 hi[4][4], lo[4][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float a = ca[kk] * sx, d = cd[kk] * sx;
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const float v = fmaf(rb[kk][pp], a, d);
+        const _Float16 hv = (_Float16)v;
+        hi[kk][pp] = hv;
+        lo[kk][pp] = (_Float16)(v - (float)hv);
+      }
+    }
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int prow = pq * 4 + pp;
+      f16x4 vh = {hi[0][pp], hi[1][pp], hi[2][pp], hi[3][pp]};
+      f16x4 vl = {lo[0][pp], lo[1][pp], lo[2][pp], lo[3][pp]};
+      *reinterpret_cast<f16x4*>(Bs_hi + prow * WLD + kq * 4) = vh;
+      *reinterpret_cast<f16x4*>(Bs_lo + prow * WLD + kq * 4) = vl;
+    }
+  };
+
+  const int kt_begin = k_lo / WBK;
+  const int kt_end = (p.K + WBK - 1) / WBK;
+  if (kt_begin < kt_end) load_tile(kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < kt_end) load_tile(kt + 1);
+    if (!wave_dead) {
+#pragma unroll
+      for (int s = 0; s < WBK / 16; ++s) {
+        f16x8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          const int off = (wr * 64 + i * 32 + l31) * WLD + s * 16 + h * 8;
+          ah[i] = *reinterpret_cast<const f16x8*>(As_hi + off);
+          al[i] = *reinterpret_cast<const f16x8*>(As_lo + off);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int off = (wc * 64 + j * 32 + l31) * WLD + s * 16 + h * 8;
+          bh[j] = *reinterpret_cast<const f16x8*>(Bs_hi + off);
+          bl[j] = *reinterpret_cast<const f16x8*>(Bs_lo + off);
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (!wave_dead) gemm_epilogue_at<WM, WN>(acc, p, z, m0 + wr * 64, n0 + wc * 64, p.M_store, out_scale);
+}
+
+template <int TAG>
+int launch_h3_wide(const GemmParams& p, const H3Packed& pk, float sx, float out_scale, hipStream_t stream) {
+  constexpr size_t smem = (size_t)(2 * 256 + 2 * 128) * WLD * sizeof(_Float16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_wide_kernel<TAG>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  dim3 grid((p.M_store + 255) / 256, (p.N + 127) / 128, p.nbatch);
+  hipLaunchKernelGGL((gemm_h3_wide_kernel<TAG>), grid, dim3(512), smem, stream, p, pk, sx, out_scale);
+  return sdy_launch_status();
+}
+
 }  // namespace
 
 // `p` carries the fp32 operand (B for rows_mode 0, A for rows_mode 1), C and the epilogue exactly as for
@@ -317,6 +481,16 @@ int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, in
   if (!p.B) return SDY_ERR_ARG;
   if ((p.N & 3) || (p.ldb & 3) || (p.sB & 3)) return SDY_ERR_ALIGN;
   if (rows_pad < ((p.M_store + 127) / 128) * 128) return SDY_ERR_ARG;
+  // wide tile for 256-row conv layers (measured: 256 -> 256 and 512 -> 256 convs +8-10 %; the short-K, triangular
+  // Legendre GEMMs and the 512-row fc1 are faster on the 128 x 128 kernel)
+  if (p.tri_mode == SDY_TRI_NONE && p.M_store == 256 && rows_pad % 256 == 0 && !getenv("SDY_H3_NO_WIDE")) {
+    switch (p.tag) {
+      case 1: return launch_h3_wide<1>(p, pk, sx, out_scale, stream);
+      case 2: return launch_h3_wide<2>(p, pk, sx, out_scale, stream);
+      case 3: return launch_h3_wide<3>(p, pk, sx, out_scale, stream);
+      default: return launch_h3_wide<0>(p, pk, sx, out_scale, stream);
+    }
+  }
   switch (p.tag) {
     case 1: return launch_h3<2, 2, MODE_COLS, 1>(p, pk, sx, out_scale, stream);
     case 2: return launch_h3<2, 2, MODE_COLS, 2>(p, pk, sx, out_scale, stream);
