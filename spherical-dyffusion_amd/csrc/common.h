@@ -104,5 +104,9 @@ int sdy_gemm_launch(const GemmParams& p, hipStream_t stream);
 int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, int Kpad, long bstride, long plane_halfs,
                        float w_scale, int rows_mode, hipStream_t stream);
 
+// persistent warp-specialised variant for conv mode (gemm_h3_ws.hip)
+int sdy_gemm_h3_ws_launch(const GemmParams& p, const void* packed, int rows_pad, int Kpad, long plane_halfs, float w_scale,
+                          hipStream_t stream);
+
 // ---- host tables (tables.cpp) --------------------------------------------------------------------------
 int sdy_factor_radices(int n, int* radices, int* nstages);  // n = prod(radices), radices in {4,2,3,5}
