@@ -21,6 +21,7 @@
 // shorter than a loaded memory round trip (~2 us): with one tile in flight the waves sat parked ~40 % of their life.
 // The accumulator layout equals gemm.hip's, so the fused epilogue (bias / add / GELU / Philox dropout / residual) is shared.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -137,7 +138,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, con
   const int kq = tid % HKQ, pq = tid / HKQ;
   const int prow0 = (MODE == MODE_COLS) ? m0 : n0;   // first packed row of this tile
 
-  auto load_tile = [&](Stage& S, int kt) {
+  // FAST (interior tile, K a multiple of the k-tile): no predicates and therefore no control flow between the loads, so
+  // hipcc keeps exact vmcnt counts and the wait in store_tile retires only the stage being converted -- the younger
+  // stage stays in flight.  (With `if`-guarded loads it falls back to vmcnt(0) and the two-stage prefetch is moot.)
+  auto load_tile = [&](Stage& S, int kt, auto fast_tag, auto aff_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    constexpr bool AFF = decltype(aff_tag)::value;
     const int k0 = kt * HBK;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -156,7 +162,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, con
           const int gk = k0 + kq * 4 + kk;
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
           float a = 0.f, d = 0.f;
-          if (gk >= k_lo && gk < p.K && gn < p.N) {
+          if constexpr (FAST) {
+            v = *reinterpret_cast<const f32x4*>(Fg + (long)gk * p.ldb + gn);
+            a = 1.0f;
+            if constexpr (AFF) {
+              a = pa[gk];
+              d = pd[gk];
+            }
+          } else if (gk >= k_lo && gk < p.K && gn < p.N) {
             v = *reinterpret_cast<const f32x4*>(Fg + (long)gk * p.ldb + gn);
             a = 1.0f;
             if (pa) {
@@ -176,7 +189,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, con
         const int row = idx / HKQ, q = idx % HKQ;
         const int gm = m0 + row, gk = k0 + q * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gm < M_valid && gk < p.K) v = *reinterpret_cast<const f32x4*>(Fg + (long)gm * p.lda + gk);
+        if constexpr (FAST)
+          v = *reinterpret_cast<const f32x4*>(Fg + (long)gm * p.lda + gk);
+        else if (gm < M_valid && gk < p.K)
+          v = *reinterpret_cast<const f32x4*>(Fg + (long)gm * p.lda + gk);
         S.rr[i] = v;
       }
     }
@@ -256,21 +272,32 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, con
 
   const int kt_begin = k_lo / HBK;
   const int kt_end = (p.K + HBK - 1) / HBK;
-  if (kt_begin < kt_end) load_tile(st0, kt_begin);
-  if (kt_begin + 1 < kt_end) load_tile(st1, kt_begin + 1);
-  for (int kt = kt_begin; kt < kt_end; kt += 2) {
-    store_tile(st0);                                  // waits for set 0 only: set 1 stays in flight
-    __syncthreads();
-    if (kt + 2 < kt_end) load_tile(st0, kt + 2);
-    compute_tile();
-    __syncthreads();
-    if (kt + 1 < kt_end) {
-      store_tile(st1);
+  auto run = [&](auto fast_tag, auto aff_tag) {
+    if (kt_begin < kt_end) load_tile(st0, kt_begin, fast_tag, aff_tag);
+    if (kt_begin + 1 < kt_end) load_tile(st1, kt_begin + 1, fast_tag, aff_tag);
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+      store_tile(st0);                                  // waits for set 0 only: set 1 stays in flight
       __syncthreads();
-      if (kt + 3 < kt_end) load_tile(st1, kt + 3);
+      if (kt + 2 < kt_end) load_tile(st0, kt + 2, fast_tag, aff_tag);
       compute_tile();
       __syncthreads();
+      if (kt + 1 < kt_end) {
+        store_tile(st1);
+        __syncthreads();
+        if (kt + 3 < kt_end) load_tile(st1, kt + 3, fast_tag, aff_tag);
+        compute_tile();
+        __syncthreads();
+      }
     }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  const bool interior = (p.K % HBK == 0) && (k_lo == 0) &&
+                        (MODE == MODE_COLS ? (n0 + BN <= p.N) : (m0 + BM <= M_valid));   // workgroup-uniform
+  if (interior) {
+    if (pa) run(T_{}, T_{}); else run(T_{}, F_{});
+  } else {
+    run(F_{}, F_{});
   }
 
   gemm_epilogue<WM, WN>(acc, p, z, m0, n0, M_valid, out_scale);
