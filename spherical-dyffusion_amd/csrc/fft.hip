@@ -199,7 +199,10 @@ __device__ __forceinline__ void load_tables(const SdyFftDesc& f, LdsView& L) {
 }
 
 // x (B,C,K,N) -> Xf[m][k][b][ri][c]      (NH = nlon/2 known at compile time, or 0 for the generic path)
-template <int NH>
+// A workgroup walks KPW consecutive latitude rings of its (b, channel block): the global loads of ring k+1 are issued
+// into registers before the FFT passes of ring k, so the load latency hides under the LDS work instead of opening every
+// ring (the kernel is otherwise a strict load -> transform -> store sequence with 3 workgroups per CU).
+template <int NH, int KPW>
 __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const float* __restrict__ x,
                                                        const float* __restrict__ pa, const float* __restrict__ pd,
                                                        float* __restrict__ xn_out, float* __restrict__ Xf, int B,
@@ -207,144 +210,211 @@ __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const 
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int n = NH ? NH : f.n, N = 2 * n, S = NH ? ((NH + 1) | 1) : f.S;
   LdsView L = carve(sm, S, n);
-  const int c0 = blockIdx.x * CB, k = blockIdx.y, b = blockIdx.z;
+  const int c0 = blockIdx.x * CB, b = blockIdx.z;
+  const int k_begin = blockIdx.y * KPW, k_end = min(K, k_begin + KPW);
   load_tables(f, L);
 
   const int q4 = N / 4;
-  for (int idx = threadIdx.x; idx < CB * q4; idx += NT) {
+  constexpr int ITER = NH ? (CB * (NH / 2) + NT - 1) / NT : 1;
+  f32x4 regs[ITER];
+  auto gload = [&](int k) {          // NH != 0 only
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = threadIdx.x + it * NT;
+      const int r = idx / q4, q = idx - r * q4;
+      const int c = c0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < CB * q4 && c < C) v = *reinterpret_cast<const f32x4*>(x + (((long)b * C + c) * K + k) * N + 4 * q);
+      regs[it] = v;
+    }
+  };
+  auto stage_row = [&](int idx, f32x4 v, int k) {   // affine, optional residual store, LDS image
     const int r = idx / q4, q = idx - r * q4;
     const int c = c0 + r;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-      const long off = (((long)b * C + c) * K + k) * N + 4 * q;
-      v = *reinterpret_cast<const f32x4*>(x + off);
       if (pa) v = v * pa[b * C + c] + pd[b * C + c];
-      if (xn_out) *reinterpret_cast<f32x4*>(xn_out + off) = v;
+      if (xn_out) *reinterpret_cast<f32x4*>(xn_out + (((long)b * C + c) * K + k) * N + 4 * q) = v;
     }
     L.a_re[r * S + 2 * q] = v.x;
     L.a_im[r * S + 2 * q] = v.y;
     L.a_re[r * S + 2 * q + 1] = v.z;
     L.a_im[r * S + 2 * q + 1] = v.w;
-  }
-  __syncthreads();
+  };
 
-  float *zr, *zi;
-  if constexpr (NH != 0)
-    fft_rows_ct<NH>(L, S, -1.0f, &zr, &zi);
-  else
-    fft_rows(f, L, S, -1.0f, &zr, &zi);
-
-  // split step: X[m] = E + w^m O, X[n-m] = conj(E - w^m O); scaled by 2*pi/N
-  const float scale = 6.28318530717958647692f / (float)N;
-  const int np = n / 2 + 1;
-  for (int id = threadIdx.x; id < CB * np; id += NT) {
-    const int r = id / np, m = id - r * np;
-    float* re = zr + r * S;
-    float* im = zi + r * S;
-    const int m2 = (m == 0) ? 0 : n - m;
-    const float a = re[m], bq = im[m], c = re[m2], d = im[m2];
-    const cpx E = cpx{0.5f * (a + c), 0.5f * (bq - d)};
-    const cpx O = cpx{0.5f * (bq + d), -0.5f * (a - c)};
-    const cpx T = cmul(cpx{L.pw_re[m], L.pw_im[m]}, O);
-    re[m] = scale * (E.r + T.r);
-    im[m] = scale * (E.i + T.i);
-    re[n - m] = scale * (E.r - T.r);
-    im[n - m] = -scale * (E.i - T.i);
-  }
-  __syncthreads();
-
-  // 16-byte stores: a thread owns 4 consecutive channels (C % 4 == 0) of one m; 4 lanes cover the workgroup's 64-byte
-  // run, 16 m's per wave instruction
-  const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
-  const int c = c0 + 4 * c4;
-  if (c < C) {
-    for (int m = mg; m < mtr; m += NT / 4) {
-      const long o = (((long)m * K + k) * B + b) * (2L * C) + c;
-      f32x4 vr, vi;
+  if constexpr (NH != 0) gload(k_begin);
+  for (int k = k_begin; k < k_end; ++k) {
+    if constexpr (NH != 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        vr[j] = zr[(4 * c4 + j) * S + m];
-        vi[j] = zi[(4 * c4 + j) * S + m];
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = threadIdx.x + it * NT;
+        if (idx < CB * q4) stage_row(idx, regs[it], k);
       }
-      *reinterpret_cast<f32x4*>(Xf + o) = vr;
-      *reinterpret_cast<f32x4*>(Xf + o + C) = vi;
+    } else {
+      for (int idx = threadIdx.x; idx < CB * q4; idx += NT) {
+        const int r = idx / q4, q = idx - r * q4;
+        const int c = c0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < C) v = *reinterpret_cast<const f32x4*>(x + (((long)b * C + c) * K + k) * N + 4 * q);
+        stage_row(idx, v, k);
+      }
     }
+    __syncthreads();
+    if constexpr (NH != 0) {
+      if (k + 1 < k_end) gload(k + 1);   // in flight under the FFT passes below
+    }
+
+    float *zr, *zi;
+    if constexpr (NH != 0)
+      fft_rows_ct<NH>(L, S, -1.0f, &zr, &zi);
+    else
+      fft_rows(f, L, S, -1.0f, &zr, &zi);
+
+    // split step: X[m] = E + w^m O, X[n-m] = conj(E - w^m O); scaled by 2*pi/N
+    const float scale = 6.28318530717958647692f / (float)N;
+    const int np = n / 2 + 1;
+    for (int id = threadIdx.x; id < CB * np; id += NT) {
+      const int r = id / np, m = id - r * np;
+      float* re = zr + r * S;
+      float* im = zi + r * S;
+      const int m2 = (m == 0) ? 0 : n - m;
+      const float a = re[m], bq = im[m], c = re[m2], d = im[m2];
+      const cpx E = cpx{0.5f * (a + c), 0.5f * (bq - d)};
+      const cpx O = cpx{0.5f * (bq + d), -0.5f * (a - c)};
+      const cpx T = cmul(cpx{L.pw_re[m], L.pw_im[m]}, O);
+      re[m] = scale * (E.r + T.r);
+      im[m] = scale * (E.i + T.i);
+      re[n - m] = scale * (E.r - T.r);
+      im[n - m] = -scale * (E.i - T.i);
+    }
+    __syncthreads();
+
+    // 16-byte stores: a thread owns 4 consecutive channels (C % 4 == 0) of one m; 4 lanes cover the workgroup's 64-byte
+    // run, 16 m's per wave instruction
+    const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
+    const int c = c0 + 4 * c4;
+    if (c < C) {
+      for (int m = mg; m < mtr; m += NT / 4) {
+        const long o = (((long)m * K + k) * B + b) * (2L * C) + c;
+        f32x4 vr, vi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vr[j] = zr[(4 * c4 + j) * S + m];
+          vi[j] = zi[(4 * c4 + j) * S + m];
+        }
+        *reinterpret_cast<f32x4*>(Xf + o) = vr;
+        *reinterpret_cast<f32x4*>(Xf + o + C) = vi;
+      }
+    }
+    __syncthreads();   // the LDS image is rewritten by the next ring
   }
 }
 
-// Yf[m][k][b][ri][c] -> y (B,C,K,N) (+ bias[c])
-template <int NH>
+// Yf[m][k][b][ri][c] -> y (B,C,K,N) (+ bias[c]); same ring pipeline as the forward kernel
+template <int NH, int KPW>
 __global__ __launch_bounds__(NT) void irfft_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
                                                     const float* __restrict__ bias, float* __restrict__ y, int B, int C,
                                                     int K, int mtr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int n = NH ? NH : f.n, N = 2 * n, S = NH ? ((NH + 1) | 1) : f.S;
   LdsView L = carve(sm, S, n);
-  const int c0 = blockIdx.x * CB, k = blockIdx.y, b = blockIdx.z;
+  const int c0 = blockIdx.x * CB, b = blockIdx.z;
+  const int k_begin = blockIdx.y * KPW, k_end = min(K, k_begin + KPW);
   load_tables(f, L);
 
-  {
-    const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
-    const int c = c0 + 4 * c4;
-    for (int m = mg; m <= n; m += NT / 4) {
+  const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
+  const int cq = c0 + 4 * c4;
+  constexpr int MIT = NH ? (NH + 1 + NT / 4 - 1) / (NT / 4) : 1;
+  f32x4 rr[MIT], ri[MIT];
+  auto gload = [&](int k) {          // NH != 0 only
+#pragma unroll
+    for (int it = 0; it < MIT; ++it) {
+      const int m = mg + it * (NT / 4);
       f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
-      if (c < C && m < mtr) {
-        const long o = (((long)m * K + k) * B + b) * (2L * C) + c;
+      if (cq < C && m < mtr) {
+        const long o = (((long)m * K + k) * B + b) * (2L * C) + cq;
         vr = *reinterpret_cast<const f32x4*>(Yf + o);
         vi = *reinterpret_cast<const f32x4*>(Yf + o + C);
       }
+      rr[it] = vr;
+      ri[it] = vi;
+    }
+  };
+  auto stage_m = [&](int m, const f32x4& vr, const f32x4& vi) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        L.a_re[(4 * c4 + j) * S + m] = vr[j];
-        L.a_im[(4 * c4 + j) * S + m] = vi[j];
+    for (int j = 0; j < 4; ++j) {
+      L.a_re[(4 * c4 + j) * S + m] = vr[j];
+      L.a_im[(4 * c4 + j) * S + m] = vi[j];
+    }
+  };
+
+  if constexpr (NH != 0) gload(k_begin);
+  for (int k = k_begin; k < k_end; ++k) {
+    if constexpr (NH != 0) {
+#pragma unroll
+      for (int it = 0; it < MIT; ++it) {
+        const int m = mg + it * (NT / 4);
+        if (m <= n) stage_m(m, rr[it], ri[it]);
+      }
+    } else {
+      for (int m = mg; m <= n; m += NT / 4) {
+        f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
+        if (cq < C && m < mtr) {
+          const long o = (((long)m * K + k) * B + b) * (2L * C) + cq;
+          vr = *reinterpret_cast<const f32x4*>(Yf + o);
+          vi = *reinterpret_cast<const f32x4*>(Yf + o + C);
+        }
+        stage_m(m, vr, vi);
       }
     }
-  }
-  __syncthreads();
-
-  // merge step: Z[m] = S + i D, Z[n-m] = conj(S - i D),  S = X[m] + conj(X[n-m]),  D = e^{+2 pi i m/N} (X[m] - conj(X[n-m]))
-  const int np = n / 2 + 1;
-  for (int id = threadIdx.x; id < CB * np; id += NT) {
-    const int r = id / np, m = id - r * np;
-    float* re = L.a_re + r * S;
-    float* im = L.a_im + r * S;
-    cpx A = cpx{re[m], im[m]};
-    cpx Bc = cpx{re[n - m], -im[n - m]};
-    if (m == 0) {  // irfft ignores the imaginary parts of the DC and Nyquist bins
-      A.i = 0.f;
-      Bc.i = 0.f;
+    __syncthreads();
+    if constexpr (NH != 0) {
+      if (k + 1 < k_end) gload(k + 1);
     }
-    const cpx Sm = cadd(A, Bc);
-    const cpx D = cmul(cpx{L.pw_re[m], -L.pw_im[m]}, csub(A, Bc));
-    // Z[m] = S + iD
-    re[m] = Sm.r - D.i;
-    im[m] = Sm.i + D.r;
-    if (m > 0) {  // Z[n-m] = conj(S - iD) = conj( (S.r + D.i) + i (S.i - D.r) )
-      re[n - m] = Sm.r + D.i;
-      im[n - m] = -(Sm.i - D.r);
-    }
-  }
-  __syncthreads();
 
-  float *zr, *zi;
-  if constexpr (NH != 0)
-    fft_rows_ct<NH>(L, S, +1.0f, &zr, &zi);
-  else
-    fft_rows(f, L, S, +1.0f, &zr, &zi);
-
-  const int q4 = N / 4;
-  for (int idx = threadIdx.x; idx < CB * q4; idx += NT) {
-    const int r = idx / q4, q = idx - r * q4;
-    const int c = c0 + r;
-    if (c < C) {
-      const float bv = bias ? bias[c] : 0.0f;
-      f32x4 v;
-      v.x = zr[r * S + 2 * q] + bv;
-      v.y = zi[r * S + 2 * q] + bv;
-      v.z = zr[r * S + 2 * q + 1] + bv;
-      v.w = zi[r * S + 2 * q + 1] + bv;
-      *reinterpret_cast<f32x4*>(y + (((long)b * C + c) * K + k) * N + 4 * q) = v;
+    // merge step: Z[m] = S + i D, Z[n-m] = conj(S - i D),  S = X[m] + conj(X[n-m]),  D = e^{+2 pi i m/N} (X[m] - conj(X[n-m]))
+    const int np = n / 2 + 1;
+    for (int id = threadIdx.x; id < CB * np; id += NT) {
+      const int r = id / np, m = id - r * np;
+      float* re = L.a_re + r * S;
+      float* im = L.a_im + r * S;
+      cpx A = cpx{re[m], im[m]};
+      cpx Bc = cpx{re[n - m], -im[n - m]};
+      if (m == 0) {  // irfft ignores the imaginary parts of the DC and Nyquist bins
+        A.i = 0.f;
+        Bc.i = 0.f;
+      }
+      const cpx Sm = cadd(A, Bc);
+      const cpx D = cmul(cpx{L.pw_re[m], -L.pw_im[m]}, csub(A, Bc));
+      re[m] = Sm.r - D.i;   // Z[m] = S + iD
+      im[m] = Sm.i + D.r;
+      if (m > 0) {          // Z[n-m] = conj(S - iD)
+        re[n - m] = Sm.r + D.i;
+        im[n - m] = -(Sm.i - D.r);
+      }
     }
+    __syncthreads();
+
+    float *zr, *zi;
+    if constexpr (NH != 0)
+      fft_rows_ct<NH>(L, S, +1.0f, &zr, &zi);
+    else
+      fft_rows(f, L, S, +1.0f, &zr, &zi);
+
+    const int q4 = N / 4;
+    for (int idx = threadIdx.x; idx < CB * q4; idx += NT) {
+      const int r = idx / q4, q = idx - r * q4;
+      const int c = c0 + r;
+      if (c < C) {
+        const float bv = bias ? bias[c] : 0.0f;
+        f32x4 v;
+        v.x = zr[r * S + 2 * q] + bv;
+        v.y = zi[r * S + 2 * q] + bv;
+        v.z = zr[r * S + 2 * q + 1] + bv;
+        v.w = zi[r * S + 2 * q + 1] + bv;
+        *reinterpret_cast<f32x4*>(y + (((long)b * C + c) * K + k) * N + 4 * q) = v;
+      }
+    }
+    __syncthreads();   // the LDS image is rewritten by the next ring
   }
 }
 
@@ -356,13 +426,16 @@ int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, cons
                        int B, int C, int K, int mtr, hipStream_t stream) {
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
-  dim3 grid((C + CB - 1) / CB, K, B);
-  if (f.n == 180)
-    hipLaunchKernelGGL(rfft_fwd_kernel<180>, grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
-  else if (f.n == 32)
-    hipLaunchKernelGGL(rfft_fwd_kernel<32>, grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
-  else
-    hipLaunchKernelGGL(rfft_fwd_kernel<0>, grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  constexpr int KPW = 4;   // latitude rings per workgroup on the pipelined (compile-time size) paths
+  dim3 grid((C + CB - 1) / CB, (K + KPW - 1) / KPW, B);
+  if (f.n == 180) {
+    hipLaunchKernelGGL((rfft_fwd_kernel<180, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  } else if (f.n == 32) {
+    hipLaunchKernelGGL((rfft_fwd_kernel<32, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  } else {
+    grid.y = K;
+    hipLaunchKernelGGL((rfft_fwd_kernel<0, 1>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  }
   return sdy_launch_status();
 }
 
@@ -370,12 +443,15 @@ int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, 
                        hipStream_t stream) {
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
-  dim3 grid((C + CB - 1) / CB, K, B);
-  if (f.n == 180)
-    hipLaunchKernelGGL(irfft_kernel<180>, grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
-  else if (f.n == 32)
-    hipLaunchKernelGGL(irfft_kernel<32>, grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
-  else
-    hipLaunchKernelGGL(irfft_kernel<0>, grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+  constexpr int KPW = 4;
+  dim3 grid((C + CB - 1) / CB, (K + KPW - 1) / KPW, B);
+  if (f.n == 180) {
+    hipLaunchKernelGGL((irfft_kernel<180, KPW>), grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+  } else if (f.n == 32) {
+    hipLaunchKernelGGL((irfft_kernel<32, KPW>), grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+  } else {
+    grid.y = K;
+    hipLaunchKernelGGL((irfft_kernel<0, 1>), grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+  }
   return sdy_launch_status();
 }
