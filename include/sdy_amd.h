@@ -215,6 +215,48 @@ int sdy_cold_update(const float* x_s, const float* x_ip_next, const float* x_ip_
 int sdy_concat_channels(const float* const* src, const int* chans, int nsrc, float* out, int B, int HW,
                         void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Stepper glue either side of the sampler ("next" row of the scope table): the device arithmetic of
+ * run_on_batch_multistep (src/ace_inference/core/stepper_multistep.py:298-466): StandardNormalizer
+ * (src/ace_inference/core/normalizer.py:96-110), Packer (src/utilities/packer.py:70-77), Prescriber
+ * (src/ace_inference/core/prescriber.py:68-92), relative LpLoss (src/ace_inference/training/utils/darcy_loss.py:214-228).
+ * Variables are separate dev tensors (B, T1, nlat*nlon) as in the reference's data dict. */
+#define SDY_MAX_VARS 96
+typedef struct sdy_var_table {
+  int nvars;
+  const float* data[SDY_MAX_VARS];  /* dev (B, T1, HW), denormalised */
+  float mean[SDY_MAX_VARS];         /* 0 / 1 for variables without statistics (passed through) */
+  float std[SDY_MAX_VARS];
+} sdy_var_table;
+/* normalise + pack: out[b][v][p] = (data_v[b][t][p] - mean_v) / std_v,  out dev (B, nvars, HW) */
+int sdy_norm_pack(const sdy_var_table* vars, int t, int T1, int B, int HW, float* out, void* stream);
+
+typedef struct sdy_step_finish_args {
+  int B, HW, T1, t;                   /* t = time index being written (1..n_forward_steps) */
+  const float* gen; int n_out;        /* dev (B, n_out, HW): the module's normalised prediction for step t */
+  const float* prev_in; float* next_in; int n_in;  /* dev (B, n_in, HW) packed model state (in_packer order) */
+  int n_entries;                      /* one entry per distinct variable in (in_packer names) U (out names) */
+  int out_idx[SDY_MAX_VARS];          /* index in the out packer or -1 (input-only: carried over, e.g. HGTsfc) */
+  int in_idx[SDY_MAX_VARS];           /* index in the in packer or -1 (diagnostic-only output) */
+  float* gen_norm_tl[SDY_MAX_VARS];   /* per entry with out_idx >= 0: dev (B, T1, HW) normalised timeline */
+  float* gen_tl[SDY_MAX_VARS];        /* ... and denormalised timeline (value*std + mean) */
+  float mean[SDY_MAX_VARS], std[SDY_MAX_VARS];
+  int presc_entry;                    /* entry overwritten by the prescriber, or -1 */
+  const float* presc_target;          /* dev (B, T1, HW) denormalised data of the prescribed variable */
+  const float* presc_mask;            /* dev (B, T1, HW) mask variable */
+  int mask_value, interpolate;
+} sdy_step_finish_args;
+/* prescriber + unpack into the timelines + denormalise + autoregressive feedback into next_in */
+int sdy_step_finish(const sdy_step_finish_args* args, void* stream);
+/* timeline slot 0: gen_norm_tl[e][b][0] = (data - mean)/std, gen_tl = that * std + mean, for the table's variables
+ * (tl_norm / tl_denorm: arrays of nvars dev pointers) */
+int sdy_init_timeline(const sdy_var_table* vars, int T1, int B, int HW, float* const* tl_norm, float* const* tl_denorm,
+                      void* stream);
+/* LpLoss.rel terms: terms[b][0] += sum (gen - target_norm)^2, terms[b][1] += sum target_norm^2 over the packed
+ * (n_out, HW) fields of sample b, target_norm from `targets` at time t.  terms: dev double [B*2], zeroed by the caller. */
+int sdy_lp_rel_terms(const float* gen, const sdy_var_table* targets, int t, int T1, int B, int HW, double* terms,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

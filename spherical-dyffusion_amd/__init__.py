@@ -13,6 +13,7 @@ from .dyffusion import DYffusion  # noqa: F401
 from .experiment import InterpolationExperiment, MultiHorizonForecastingDYffusion  # noqa: F401
 from .sfno import SphericalFourierNeuralOperatorNet  # noqa: F401
 from .sht import InverseRealSHT, RealSHT  # noqa: F401
+from .stepper import MultiStepStepper, Prescriber, SteppedData  # noqa: F401
 from . import ensemble, ops  # noqa: F401
 
 __version__ = "0.1.0"

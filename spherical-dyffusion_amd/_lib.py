@@ -40,6 +40,29 @@ class SdyConvArgs(C.Structure):
     ]
 
 
+SDY_MAX_VARS = 96
+
+
+class SdyVarTable(C.Structure):
+    _fields_ = [("nvars", C.c_int), ("data", C.c_void_p * SDY_MAX_VARS), ("mean", C.c_float * SDY_MAX_VARS),
+                ("std", C.c_float * SDY_MAX_VARS)]
+
+
+class SdyStepFinishArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("HW", C.c_int), ("T1", C.c_int), ("t", C.c_int),
+        ("gen", C.c_void_p), ("n_out", C.c_int),
+        ("prev_in", C.c_void_p), ("next_in", C.c_void_p), ("n_in", C.c_int),
+        ("n_entries", C.c_int),
+        ("out_idx", C.c_int * SDY_MAX_VARS), ("in_idx", C.c_int * SDY_MAX_VARS),
+        ("gen_norm_tl", C.c_void_p * SDY_MAX_VARS), ("gen_tl", C.c_void_p * SDY_MAX_VARS),
+        ("mean", C.c_float * SDY_MAX_VARS), ("std", C.c_float * SDY_MAX_VARS),
+        ("presc_entry", C.c_int),
+        ("presc_target", C.c_void_p), ("presc_mask", C.c_void_p),
+        ("mask_value", C.c_int), ("interpolate", C.c_int),
+    ]
+
+
 class SdySfnoConfig(C.Structure):
     _fields_ = [
         ("nlat", C.c_int), ("nlon", C.c_int),
@@ -103,6 +126,12 @@ SIGNATURES = {
     "sdy_sfno_workspace_floats": (C.c_size_t, [C.c_void_p, C.c_int]),
     "sdy_sfno_forward": (C.c_int, [C.c_void_p, C.POINTER(SdySfnoFwdArgs), C.c_void_p]),
     "sdy_sfno_time_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdy_norm_pack": (C.c_int, [C.POINTER(SdyVarTable), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sdy_step_finish": (C.c_int, [C.POINTER(SdyStepFinishArgs), C.c_void_p]),
+    "sdy_init_timeline": (C.c_int, [C.POINTER(SdyVarTable), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_void_p), C.c_void_p]),
+    "sdy_lp_rel_terms": (C.c_int, [C.c_void_p, C.POINTER(SdyVarTable), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p]),
     "sdy_cold_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdy_concat_channels": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p]),

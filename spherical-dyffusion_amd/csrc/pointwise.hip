@@ -235,7 +235,164 @@ __global__ __launch_bounds__(256) void torch_to_spec_kernel(const float* __restr
   }
 }
 
+// ---- stepper glue (src/ace_inference/core/stepper_multistep.py:298-466) -----------------------------------------
+__global__ __launch_bounds__(256) void norm_pack_kernel(const sdy_var_table v, int t, int T1, int HW4,
+                                                         float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW4) return;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const f32x4 x = reinterpret_cast<const f32x4*>(v.data[c] + ((long)b * T1 + t) * HW4 * 4)[i];
+  const float m = v.mean[c], s = v.std[c];
+  f32x4 y;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[e] = (x[e] - m) / s;   // same two operations as the reference, no reciprocal
+  reinterpret_cast<f32x4*>(out + ((long)b * v.nvars + c) * HW4 * 4)[i] = y;
+}
+
+struct PtrTable {
+  float* p[SDY_MAX_VARS];
+};
+__global__ __launch_bounds__(256) void init_timeline_kernel(const sdy_var_table v, int T1, int HW4, const PtrTable tln_t,
+                                                             const PtrTable tld_t) {
+  float* const* tln = tln_t.p;
+  float* const* tld = tld_t.p;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW4) return;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const long off = (long)b * T1 * HW4 * 4;
+  const f32x4 x = reinterpret_cast<const f32x4*>(v.data[c] + off)[i];
+  const float m = v.mean[c], s = v.std[c];
+  f32x4 y, d;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    y[e] = (x[e] - m) / s;
+    d[e] = y[e] * s + m;
+  }
+  reinterpret_cast<f32x4*>(tln[c] + off)[i] = y;
+  reinterpret_cast<f32x4*>(tld[c] + off)[i] = d;
+}
+
+__global__ __launch_bounds__(256) void step_finish_kernel(const sdy_step_finish_args a) {
+  const int HW4 = a.HW >> 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW4) return;
+  const int e = blockIdx.y, b = blockIdx.z;
+  const int oi = a.out_idx[e], ii = a.in_idx[e];
+  f32x4 g;
+  if (oi >= 0) {
+    g = reinterpret_cast<const f32x4*>(a.gen + ((long)b * a.n_out + oi) * a.HW)[i];
+    const long toff = ((long)b * a.T1 + a.t) * a.HW;
+    if (e == a.presc_entry) {   // Prescriber.__call__ (prescriber.py:68-92)
+      const f32x4 tv = reinterpret_cast<const f32x4*>(a.presc_target + toff)[i];
+      const f32x4 mk = reinterpret_cast<const f32x4*>(a.presc_mask + toff)[i];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float tn = (tv[q] - a.mean[e]) / a.std[e];
+        if (a.interpolate)
+          g[q] = mk[q] * tn + (1.0f - mk[q]) * g[q];
+        else
+          g[q] = ((int)rintf(mk[q]) == a.mask_value) ? tn : g[q];   // torch.round = round half to even
+      }
+    }
+    reinterpret_cast<f32x4*>(a.gen_norm_tl[e] + toff)[i] = g;
+    reinterpret_cast<f32x4*>(a.gen_tl[e] + toff)[i] = g * a.std[e] + a.mean[e];
+  } else {
+    g = reinterpret_cast<const f32x4*>(a.prev_in + ((long)b * a.n_in + ii) * a.HW)[i];   // input-only: carried over
+  }
+  if (ii >= 0) reinterpret_cast<f32x4*>(a.next_in + ((long)b * a.n_in + ii) * a.HW)[i] = g;
+}
+
+__global__ __launch_bounds__(256) void lp_terms_kernel(const float* __restrict__ gen, const sdy_var_table v, int t, int T1,
+                                                        int HW4, double* __restrict__ terms) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gen + ((long)b * v.nvars + c) * HW4 * 4);
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(v.data[c] + ((long)b * T1 + t) * HW4 * 4);
+  const float m = v.mean[c], s = v.std[c];
+  double d2 = 0.0, y2 = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW4; i += gridDim.x * 256) {
+    const f32x4 g = g4[i], x = x4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float y = (x[e] - m) / s;
+      const float d = g[e] - y;
+      d2 += (double)d * d;
+      y2 += (double)y * y;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    d2 += __shfl_down(d2, off, 64);
+    y2 += __shfl_down(y2, off, 64);
+  }
+  __shared__ double sh[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[wave] = d2;
+    sh[4 + wave] = y2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&terms[2 * b], sh[0] + sh[1] + sh[2] + sh[3]);
+    atomicAdd(&terms[2 * b + 1], sh[4] + sh[5] + sh[6] + sh[7]);
+  }
+}
+
 }  // namespace
+
+extern "C" int sdy_norm_pack(const sdy_var_table* vars, int t, int T1, int B, int HW, float* out, void* stream) {
+  if (!vars || !out || vars->nvars < 1 || vars->nvars > SDY_MAX_VARS || t < 0 || t >= T1 || B <= 0 || HW <= 0) return SDY_ERR_ARG;
+  if (HW & 3) return SDY_ERR_ALIGN;
+  for (int i = 0; i < vars->nvars; ++i)
+    if (!vars->data[i] || vars->std[i] == 0.0f) return SDY_ERR_ARG;
+  hipLaunchKernelGGL(norm_pack_kernel, dim3((HW / 4 + 255) / 256, vars->nvars, B), dim3(256), 0, (hipStream_t)stream, *vars,
+                     t, T1, HW / 4, out);
+  return sdy_launch_status();
+}
+
+extern "C" int sdy_init_timeline(const sdy_var_table* vars, int T1, int B, int HW, float* const* tl_norm,
+                                 float* const* tl_denorm, void* stream) {
+  if (!vars || !tl_norm || !tl_denorm || vars->nvars < 1 || vars->nvars > SDY_MAX_VARS || B <= 0 || HW <= 0) return SDY_ERR_ARG;
+  if (HW & 3) return SDY_ERR_ALIGN;
+  PtrTable tn, td;   // the host pointer arrays travel by value in the kernel arguments
+  for (int i = 0; i < vars->nvars; ++i) {
+    if (!tl_norm[i] || !tl_denorm[i] || !vars->data[i] || vars->std[i] == 0.0f) return SDY_ERR_ARG;
+    tn.p[i] = tl_norm[i];
+    td.p[i] = tl_denorm[i];
+  }
+  hipLaunchKernelGGL(init_timeline_kernel, dim3((HW / 4 + 255) / 256, vars->nvars, B), dim3(256), 0, (hipStream_t)stream,
+                     *vars, T1, HW / 4, tn, td);
+  return sdy_launch_status();
+}
+
+extern "C" int sdy_step_finish(const sdy_step_finish_args* a, void* stream) {
+  if (!a || !a->gen || !a->next_in || a->B <= 0 || a->HW <= 0 || a->n_entries < 1 || a->n_entries > SDY_MAX_VARS) return SDY_ERR_ARG;
+  if (a->HW & 3) return SDY_ERR_ALIGN;
+  if (a->t < 1 || a->t >= a->T1) return SDY_ERR_ARG;
+  for (int e = 0; e < a->n_entries; ++e) {
+    if (a->out_idx[e] < 0 && a->in_idx[e] < 0) return SDY_ERR_ARG;
+    if (a->out_idx[e] >= a->n_out || a->in_idx[e] >= a->n_in) return SDY_ERR_ARG;
+    if (a->out_idx[e] >= 0 && (!a->gen_norm_tl[e] || !a->gen_tl[e])) return SDY_ERR_ARG;
+    if (a->out_idx[e] < 0 && !a->prev_in) return SDY_ERR_ARG;
+  }
+  if (a->presc_entry >= 0 && (a->presc_entry >= a->n_entries || !a->presc_target || !a->presc_mask ||
+                              a->out_idx[a->presc_entry] < 0))
+    return SDY_ERR_ARG;
+  hipLaunchKernelGGL(step_finish_kernel, dim3((a->HW / 4 + 255) / 256, a->n_entries, a->B), dim3(256), 0,
+                     (hipStream_t)stream, *a);
+  return sdy_launch_status();
+}
+
+extern "C" int sdy_lp_rel_terms(const float* gen, const sdy_var_table* targets, int t, int T1, int B, int HW,
+                                double* terms, void* stream) {
+  if (!gen || !targets || !terms || targets->nvars < 1 || targets->nvars > SDY_MAX_VARS || t < 0 || t >= T1 || B <= 0)
+    return SDY_ERR_ARG;
+  if (HW & 3) return SDY_ERR_ALIGN;
+  int gx = (HW / 4 + 255) / 256;
+  if (gx > 16) gx = 16;
+  hipLaunchKernelGGL(lp_terms_kernel, dim3(gx, targets->nvars, B), dim3(256), 0, (hipStream_t)stream, gen, *targets, t, T1,
+                     HW / 4, terms);
+  return sdy_launch_status();
+}
 
 int sdy_instnorm_coeffs_launch(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
                                const float* ss, long ss_stride, float eps, float* a, float* d, hipStream_t stream) {

@@ -95,3 +95,44 @@ def test_call_trace_is_16_forwards():
     expect = [("F", 0.0), ("I", 1.0), ("F", 1.0), ("I", 2.0), ("I", 1.0), ("F", 2.0), ("I", 3.0), ("I", 2.0),
               ("F", 3.0), ("I", 4.0), ("I", 3.0), ("F", 4.0), ("I", 5.0), ("I", 4.0), ("F", 5.0), ("I", 5.0)]
     assert trace == expect
+
+
+def test_stepper_interpolating_prescriber_matches_oracle():
+    """MultiStepStepper with an interpolating prescriber (prescriber.py:78-81) and dropout on, vs the oracle stepper."""
+    import sdy_amd
+    from oracle.stepper import run_on_batch
+
+    exp, oracle, cs, n_forc = _build(hack=True, dropout=True)
+    in_names = ["HGTsfc"] + [f"v{i}" for i in range(1, cs)]
+    out_names, forcing_names = in_names[1:], ["f0", "f1"]
+    g = torch.Generator(device="cpu").manual_seed(99)
+    B, T1 = 2, 8
+    means = {n: float(torch.randn((), generator=g)) for n in in_names + forcing_names}
+    stds = {n: float(torch.rand((), generator=g) + 0.5) for n in in_names + forcing_names}
+    data = {n: torch.randn(B, T1, 32, 64, generator=g) * stds[n] + means[n] for n in in_names + forcing_names}
+    data["frac"] = torch.rand(B, T1, 32, 64, generator=g)
+    pres = dict(prescribed_name="v3", mask_name="frac", mask_value=1, interpolate=True)
+
+    class OMod:   # oracle-side module with the reference's prediction cache
+        true_horizon = 6
+
+        def __init__(self):
+            self.cache = None
+        from contextlib import nullcontext
+        ema_scope = inference_dropout_scope = staticmethod(nullcontext)
+
+        def get_preds_at_t_for_batch(self, batch, horizon, **kw):
+            if horizon == 1:
+                self.cache = oracle.sample(batch["dynamics"], static_condition=batch["static_condition"])
+            return {f"t{horizon}_preds_normed": self.cache[f"t{horizon}_preds"]}
+
+    tm = {k: torch.tensor(v) for k, v in means.items()}
+    ts = {k: torch.tensor(v) for k, v in stds.items()}
+    metrics, gen, gen_norm = run_on_batch(data, OMod(), in_names, out_names, forcing_names, tm, ts, T1 - 1, pres, hack=True)
+    stepper = sdy_amd.MultiStepStepper(exp, in_names + forcing_names, out_names, forcing_names, means, stds,
+                                       sdy_amd.Prescriber(**pres))
+    out = stepper.run_on_batch({k: v.cuda() for k, v in data.items()}, None, n_forward_steps=T1 - 1)
+    for n in out_names:
+        err = rel_l2(out.gen_data[n], gen[n])
+        assert err < TOL, f"{n}: {err:.3e}"
+    assert abs(float(out.metrics["loss"]) - metrics["loss"]) < 1e-3 * metrics["loss"]

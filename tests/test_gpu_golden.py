@@ -105,3 +105,42 @@ def test_sampler_vs_reference(name):
         err = rel_l2(out[k], ref[k])
         assert err < TOL, f"{name}/{k}: rel L2 {err:.3e}"
         assert err < TOL_TIGHT, f"{name}/{k}: rel L2 {err:.3e}"
+
+
+def test_stepper_vs_reference():
+    """MultiStepStepper.run_on_batch vs the reference's own run_on_batch_multistep (normalise, pack, 8 autoregressive
+    steps across a window boundary, prescriber, HGTsfc carry-over, denormalise, LpLoss metrics)."""
+    import sdy_amd
+
+    z = gu.load("fx_stepper_tiny")
+    fcfg = SFNOConfig(**json.loads(str(z["fcfg"])))
+    icfg = SFNOConfig(**json.loads(str(z["icfg"])))
+    names = {k: json.loads(str(z[k])) for k in ("in_names", "out_names", "forcing_names")}
+    n_forc = len(names["forcing_names"])
+    fnet = _net(fcfg, fcfg.in_chans - n_forc, n_forc, gu.state_dict(z, "f::"))
+    inet = _net(icfg, icfg.in_chans - n_forc, n_forc, gu.state_dict(z, "i::"))
+    exp = sdy_amd.MultiHorizonForecastingDYffusion(
+        fnet, sdy_amd.InterpolationExperiment(inet, horizon=6), horizon=6,
+        diffusion_config=dict(hack_for_imprecise_interpolation=True, enable_interpolator_dropout=False))
+    pr = json.loads(str(z["prescriber"]))
+    stepper = sdy_amd.MultiStepStepper(
+        exp, names["in_names"] + names["forcing_names"], names["out_names"], names["forcing_names"],
+        means={k[6:]: float(z[k]) for k in z.files if k.startswith("mean::")},
+        stds={k[5:]: float(z[k]) for k in z.files if k.startswith("std::")},
+        prescriber=sdy_amd.Prescriber(pr["prescribed_name"], pr["mask_name"], pr["mask_value"], pr["interpolate"]))
+    data = {k[6:]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("data::")}
+    n_steps = int(z["n_steps"])
+    out = stepper.run_on_batch(data, None, n_forward_steps=n_steps)
+    assert sorted(out.gen_data) == sorted(names["out_names"])
+    for n in names["out_names"]:
+        assert out.gen_data[n].shape == (2, n_steps + 1, 32, 64)
+        e1 = rel_l2(out.gen_data_norm[n], torch.from_numpy(z["gen_norm::" + n]))
+        e2 = rel_l2(out.gen_data[n], torch.from_numpy(z["gen::" + n]))
+        assert e1 < TOL_TIGHT and e2 < TOL_TIGHT, f"{n}: {e1:.3e} {e2:.3e}"
+    for k in z.files:
+        if k.startswith("metric::"):
+            assert abs(float(out.metrics[k[8:]]) - float(z[k])) < 1e-4 * max(1.0, abs(float(z[k]))), k
+    # normalised targets are exact (same two fp32 operations as the reference)
+    v = "v1"
+    ref = (torch.from_numpy(z["data::" + v]) - float(z["mean::" + v])) / float(z["std::" + v])
+    assert rel_l2(out.target_data_norm[v], ref) < 1e-6

@@ -110,3 +110,17 @@ def test_partition(sdy):
     assert units == [(ic, m) for ic in range(4) for m in range(25)]
     assert [len(b) for b in ensemble.batches(ensemble.rank_units(4, 25, 0, 8), 5)] == [5, 5, 3]
     assert ensemble.partition(3, 8)[5] == (3, 0)
+
+
+def test_stepper_host_validation(sdy):
+    with pytest.raises(ValueError):
+        sdy.Prescriber("a", "m", mask_value=0, interpolate=True)                  # prescriber.py:33-35
+    with pytest.raises(ValueError):                                                # prescribed var must be in & out
+        sdy.MultiStepStepper(None, ["a", "b", "f"], ["b"], ["f"], {}, {}, sdy.Prescriber("a", "m", 1))
+    st = sdy.MultiStepStepper(None, ["HGTsfc", "a", "b", "f"], ["a", "b"], ["f"], {"a": 1.0}, {"a": 2.0})
+    assert st.in_names == ["HGTsfc", "a", "b"] and st._entries == ["HGTsfc", "a", "b"]
+    with pytest.raises(RuntimeError, match="GPU only"):
+        class M:
+            true_horizon = 6
+            model = None
+        sdy.MultiStepStepper(M(), ["a", "f"], ["a"], ["f"], {}, {}).run_on_batch({"a": torch.zeros(1, 2, 4, 8)}, None, 1)

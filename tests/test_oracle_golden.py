@@ -98,3 +98,50 @@ def test_call_trace_fixture():
         tr = json.load(f)
     assert [c for c, _ in tr].count("F") == 6 and [c for c, _ in tr].count("I") == 10
     assert tr[:5] == [["F", 0.0], ["I", 1.0], ["F", 1.0], ["I", 2.0], ["I", 1.0]]
+
+
+def test_stepper_matches_reference():
+    """oracle/stepper.py vs the reference's own run_on_batch_multistep (fixture fx_stepper_tiny)."""
+    from contextlib import nullcontext
+
+    from oracle.stepper import run_on_batch
+
+    z = gu.load("fx_stepper_tiny")
+    smp, _ = _sampler(_ZWrap(z, hack=1))
+
+    class Mod:   # the stateful prediction cache of forecasting_multi_horizon.py:347-380, on the oracle sampler
+        true_horizon = 6
+        ema_scope = inference_dropout_scope = staticmethod(nullcontext)
+
+        def __init__(self):
+            self.cache = None
+
+        def get_preds_at_t_for_batch(self, batch, horizon, **kw):
+            if horizon == 1:
+                x = batch["dynamics"]
+                self.cache = smp.sample(x, static_condition=batch["static_condition"])
+            return {f"t{horizon}_preds_normed": self.cache[f"t{horizon}_preds"]}
+
+    names = {k: json.loads(str(z[k])) for k in ("in_names", "out_names", "forcing_names")}
+    data = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("data::")}
+    means = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mean::")}
+    stds = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("std::")}
+    metrics, gen, gen_norm = run_on_batch(data, Mod(), names["in_names"], names["out_names"], names["forcing_names"],
+                                          means, stds, int(z["n_steps"]), json.loads(str(z["prescriber"])), hack=True)
+    for n in names["out_names"]:
+        assert rel_l2(gen_norm[n], torch.from_numpy(z["gen_norm::" + n])) < 5e-6, n
+        assert rel_l2(gen[n], torch.from_numpy(z["gen::" + n])) < 5e-6, n
+    for k in z.files:
+        if k.startswith("metric::"):
+            assert abs(metrics[k[8:]] - float(z[k])) < 1e-4 * max(1.0, abs(float(z[k]))), k
+
+
+class _ZWrap:
+    """npz view with an overridable scalar (the stepper fixture has no 'hack'/'dropout' entries)."""
+
+    def __init__(self, z, **over):
+        self.z, self.over = z, over
+        self.files = list(z.files) + list(over)
+
+    def __getitem__(self, k):
+        return self.over[k] if k in self.over else self.z[k]

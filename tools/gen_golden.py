@@ -210,6 +210,56 @@ def gen_sample(tag, hack, dropout):
     # also exercise the stepper-facing surface once (get_preds_at_t_for_batch), results must equal sample()
 
 
+def gen_stepper(tag="fx_stepper_tiny"):
+    """The reference's own `run_on_batch_multistep` (src/ace_inference/core/stepper_multistep.py:298-466): normalise, pack,
+    autoregressive loop over n_forward_steps with the DYffusion module, prescriber, denormalise."""
+    from src.ace_inference.core.normalizer import StandardNormalizer
+    from src.ace_inference.core.optimization import NullOptimization
+    from src.ace_inference.core.prescriber import Prescriber
+    from src.ace_inference.core.stepper_multistep import run_on_batch_multistep
+    from src.ace_inference.training.utils.darcy_loss import LpLoss
+    from src.utilities.packer import Packer
+
+    C, n_forc, H, W, E, L = 6, 2, 32, 64, 16, 2
+    fc, ipol, fcfg, icfg, fsd, isd, cs = build_experiments(C, n_forc, H, W, E, L, True, False, 11, 22)
+    in_names = ["HGTsfc"] + [f"v{i}" for i in range(1, cs)]     # HGTsfc is input-only (the "imprecise" case)
+    out_names = in_names[1:]
+    forcing_names = [f"f{i}" for i in range(n_forc)]
+    mask_name = "ocean_fraction"
+    n_steps, B = 8, 2
+    g = torch.Generator(device="cpu").manual_seed(2024)
+    names = in_names + forcing_names
+    means = {n: torch.randn((), generator=g) * 3.0 for n in names}
+    stds = {n: torch.rand((), generator=g) * 2.0 + 0.5 for n in names}
+    data = {n: torch.randn(B, n_steps + 1, H, W, generator=g) * stds[n] + means[n] for n in names}
+    data[mask_name] = torch.rand(B, n_steps + 1, H, W, generator=g)
+    pres = Prescriber(prescribed_name="v2", mask_name=mask_name, mask_value=1, interpolate=False)
+
+    class _NullAgg:
+        def record_batch(self, *a, **k):
+            pass
+
+    axis = -3
+    stepped = run_on_batch_multistep(
+        data={k: v.clone() for k, v in data.items()}, module=fc, normalizer=StandardNormalizer(means, stds),
+        in_packer=Packer(in_names, axis=axis), out_packer=Packer(out_names, axis=axis),
+        forcings_packer=Packer(forcing_names, axis=axis), optimization=NullOptimization(), loss_obj=LpLoss(),
+        prescriber=pres, aggregator=_NullAgg(), n_forward_steps=n_steps)
+    out = dict(in_names=json.dumps(in_names), out_names=json.dumps(out_names), forcing_names=json.dumps(forcing_names),
+               prescriber=json.dumps(pres.get_state()), n_steps=np.array(n_steps),
+               fcfg=json.dumps(fcfg.__dict__), icfg=json.dumps(icfg.__dict__))
+    out.update({"f::" + k: v.numpy() for k, v in fsd.items()})
+    out.update({"i::" + k: v.numpy() for k, v in isd.items()})
+    out.update({"data::" + k: v.numpy() for k, v in data.items()})
+    out.update({"mean::" + k: v.numpy() for k, v in means.items()})
+    out.update({"std::" + k: v.numpy() for k, v in stds.items()})
+    out.update({"gen::" + k: v.numpy() for k, v in stepped.gen_data.items()})
+    out.update({"gen_norm::" + k: v.numpy() for k, v in stepped.gen_data_norm.items()})
+    out.update({"metric::" + k: np.asarray(float(v)) for k, v in stepped.metrics.items()})
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"{tag}: loss {float(stepped.metrics['loss']):.5f}, gen vars {sorted(stepped.gen_data)[:3]}..., saved")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # C1: one block, 32x64, 8 channels (BASELINE.json configs[0])
@@ -227,5 +277,6 @@ if __name__ == "__main__":
     gen_sample("fx_sample_tiny_masks", hack=True, dropout=True)
     with open(os.path.join(OUT, "fx_trace.json"), "w") as f:
         json.dump(t1, f)
+    gen_stepper()
     sizes = {n: os.path.getsize(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT))}
     print(sizes)

@@ -152,8 +152,15 @@ def install():
         def __init__(self, d=None, batch_size=None, **k):
             super().__init__(d or {})
 
+        def to(self, *a, **k):
+            return TensorDict({n: (v.to(*a, **k) if hasattr(v, "to") else v) for n, v in self.items()})
+
     _module("tensordict", TensorDict=TensorDict, TensorDictBase=TensorDict)
     _module("wandb", run=None, Table=_Anything, Image=_Anything, Video=_Anything)
+    # imported (not used on the sampling path) by src/ace_inference/core/stepper_multistep.py and friends
+    _module("dacite", from_dict=lambda *a, **k: None, Config=_Anything)
+    _module("netCDF4", Dataset=_Anything)
+    _module("h5py", File=_Anything)
     _module("tensorly", set_backend=lambda *a, **k: None, ndim=lambda x: x.ndim, einsum=torch.einsum)
     _module("tltorch")
     _module("tltorch.factorized_tensors")
