@@ -153,6 +153,32 @@ int sdy_conv1x1(const sdy_conv_args* args, void* stream);
 size_t sdy_h3_pack_bytes(int Cout, int Cin);
 int sdy_h3_pack_weight(const float* w_host, int Cout, int Cin, void* packed_dev, float* scale);
 
+/* Fused MLP of one SFNO block (src/models/sfno/layers.py:73-80 as called from src/models/sfno/sfnonet.py:313-335):
+ *   out[b] = batch_scale[b] * dropout2( W2 . dropout1( GELU( W1 . (pa[b]*x[b] + pd[b]) + b1 ) ) + b2 ) + add[b]
+ * in ONE launch; the hidden activation stays on the compute unit (never written to HBM).  Split-fp16 arithmetic and
+ * Philox stream identical to two sdy_conv1x1 calls with (stream_fc1, stream_fc2).  Supported shape: E = 256,
+ * hidden = 512 (sdy_mlp_h3_supported); anything else returns SDY_ERR_UNSUPPORTED and the caller uses sdy_conv1x1. */
+typedef struct sdy_mlp_args {
+  const float* x;  long x_bstride;     /* dev (B, E, HW) */
+  const float* pa; const float* pd;    /* dev [B*E] each or NULL (norm affine folded into the load) */
+  const void* w; float w1_scale; float w2_scale;     /* sdy_mlp_h3_pack output and the two scales it returned */
+  const float* b1; const float* b2;                  /* dev [hidden], dev [E] */
+  float* out;      long out_bstride;   /* dev (B, E, HW) */
+  const float* add; long add_bstride;  /* dev (B, E, HW) residual or NULL */
+  int B, E, hidden, HW;
+  float drop_p;                        /* 0 = no dropout */
+  uint64_t seed; uint32_t call; uint32_t stream_fc1; uint32_t stream_fc2; uint32_t batch_offset;
+  const float* batch_scale;            /* dev [B] or NULL (drop-path scale) */
+} sdy_mlp_args;
+int sdy_mlp_h3_supported(int E, int hidden);
+size_t sdy_mlp_h3_pack_bytes(int E, int hidden);
+/* w1_host: (hidden, E) row-major = mlp.fwd.0.weight;  w2_host: (E, hidden) row-major = mlp.fwd.{2|3}.weight.
+ * Both are split to fp16 hi|lo (times a power of two each, returned) and interleaved into one per-wave stream in the
+ * order the kernel consumes them. */
+int sdy_mlp_h3_pack(const float* w1_host, const float* w2_host, int E, int hidden, void* packed_dev, float* scale1,
+                    float* scale2);
+int sdy_mlp_h3(const sdy_mlp_args* args, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Whole network.  Replaces SphericalFourierNeuralOperatorNet.__init__/forward
  * (src/models/sfno/sfnonet.py:426-841) + BaseModel.concat_condition_if_needed (src/models/_base_model.py:166-192)

@@ -40,6 +40,22 @@ class SdyConvArgs(C.Structure):
     ]
 
 
+class SdyMlpArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_bstride", C.c_long),
+        ("pa", C.c_void_p), ("pd", C.c_void_p),
+        ("w", C.c_void_p), ("w1_scale", C.c_float), ("w2_scale", C.c_float),
+        ("b1", C.c_void_p), ("b2", C.c_void_p),
+        ("out", C.c_void_p), ("out_bstride", C.c_long),
+        ("add", C.c_void_p), ("add_bstride", C.c_long),
+        ("B", C.c_int), ("E", C.c_int), ("hidden", C.c_int), ("HW", C.c_int),
+        ("drop_p", C.c_float),
+        ("seed", C.c_uint64), ("call", C.c_uint32), ("stream_fc1", C.c_uint32), ("stream_fc2", C.c_uint32),
+        ("batch_offset", C.c_uint32),
+        ("batch_scale", C.c_void_p),
+    ]
+
+
 SDY_MAX_VARS = 96
 
 
@@ -116,6 +132,11 @@ SIGNATURES = {
     "sdy_instnorm_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_conv1x1": (C.c_int, [C.POINTER(SdyConvArgs), C.c_void_p]),
+    "sdy_mlp_h3_supported": (C.c_int, [C.c_int, C.c_int]),
+    "sdy_mlp_h3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sdy_mlp_h3_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float),
+                                  C.POINTER(C.c_float)]),
+    "sdy_mlp_h3": (C.c_int, [C.POINTER(SdyMlpArgs), C.c_void_p]),
     "sdy_h3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sdy_h3_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "sdy_sfno_create": (C.c_int, [C.POINTER(SdySfnoConfig), C.POINTER(C.c_void_p)]),

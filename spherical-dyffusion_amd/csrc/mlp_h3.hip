@@ -1,0 +1,400 @@
+// Fused SFNO MLP for gfx950:  out = post( W2 . dropout(GELU(W1 . (a*x + d) + b1)) + b2 ) + residual
+// (src/models/sfno/layers.py:73-80 inside the block of src/models/sfno/sfnonet.py:313-335), E = 256 -> 512 -> 256.
+//
+// Unfused, the hidden activation (B x 512 x HW fp32, 3.3 GB at B = 25) is written by fc1 and read back by fc2: two thirds
+// of the HBM traffic of the pair.  Here one workgroup (4 waves, one per SIMD, full register budget) owns 64 pixels end
+// to end and the hidden tile never leaves the CU:
+//
+//   phase 0   x[256 ch][64 px] fp32 -> norm affine, x16, split hi/lo fp16 -> LDS, [px][k] rows, 16-byte chunks
+//             XOR-swizzled so that the MFMA fragment reads (ds_read_b128) are bank-conflict free.
+//   chunk hc  (4 chunks of 128 hidden channels, a runtime loop):
+//     fc1     wave w: hidden rows 128 hc + 32 w .. +32, all 64 px (1 x 2 tiles of 32 x 32), K = 256.
+//     chain   bias + GELU + Philox dropout on the accumulators, x16, split hi/lo -> LDS H[px][128 k] (same swizzle),
+//             two alternating buffers: ONE barrier per chunk.
+//     fc2     wave w: output rows 64 w .. +64 (2 x 2 tiles, accumulators live across all chunks), K = this chunk's
+//             128 hidden channels read from LDS.  No cross-wave reduction.
+//   epilogue  bias, Philox dropout, drop-path scale, residual add, store.
+//
+// Weights never touch LDS: they are packed on the host into ONE linear stream per wave, in exactly the order the wave
+// consumes them, as MFMA A-fragments (32 rows x 16 k, 1 KB, lane-major): a "group" = (hi, lo) fragment pair = two fully
+// coalesced 1 KB loads feeding 6 MFMAs (3 split-precision passes x 2 pixel tiles).  128 groups per wave per tile.  At
+// f16 MFMA rates a group is ~190 cycles of matrix work while an L2 round trip under load is > 2000 cycles, so a ring of
+// RING = 16 groups (128 VGPRs) is kept in flight -- that, not LDS, is what the register budget is spent on.
+//
+// Precision is the split-fp16 scheme of gemm_h3.hip (Ah.Bh + Ah.Bl + Al.Bh, fp32 accumulation); the dropout stream and
+// epilogue arithmetic equal sdy_conv1x1's for the same (seed, call, stream, batch_offset): the unfused and fused paths
+// agree to fp32 round-off and draw identical masks.
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ME = 256;        // embedding channels
+constexpr int MH = 512;        // hidden channels
+constexpr int TN = 64;         // pixels per workgroup
+constexpr int HC = 128;        // hidden channels per chunk
+constexpr int NCH = MH / HC;   // chunks
+constexpr int KS1 = ME / 16;   // k-steps of fc1
+constexpr int KSC = HC / 16;   // k-steps of fc2 per chunk
+constexpr int GPC = KS1 + 2 * KSC;      // weight groups per chunk per wave (16 fc1 + 16 fc2)
+constexpr int RING = 16;                // groups in flight; GPC % RING == 0, so slot = position % RING (compile time)
+constexpr int NGROUPS = NCH * GPC;      // 128
+constexpr float SX = 16.0f;    // activation pre-scale (keeps lo parts out of the fp16 subnormals)
+constexpr int GROUP_F8 = 2 * 64;        // f16x8 elements per group (hi fragment, lo fragment)
+
+struct MlpParams {
+  const float* x; long x_bs;
+  const float* pa; const float* pd;
+  const f16x8* w;                          // [4 waves][NGROUPS + RING groups][hi | lo][64 lanes]
+  const float* b1; const float* b2;
+  float* out; long out_bs;
+  const float* add; long add_bs;
+  int HW;
+  float s1, s2;                            // accumulator scales: 1 / (w_scale * SX)
+  uint32_t drop_thr; float drop_scale;
+  uint32_t seed_lo, seed_hi, stream1, stream2, call, batch_offset;
+  const float* batch_scale;
+};
+
+// 4-bit slot swizzle of pixel row px: injective on each ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}
+// of the 32 pixels one fragment read touches), so B-fragment reads are conflict free for 256-B and 512-B rows alike.
+__device__ __forceinline__ int px_swz(int px) { return (px & 15) ^ (((px >> 4) & 1) * 3); }
+// x tile: rows of 256 k = 512 B (two bank rows); position in halfs of the 16-byte chunk c (0..31)
+__device__ __forceinline__ int xs_off(int px, int c) { return px * ME + (((c & 16) | ((c ^ px_swz(px)) & 15)) << 3); }
+// hidden chunk: rows of 128 k = 256 B (one bank row); chunk c (0..15)
+__device__ __forceinline__ int hs_off(int px, int c) { return px * HC + (((c ^ px_swz(px)) & 15) << 3); }
+
+__global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 64 KB x tile + 2 x 32 KB hidden chunk
+  _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
+  _Float16* Xs_lo = Xs_hi + TN * ME;
+  _Float16* Hs = Xs_lo + TN * ME;          // [buf][hi | lo][px][HC]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int z = blockIdx.y;
+  const int n0 = blockIdx.x * TN;
+  const bool full = n0 + TN <= p.HW;   // workgroup-uniform
+
+  // ---- weight ring: slot s holds group (chunk, s); refilled for the next chunk right after its use
+  f16x8 r_hi[RING], r_lo[RING];
+  const f16x8* __restrict__ wp = p.w + (size_t)wave * (NGROUPS + RING) * GROUP_F8 + lane;
+#pragma unroll
+  for (int s = 0; s < RING; ++s) {
+    r_hi[s] = wp[s * GROUP_F8];
+    r_lo[s] = wp[s * GROUP_F8 + 64];
+  }
+  wp += RING * GROUP_F8;   // from here on wp[i * GROUP_F8] is the group RING positions after position i of the chunk
+
+  // ---- phase 0: x tile -> LDS (fp16 hi / lo, [px][k])
+  {
+    const int q = tid & 15, o = tid >> 4;   // pixel quad, channel octets o and o + 16
+    // ragged last tile: clamp the address (branch-free loads keep exact vmcnt counts) and zero the values afterwards
+    const bool ok = full || (n0 + 4 * q < p.HW);
+    const float* __restrict__ xg = p.x + (long)z * p.x_bs + (ok ? n0 + 4 * q : 0);
+    f32x4 xr[2][8];
+#pragma unroll
+    for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = 8 * (o + 16 * oc) + e;
+        xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)ch * p.HW);
+      }
+    if (!ok) {
+#pragma unroll
+      for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[oc][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int oc = 0; oc < 2; ++oc) {
+      const int c0 = 8 * (o + 16 * oc);
+      float av[8], dv[8];
+      if (p.pa) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * ME + c0);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * ME + c0 + 4);
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.pd + (long)z * ME + c0);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(p.pd + (long)z * ME + c0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          av[e] = a0[e] * SX; av[e + 4] = a1[e] * SX;
+          dv[e] = d0[e] * SX; dv[e + 4] = d1[e] * SX;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { av[e] = SX; dv[e] = 0.f; }
+      }
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const int px = 4 * q + pp;
+        f16x8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = fmaf(xr[oc][e][pp], av[e], dv[e]);
+          const _Float16 hv = (_Float16)v;
+          vh[e] = hv;
+          vl[e] = (_Float16)(v - (float)hv);
+        }
+        const int off = xs_off(px, o + 16 * oc);
+        *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
+        *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x16 oacc[2][2];   // this wave's 64 output rows x 64 px
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[mi][j][r] = 0.0f;
+  f32x4 rres[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) rres[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int e_col = n0 + 4 * (tid & 15);                    // store phase: first pixel of this thread's quad
+  const bool e_ok = full || e_col < p.HW;
+  const long e_off = e_ok ? e_col : 0;
+
+  const bool do_drop = p.drop_thr != 0u;
+  const uint32_t c1_base = (uint32_t)(((uint64_t)(z + p.batch_offset) * (uint64_t)(MH >> 2)) & 0xFFFFFFFFu);
+
+  for (int hc = 0; hc < NCH; ++hc) {
+    // ---- fc1 of this chunk: hidden rows 128 hc + 32 wave .. +32
+    // (its bias is requested first: a load issued after the ring refills could only be waited for by draining the ring)
+    const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
+    f32x4 bv[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) bv[g4] = *reinterpret_cast<const f32x4*>(p.b1 + row0 + 8 * g4);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      f16x8 bh[2], bl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = xs_off(32 * j + l31, 2 * ks + h);
+        bh[j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
+        bl[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[ks % RING], bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks % RING], bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks % RING], bh[j], acc[j], 0, 0, 0);
+      r_hi[ks % RING] = wp[ks * GROUP_F8];
+      r_lo[ks % RING] = wp[ks * GROUP_F8 + 64];
+      __builtin_amdgcn_sched_barrier(0);   // keep the refill here: the scheduler otherwise sinks it next to its use
+    }
+    // ---- chain: bias + GELU + dropout, x16, split -> LDS hidden chunk [px][k]
+    _Float16* Hh = Hs + (hc & 1) * (2 * TN * HC);
+    _Float16* Hl = Hh + TN * HC;
+    {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int px = 32 * j + l31;
+        const int gn = n0 + px;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+          if (do_drop) {
+            const philox4 w = philox4x32_10((uint32_t)gn, c1_base + (uint32_t)((row0 + 8 * g4) >> 2), p.stream1, p.call,
+                                            p.seed_lo, p.seed_hi);
+            words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
+          }
+          f16x4 vh, vl;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            float v = acc[j][4 * g4 + r4] * p.s1 + bv[g4][r4];
+            v = gelu_erf(v);
+            if (do_drop) v = (words[r4] >= p.drop_thr) ? v * p.drop_scale : 0.0f;
+            v *= SX;
+            const _Float16 hv = (_Float16)v;
+            vh[r4] = hv;
+            vl[r4] = (_Float16)(v - (float)hv);
+          }
+          // local k of these 4 values: 32 wave + 8 g4 + 4 h .. +3  ->  16-byte chunk 4 wave + g4, half h
+          const int off = hs_off(px, 4 * wave + g4) + 4 * h;
+          *reinterpret_cast<f16x4*>(Hh + off) = vh;
+          *reinterpret_cast<f16x4*>(Hl + off) = vl;
+        }
+      }
+    }
+    __syncthreads();   // the only barrier per chunk (the other hidden buffer is rewritten one barrier later)
+    if (hc == NCH - 1 && p.add) {
+      // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested one fc2 phase
+      // ahead of their use; older than every later ring refill, so waiting for them does not drain the ring
+      const float* ag = p.add + (long)z * p.add_bs + (long)(tid >> 4) * p.HW + e_off;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rres[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+    }
+    // ---- fc2 partial: output rows 64 wave .. +64 += W2[:, chunk] . hidden chunk
+#pragma unroll
+    for (int t = 0; t < KSC; ++t) {
+      f16x8 bh[2], bl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = hs_off(32 * j + l31, 2 * t + h);
+        bh[j] = *reinterpret_cast<const f16x8*>(Hh + off);
+        bl[j] = *reinterpret_cast<const f16x8*>(Hl + off);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int pos = KS1 + 2 * t + mi, s = pos % RING;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], oacc[mi][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], oacc[mi][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], oacc[mi][j], 0, 0, 0);
+        r_hi[s] = wp[pos * GROUP_F8];
+        r_lo[s] = wp[pos * GROUP_F8 + 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    wp += GPC * GROUP_F8;
+  }
+
+  // ---- epilogue: bias, dropout, drop-path scale in accumulator layout -> LDS [256 rows][64 px] (the x tile's storage:
+  //      every wave passed the last chunk's barrier after its final x read), then residual add + 16-byte row stores
+  {
+    const float bscale = p.batch_scale ? p.batch_scale[z] : 1.0f;
+    const uint32_t c1_base2 = (uint32_t)(((uint64_t)(z + p.batch_offset) * (uint64_t)(ME >> 2)) & 0xFFFFFFFFu);
+    float* Os = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row0 = 64 * wave + 32 * mi + 4 * h;
+      f32x4 bv[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) bv[g4] = *reinterpret_cast<const f32x4*>(p.b2 + row0 + 8 * g4);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int px = 32 * j + l31;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+          if (do_drop) {
+            const philox4 w = philox4x32_10((uint32_t)(n0 + px), c1_base2 + (uint32_t)((row0 + 8 * g4) >> 2), p.stream2,
+                                            p.call, p.seed_lo, p.seed_hi);
+            words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
+          }
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            float o = oacc[mi][j][4 * g4 + r4] * p.s2 + bv[g4][r4];
+            if (do_drop) o = (words[r4] >= p.drop_thr) ? o * p.drop_scale : 0.0f;
+            Os[(row0 + 8 * g4 + r4) * TN + px] = o * bscale;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (e_ok) {
+      float* og = p.out + (long)z * p.out_bs + (long)(tid >> 4) * p.HW + e_col;
+      const float* os = Os + (tid >> 4) * TN + 4 * (tid & 15);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(os + 16 * i * TN) + rres[i];
+        *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
+      }
+    }
+  }
+}
+
+// power-of-two scale that puts max|w| in [2^12, 2^13) (same rule as the other split-fp16 packers)
+float pick_scale(const float* w, size_t n) {
+  float mx = 0.f;
+  for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+  if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+  int e;
+  std::frexp(mx, &e);
+  return std::ldexp(1.0f, 13 - e);
+}
+
+// one MFMA A-fragment pair (hi, lo) of rows 32 mt .. +32, columns 16 ks .. +16 of the row-major [.][K] matrix w
+void put_group(_Float16* dst, const float* w, int K, int mt, int ks, float s) {
+  for (int ln = 0; ln < 64; ++ln)
+    for (int e = 0; e < 8; ++e) {
+      const float v = w[(size_t)(32 * mt + (ln & 31)) * K + 16 * ks + 8 * (ln >> 5) + e] * s;
+      const _Float16 hv = (_Float16)v;
+      dst[ln * 8 + e] = hv;
+      dst[64 * 8 + ln * 8 + e] = (_Float16)(v - (float)hv);
+    }
+}
+
+}  // namespace
+
+extern "C" int sdy_mlp_h3_supported(int E, int hidden) { return (E == ME && hidden == MH) ? 1 : 0; }
+
+extern "C" size_t sdy_mlp_h3_pack_bytes(int E, int hidden) {
+  if (!sdy_mlp_h3_supported(E, hidden)) return 0;
+  return (size_t)4 * (NGROUPS + RING) * GROUP_F8 * sizeof(f16x8);
+}
+
+// w1_host: (hidden, E) row-major = mlp.fwd.0.weight;  w2_host: (E, hidden) row-major = mlp.fwd.{2|3}.weight
+extern "C" int sdy_mlp_h3_pack(const float* w1_host, const float* w2_host, int E, int hidden, void* packed_dev,
+                               float* scale1, float* scale2) {
+  if (!w1_host || !w2_host || !packed_dev || !scale1 || !scale2) return SDY_ERR_ARG;
+  if (!sdy_mlp_h3_supported(E, hidden)) return SDY_ERR_UNSUPPORTED;
+  const float s1 = pick_scale(w1_host, (size_t)E * hidden), s2 = pick_scale(w2_host, (size_t)E * hidden);
+  const size_t gh = (size_t)GROUP_F8 * 8;   // halfs per group
+  std::vector<_Float16> buf((size_t)4 * (NGROUPS + RING) * gh, (_Float16)0.0f);
+  for (int w = 0; w < 4; ++w) {
+    _Float16* d = buf.data() + (size_t)w * (NGROUPS + RING) * gh;
+    for (int hc = 0; hc < NCH; ++hc) {
+      for (int ks = 0; ks < KS1; ++ks, d += gh) put_group(d, w1_host, ME, 4 * hc + w, ks, s1);   // hidden rows 128hc+32w
+      for (int t = 0; t < KSC; ++t)
+        for (int mi = 0; mi < 2; ++mi, d += gh) put_group(d, w2_host, MH, 2 * w + mi, KSC * hc + t, s2);
+    }
+  }
+  SDY_HIP_TRY(hipMemcpy(packed_dev, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  *scale1 = s1;
+  *scale2 = s2;
+  return SDY_OK;
+}
+
+extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
+  if (!a || !a->x || !a->w || !a->b1 || !a->b2 || !a->out) return SDY_ERR_ARG;
+  if (a->B <= 0 || a->HW <= 0) return SDY_ERR_ARG;
+  if (!sdy_mlp_h3_supported(a->E, a->hidden)) return SDY_ERR_UNSUPPORTED;
+  if ((a->pa == nullptr) != (a->pd == nullptr)) return SDY_ERR_ARG;
+  if ((a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3) || (a->add && (a->add_bstride & 3))) return SDY_ERR_ALIGN;
+  if (a->drop_p < 0.0f || a->drop_p >= 1.0f) return SDY_ERR_ARG;
+  if (a->B > 65535) return SDY_ERR_UNSUPPORTED;
+  MlpParams p{};
+  p.x = a->x; p.x_bs = a->x_bstride; p.pa = a->pa; p.pd = a->pd;
+  p.w = reinterpret_cast<const f16x8*>(a->w);
+  p.b1 = a->b1; p.b2 = a->b2;
+  p.out = a->out; p.out_bs = a->out_bstride; p.add = a->add; p.add_bs = a->add_bstride;
+  p.HW = a->HW;
+  p.s1 = 1.0f / (a->w1_scale * SX);
+  p.s2 = 1.0f / (a->w2_scale * SX);
+  if (a->drop_p > 0.0f) {
+    p.drop_thr = sdy_drop_threshold(a->drop_p);
+    if (p.drop_thr == 0u) p.drop_thr = 1u;
+    p.drop_scale = 1.0f / (1.0f - a->drop_p);
+  }
+  p.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFu); p.seed_hi = (uint32_t)(a->seed >> 32);
+  p.stream1 = a->stream_fc1; p.stream2 = a->stream_fc2; p.call = a->call; p.batch_offset = a->batch_offset;
+  p.batch_scale = a->batch_scale;
+  dim3 grid((a->HW + TN - 1) / TN, a->B);
+  constexpr size_t smem = (size_t)(2 * TN * ME + 4 * TN * HC) * sizeof(_Float16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(mlp_h3_kernel, grid, dim3(256), smem, (hipStream_t)stream, p);
+  return sdy_launch_status();
+}

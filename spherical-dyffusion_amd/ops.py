@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import SdyConvArgs, check, current_stream, lib, ptr
+from ._lib import SdyConvArgs, SdyMlpArgs, check, current_stream, lib, ptr
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -151,6 +151,63 @@ def pack_h3(weight: torch.Tensor, device):
     with torch.cuda.device(device):
         check(lib.sdy_h3_pack_weight(ptr(w), Cout, Cin, ptr(buf), C.byref(sc)), "sdy_h3_pack_weight")
     return buf, sc.value
+
+
+def pack_mlp_h3(w1: torch.Tensor, w2: torch.Tensor, device):
+    """fc1 (hidden, E) and fc2 (E, hidden) weights -> (per-wave fragment stream, scale1, scale2) for `mlp_fused`."""
+    a = w1.detach().to("cpu", torch.float32).reshape(w1.shape[0], -1).contiguous()
+    b = w2.detach().to("cpu", torch.float32).reshape(w2.shape[0], -1).contiguous()
+    hidden, E = a.shape
+    assert b.shape == (E, hidden)
+    if not lib.sdy_mlp_h3_supported(E, hidden):
+        raise NotImplementedError(f"fused MLP kernel supports E=256, hidden=512 (got {E}, {hidden}); use conv1x1")
+    buf = torch.empty(lib.sdy_mlp_h3_pack_bytes(E, hidden), dtype=torch.uint8, device=device)
+    s1, s2 = C.c_float(), C.c_float()
+    with torch.cuda.device(device):
+        check(lib.sdy_mlp_h3_pack(ptr(a), ptr(b), E, hidden, ptr(buf), C.byref(s1), C.byref(s2)), "sdy_mlp_h3_pack")
+    return (buf, s1.value, s2.value)
+
+
+def mlp_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, *,
+              pre_affine=None, add: Optional[torch.Tensor] = None, drop_p: float = 0.0, seed: int = 0, call: int = 0,
+              stream_fc1: int = 0, stream_fc2: int = 1, batch_offset: int = 0,
+              batch_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              prepared=None) -> torch.Tensor:
+    """The block's MLP (`src/models/sfno/layers.py:73-80`) with the norm affine, both dropouts, DropPath scale and the
+    residual add in one launch (include/sdy_amd.h, sdy_mlp_h3).  Same arithmetic and dropout stream as
+    conv1x1(fc1, gelu, stream_fc1) -> conv1x1(fc2, stream_fc2, add_mode=2)."""
+    x = _f32c(x)
+    B, E, H, W = x.shape
+    if prepared is None:
+        prepared = pack_mlp_h3(w1, w2, x.device)
+    hidden = b1.numel()
+    if out is None:
+        out = torch.empty_like(x)
+    a = SdyMlpArgs()
+    a.x, a.x_bstride = ptr(x), E * H * W
+    a.w, a.w1_scale, a.w2_scale = ptr(prepared[0]), prepared[1], prepared[2]
+    bb1, bb2 = _aux(b1, x.device), _aux(b2, x.device)
+    a.b1, a.b2 = ptr(bb1), ptr(bb2)
+    a.out, a.out_bstride = ptr(out), E * H * W
+    keep = [x, bb1, bb2, out, prepared]
+    if pre_affine is not None:
+        pa, pd = _aux(pre_affine[0], x.device), _aux(pre_affine[1], x.device)
+        a.pa, a.pd = ptr(pa), ptr(pd)
+        keep += [pa, pd]
+    if add is not None:
+        ad = _aux(add, x.device)
+        a.add, a.add_bstride = ptr(ad), E * H * W
+        keep.append(ad)
+    a.B, a.E, a.hidden, a.HW = B, E, hidden, H * W
+    a.drop_p = drop_p
+    a.seed, a.call, a.stream_fc1, a.stream_fc2, a.batch_offset = seed, call, stream_fc1, stream_fc2, batch_offset
+    if batch_scale is not None:
+        bs = _aux(batch_scale, x.device)
+        a.batch_scale = ptr(bs)
+        keep.append(bs)
+    with torch.cuda.device(x.device):
+        check(lib.sdy_mlp_h3(C.byref(a), current_stream()), "sdy_mlp_h3")
+    return out
 
 
 def cold_update(x_s: torch.Tensor, x_ip_next: torch.Tensor, x_ip_s: Optional[torch.Tensor]) -> torch.Tensor:

@@ -221,3 +221,56 @@ def test_conv1x1_split_fp16_mode(sdy, B, Cin, Cout, H, W):
         got = sdy.ops.conv1x1((x * s).cuda(), w, None, h3=True)
         err = rel_l2(got, F.conv2d(x.double() * s, w.double()))
         assert err < 5e-6, f"scale {s}: {err:.3e}"
+
+
+@pytest.mark.parametrize("B,H,W,drop", [(2, 8, 40, 0.0), (2, 8, 40, 0.1), (1, 45, 64, 0.1), (3, 6, 36, 0.25)])
+def test_mlp_fused_matches_fp64_and_unfused(sdy, B, H, W, drop):
+    """sdy_mlp_h3 (hidden activation kept on the CU) == fc1 -> GELU -> dropout -> fc2 -> dropout -> drop-path scale ->
+    + residual, against an fp64 restatement with the Philox oracle's masks, and against the two-launch path."""
+    from oracle.philox import element_keep_mask
+
+    E, Hd = 256, 512
+    g = _gen(21)
+    F = torch.nn.functional
+    x = torch.randn(B, E, H, W, generator=g) * 1.3 + 0.2
+    w1 = torch.randn(Hd, E, 1, 1, generator=g) / np.sqrt(E)
+    b1 = 0.1 * torch.randn(Hd, generator=g)
+    w2 = torch.randn(E, Hd, 1, 1, generator=g) / np.sqrt(Hd)
+    b2 = 0.1 * torch.randn(E, generator=g)
+    res = torch.randn(B, E, H, W, generator=g)
+    pa = 1 + 0.2 * torch.randn(B, E, generator=g)
+    pd = 0.2 * torch.randn(B, E, generator=g)
+    bs = torch.tensor([1.25, 0.0, 0.8][:B])
+    seed, call, layer, boff = 0xABCDEF0123456789, 3, 5, 7
+    hid = F.gelu(F.conv2d(x.double() * pa.double()[:, :, None, None] + pd.double()[:, :, None, None], w1.double(),
+                          b1.double()))
+    if drop > 0:
+        k1 = torch.from_numpy(element_keep_mask(seed, call, layer, 0, drop, B, Hd, H, W, batch_offset=boff)).double()
+        k2 = torch.from_numpy(element_keep_mask(seed, call, layer, 1, drop, B, E, H, W, batch_offset=boff)).double()
+        hid = hid * k1 / (1.0 - drop)
+    o = F.conv2d(hid, w2.double(), b2.double())
+    if drop > 0:
+        o = o * k2 / (1.0 - drop)
+    ref = o * bs.double()[:, None, None, None] + res.double()
+    kw = dict(drop_p=drop, seed=seed, call=call, batch_offset=boff)
+    got = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2, pre_affine=(pa.cuda(), pd.cuda()), add=res.cuda(),
+                            stream_fc1=2 * layer, stream_fc2=2 * layer + 1, batch_scale=bs.cuda(), **kw)
+    err = rel_l2(got, ref)
+    assert err < TOL_OP, f"fused MLP vs fp64: {err:.3e}"
+    h = sdy.ops.conv1x1(x.cuda(), w1, b1, pre_affine=(pa.cuda(), pd.cuda()), gelu=True, stream_id=2 * layer, h3=True, **kw)
+    two = sdy.ops.conv1x1(h, w2, b2, add=res.cuda(), add_mode=2, batch_scale=bs.cuda(), stream_id=2 * layer + 1, h3=True,
+                          **kw)
+    assert rel_l2(got, two) < 5e-6
+    if drop > 0:   # identical masks: without residual / drop-path exactly the same elements are zero
+        f0 = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2, stream_fc1=2 * layer, stream_fc2=2 * layer + 1, **kw).cpu()
+        assert torch.equal(f0 == 0, k2 == 0), "fc2 dropout mask differs from the Philox oracle"
+    # no affine / no residual / no scale
+    got = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2)
+    ref = F.conv2d(F.gelu(F.conv2d(x.double(), w1.double(), b1.double())), w2.double(), b2.double())
+    assert rel_l2(got, ref) < TOL_OP
+
+
+def test_mlp_fused_rejects_other_shapes(sdy):
+    x = torch.zeros(1, 64, 8, 16).cuda()
+    with pytest.raises(NotImplementedError):
+        sdy.ops.mlp_fused(x, torch.zeros(128, 64), torch.zeros(128), torch.zeros(64, 128), torch.zeros(64))
