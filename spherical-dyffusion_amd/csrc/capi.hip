@@ -426,6 +426,10 @@ struct BlockW {
   DevBuf fb;                  // [E]
   DevBuf skw, skb;            // inner skip: [E][E] transposed, [E]
   DevBuf w1, b1, w2, b2;      // MLP: [E][hid], [hid], [hid][E], [E]
+  // fused MLP kernel (mlp_h3.hip): host copies until both weights are known, then one packed device stream
+  std::vector<float> w1_host, w2_host;
+  void* mlp = nullptr;
+  float mlp_s1 = 1.0f, mlp_s2 = 1.0f;
 };
 
 }  // namespace
@@ -539,6 +543,7 @@ extern "C" void sdy_sfno_destroy(sdy_sfno* n) {
   for (BlockW& w : n->blk) {
     DevBuf* bs[] = {&w.n0w, &w.n0b, &w.n1w, &w.n1b, &w.fw, &w.fb, &w.skw, &w.skb, &w.w1, &w.b1, &w.w2, &w.b2};
     for (DevBuf* b : bs) dev_free(*b);
+    if (w.mlp) (void)hipFree(w.mlp);
   }
   delete n;
 }
@@ -627,12 +632,25 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
     if (rest == "filter.filter.bias") { EXPECT_NUMEL(E); return dev_upload(w.fb, host, numel); }
     if (rest == "inner_skip.weight") { EXPECT_NUMEL((size_t)E * E); return dev_upload_conv(w.skw, host, E, E, E, h3); }
     if (rest == "inner_skip.bias") { EXPECT_NUMEL(E); return dev_upload(w.skb, host, numel); }
-    if (rest == "mlp.fwd.0.weight") { EXPECT_NUMEL((size_t)H * E); return dev_upload_conv(w.w1, host, H, E, H, h3); }
+    // fused MLP stream: (re)packed whenever both fc weights are known
+    auto pack_mlp = [&]() -> int {
+      if (!h3 || !sdy_mlp_h3_supported(E, H) || w.w1_host.empty() || w.w2_host.empty()) return SDY_OK;
+      if (!w.mlp) SDY_HIP_TRY(hipMalloc(&w.mlp, sdy_mlp_h3_pack_bytes(E, H)));
+      return sdy_mlp_h3_pack(w.w1_host.data(), w.w2_host.data(), E, H, w.mlp, &w.mlp_s1, &w.mlp_s2);
+    };
+    if (rest == "mlp.fwd.0.weight") {
+      EXPECT_NUMEL((size_t)H * E);
+      SDY_TRY(dev_upload_conv(w.w1, host, H, E, H, h3));
+      if (h3 && sdy_mlp_h3_supported(E, H)) { w.w1_host.assign(host, host + numel); SDY_TRY(pack_mlp()); }
+      return SDY_OK;
+    }
     if (rest == "mlp.fwd.0.bias") { EXPECT_NUMEL(H); return dev_upload(w.b1, host, numel); }
     // layers.py:76-80: fc2 is index 3 of the Sequential when dropout > 0, else index 2
     if (rest == "mlp.fwd.2.weight" || rest == "mlp.fwd.3.weight") {
       EXPECT_NUMEL((size_t)E * H);
-      return dev_upload_conv(w.w2, host, E, H, E, h3);
+      SDY_TRY(dev_upload_conv(w.w2, host, E, H, E, h3));
+      if (h3 && sdy_mlp_h3_supported(E, H)) { w.w2_host.assign(host, host + numel); SDY_TRY(pack_mlp()); }
+      return SDY_OK;
     }
     if (rest == "mlp.fwd.2.bias" || rest == "mlp.fwd.3.bias") { EXPECT_NUMEL(E); return dev_upload(w.b2, host, numel); }
   }
@@ -801,21 +819,36 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     SDY_TRY(sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca, cd, stream));
     // MLP (layers.py:73-80): fc1 + GELU + dropout
     const float pm = (drop && c.dropout_mlp > 0.f) ? c.dropout_mlp : 0.f;
-    conv_reset();
-    cv.x = y; cv.x_bstride = (long)E * HW; use_w(bw.w1); cv.ldw = Hd; cv.out = hid; cv.out_bstride = (long)Hd * HW;
-    cv.Cin = E; cv.Cout = Hd; cv.pa = ca; cv.pd = cd; cv.bias = bw.b1.p; cv.act = 1; cv.kernel_tag = 1;
-    cv.drop_p = pm; cv.stream_id = 2u * i; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i] : nullptr;
-    SDY_TRY(sdy_conv1x1(&cv, stream));
-    // fc2 + dropout, DropPath, + residual (sfnonet.py:325-335)
     float* dst = (i == L - 1) ? cat : nxt;
     const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;
-    conv_reset();
-    cv.x = hid; cv.x_bstride = (long)Hd * HW; use_w(bw.w2); cv.ldw = E; cv.out = dst; cv.out_bstride = dst_bs;
-    cv.Cin = Hd; cv.Cout = E; cv.bias = bw.b2.p; cv.kernel_tag = 2;
-    cv.drop_p = pm; cv.stream_id = 2u * i + 1u; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i + 1] : nullptr;
-    if (drop && n->tm.dp_rate[i] > 0.f) cv.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
-    cv.add = xn; cv.add_bstride = (long)E * HW; cv.add_mode = 2;
-    SDY_TRY(sdy_conv1x1(&cv, stream));
+    static const bool no_fused = std::getenv("SDY_NO_FUSED_MLP") != nullptr;
+    if (bw.mlp && !no_fused && !(pm > 0.f && a->keep_masks)) {
+      // fc1 + GELU + dropout + fc2 + dropout + DropPath + residual in one launch: the hidden activation stays on the CU
+      sdy_mlp_args ma;
+      std::memset(&ma, 0, sizeof(ma));
+      ma.x = y; ma.x_bstride = (long)E * HW; ma.pa = ca; ma.pd = cd;
+      ma.w = bw.mlp; ma.w1_scale = bw.mlp_s1; ma.w2_scale = bw.mlp_s2; ma.b1 = bw.b1.p; ma.b2 = bw.b2.p;
+      ma.out = dst; ma.out_bstride = dst_bs; ma.add = xn; ma.add_bstride = (long)E * HW;
+      ma.B = B; ma.E = E; ma.hidden = Hd; ma.HW = HW;
+      ma.drop_p = pm; ma.seed = a->seed; ma.call = a->call; ma.stream_fc1 = 2u * i; ma.stream_fc2 = 2u * i + 1u;
+      ma.batch_offset = a->batch_offset;
+      if (drop && n->tm.dp_rate[i] > 0.f) ma.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
+      SDY_TRY(sdy_mlp_h3(&ma, stream));
+    } else {
+      conv_reset();
+      cv.x = y; cv.x_bstride = (long)E * HW; use_w(bw.w1); cv.ldw = Hd; cv.out = hid; cv.out_bstride = (long)Hd * HW;
+      cv.Cin = E; cv.Cout = Hd; cv.pa = ca; cv.pd = cd; cv.bias = bw.b1.p; cv.act = 1; cv.kernel_tag = 1;
+      cv.drop_p = pm; cv.stream_id = 2u * i; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i] : nullptr;
+      SDY_TRY(sdy_conv1x1(&cv, stream));
+      // fc2 + dropout, DropPath, + residual (sfnonet.py:325-335)
+      conv_reset();
+      cv.x = hid; cv.x_bstride = (long)Hd * HW; use_w(bw.w2); cv.ldw = E; cv.out = dst; cv.out_bstride = dst_bs;
+      cv.Cin = Hd; cv.Cout = E; cv.bias = bw.b2.p; cv.kernel_tag = 2;
+      cv.drop_p = pm; cv.stream_id = 2u * i + 1u; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i + 1] : nullptr;
+      if (drop && n->tm.dp_rate[i] > 0.f) cv.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
+      cv.add = xn; cv.add_bstride = (long)E * HW; cv.add_mode = 2;
+      SDY_TRY(sdy_conv1x1(&cv, stream));
+    }
     cur = dst;
     nxt = (dst == xa) ? xb : xa;
   }

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <type_traits>
 
 #include "common.h"
 
@@ -42,9 +43,9 @@ constexpr int HC = 128;        // hidden channels per chunk
 constexpr int NCH = MH / HC;   // chunks
 constexpr int KS1 = ME / 16;   // k-steps of fc1
 constexpr int KSC = HC / 16;   // k-steps of fc2 per chunk
-constexpr int GPC = KS1 + 2 * KSC;      // weight groups per chunk per wave (16 fc1 + 16 fc2)
-constexpr int RING = 16;                // groups in flight; GPC % RING == 0, so slot = position % RING (compile time)
-constexpr int NGROUPS = NCH * GPC;      // 128
+constexpr int RING = 16;                // groups in flight = groups per block (16 fc1 k-steps, 8 x 2 fc2 groups)
+constexpr int NGROUPS = NCH * 2 * RING;      // 128
+static_assert(KS1 == RING && 2 * KSC == RING, "ring slot = index inside a block");
 constexpr float SX = 16.0f;    // activation pre-scale (keeps lo parts out of the fp16 subnormals)
 constexpr int GROUP_F8 = 2 * 64;        // f16x8 elements per group (hi fragment, lo fragment)
 
@@ -60,6 +61,7 @@ struct MlpParams {
   uint32_t drop_thr; float drop_scale;
   uint32_t seed_lo, seed_hi, stream1, stream2, call, batch_offset;
   const float* batch_scale;
+  int dbg;                                 // timing experiments only (SDY_MLP_DBG): bit 0 = weight stream pinned to one block
 };
 
 // 4-bit slot swizzle of pixel row px: injective on each ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}
@@ -70,6 +72,9 @@ __device__ __forceinline__ int xs_off(int px, int c) { return px * ME + (((c & 1
 // hidden chunk: rows of 128 k = 256 B (one bank row); chunk c (0..15)
 __device__ __forceinline__ int hs_off(int px, int c) { return px * HC + (((c ^ px_swz(px)) & 15) << 3); }
 
+// DROP: dropout on (compile time: a runtime test would split every chain piece into basic blocks and the scheduler
+// interleaves VALU with MFMAs only inside one block)
+template <bool DROP>
 __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 64 KB x tile + 2 x 32 KB hidden chunk
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
@@ -90,7 +95,9 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     r_hi[s] = wp[s * GROUP_F8];
     r_lo[s] = wp[s * GROUP_F8 + 64];
   }
-  wp += RING * GROUP_F8;   // from here on wp[i * GROUP_F8] is the group RING positions after position i of the chunk
+  const int wstep = (p.dbg & 1) ? 0 : RING * GROUP_F8;
+  const int gstr = (p.dbg & 2) ? 0 : GROUP_F8;
+  wp += wstep;   // from here on wp[i * GROUP_F8] is group i of the block AFTER the one being consumed
 
   // ---- phase 0: x tile -> LDS (fp16 hi / lo, [px][k])
   {
@@ -163,108 +170,213 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   const bool e_ok = full || e_col < p.HW;
   const long e_off = e_ok ? e_col : 0;
 
-  const bool do_drop = p.drop_thr != 0u;
+  constexpr bool do_drop = DROP;
   const uint32_t c1_base = (uint32_t)(((uint64_t)(z + p.batch_offset) * (uint64_t)(MH >> 2)) & 0xFFFFFFFFu);
 
-  for (int hc = 0; hc < NCH; ++hc) {
-    // ---- fc1 of this chunk: hidden rows 128 hc + 32 wave .. +32
-    // (its bias is requested first: a load issued after the ring refills could only be waited for by draining the ring)
-    const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
-    f32x4 bv[4];
+  // The chunk pipeline (MFMA work of one chunk overlaps the VALU work of the next):
+  //     fc1(0) | chain(0) | B | fc1(1) | { chain(1) || fc2(0) } | B | fc1(2) | { chain(2) || fc2(1) } | B | fc1(3) |
+  //     { chain(3) || fc2(2) } | B | fc2(3)            (B = barrier; chain(c) writes hidden buffer c & 1, fc2(c) reads it)
+  // The weight stream is packed in exactly this block order, 16 groups per block, so ring slot = index in the block.
+  f32x16 acc[2];
+  f32x4 bv[4];
+  auto load_bias = [&](int hc) {   // requested before the block's ring refills (see fc1)
+    const int row0 = HC * hc + 32 * wave + 4 * h;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) bv[g4] = *reinterpret_cast<const f32x4*>(p.b1 + row0 + 8 * g4);
-    f32x16 acc[2];
+  };
+  // fc1 of chunk hc: hidden rows 128 hc + 32 wave .. +32 (1 x 2 tiles), K = 256 from the x tile.  The B fragments of
+  // k-step ks + 1 are read from LDS while the MFMAs of k-step ks run (two register sets).
+  auto fc1 = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) {
-      f16x8 bh[2], bl[2];
+    f16x8 bh[2][2], bl[2][2];
+    auto ldb = [&](int set, int ks) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int off = xs_off(32 * j + l31, 2 * ks + h);
-        bh[j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
-        bl[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
+        bh[set][j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
+        bl[set][j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
       }
+    };
+    ldb(0, 0);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[ks % RING], bh[j], acc[j], 0, 0, 0);
+    for (int ks = 0; ks < KS1; ++ks) {
+      const int c = ks & 1;
+      if (ks + 1 < KS1) ldb(c ^ 1, ks + 1);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks % RING], bl[j], acc[j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[ks], bh[c][j], acc[j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks % RING], bh[j], acc[j], 0, 0, 0);
-      r_hi[ks % RING] = wp[ks * GROUP_F8];
-      r_lo[ks % RING] = wp[ks * GROUP_F8 + 64];
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks], bl[c][j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks], bh[c][j], acc[j], 0, 0, 0);
+      r_hi[ks] = wp[ks * gstr];
+      r_lo[ks] = wp[ks * gstr + 64];
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next k-step's LDS reads first
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // then the MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // then the ring refill
       __builtin_amdgcn_sched_barrier(0);   // keep the refill here: the scheduler otherwise sinks it next to its use
     }
-    // ---- chain: bias + GELU + dropout, x16, split -> LDS hidden chunk [px][k]
-    _Float16* Hh = Hs + (hc & 1) * (2 * TN * HC);
-    _Float16* Hl = Hh + TN * HC;
-    {
+    wp += wstep;
+  };
+  // One eighth of chain(hc): 4 accumulator values (tile j, row group g4): bias + exact-erf GELU (same arithmetic as
+  // gelu_erf in common.h) + Philox dropout, x16, fp16 hi/lo split -> LDS.  Cut into 12 stages of a few VALU instructions
+  // each, so that fc2 can issue ONE stage after EACH of the 12 MFMAs of a k-step: an MFMA holds the matrix pipe for 32
+  // cycles but the issue port for 4, and the stage runs in that shadow.  (Left to itself the scheduler puts the whole
+  // piece after the MFMAs; sched_group_barrier hints were honoured for the first k-step only.)
+  struct Piece {
+    float v[4], t[4], e[4], q[4];
+    uint32_t c0, c1, c2, c3, k0, k1;
+  };
+  auto chain_stage = [&](Piece& s, int st, int hc, int j, int g4) {
+    const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
+    const int px = 32 * j + l31;
+    if (do_drop && st < 10) {
+      if (st == 0) {
+        s.c0 = (uint32_t)(n0 + px); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = p.call;
+        s.k0 = p.seed_lo; s.k1 = p.seed_hi;
+      }
+      const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0, p1 = (uint64_t)0xCD9E8D57u * s.c2;   // one Philox4x32 round
+      const uint32_t m0 = (uint32_t)(p1 >> 32) ^ s.c1 ^ s.k0, m2 = (uint32_t)(p0 >> 32) ^ s.c3 ^ s.k1;
+      s.c0 = m0; s.c1 = (uint32_t)p1; s.c2 = m2; s.c3 = (uint32_t)p0;
+      s.k0 += 0x9E3779B9u; s.k1 += 0xBB67AE85u;
+    }
+    switch (st) {
+      case 0:
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int px = 32 * j + l31;
-        const int gn = n0 + px;
+        for (int r = 0; r < 4; ++r) s.v[r] = acc[j][4 * g4 + r] * p.s1 + bv[g4][r];
+        break;
+      case 1:
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-          if (do_drop) {
-            const philox4 w = philox4x32_10((uint32_t)gn, c1_base + (uint32_t)((row0 + 8 * g4) >> 2), p.stream1, p.call,
-                                            p.seed_lo, p.seed_hi);
-            words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
-          }
-          f16x4 vh, vl;
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            float v = acc[j][4 * g4 + r4] * p.s1 + bv[g4][r4];
-            v = gelu_erf(v);
-            if (do_drop) v = (words[r4] >= p.drop_thr) ? v * p.drop_scale : 0.0f;
-            v *= SX;
-            const _Float16 hv = (_Float16)v;
-            vh[r4] = hv;
-            vl[r4] = (_Float16)(v - (float)hv);
-          }
-          // local k of these 4 values: 32 wave + 8 g4 + 4 h .. +3  ->  16-byte chunk 4 wave + g4, half h
-          const int off = hs_off(px, 4 * wave + g4) + 4 * h;
-          *reinterpret_cast<f16x4*>(Hh + off) = vh;
-          *reinterpret_cast<f16x4*>(Hl + off) = vl;
+        for (int r = 0; r < 4; ++r) {
+          const float zz = fabsf(s.v[r]) * 0.70710678118654752440f;
+          s.t[r] = fmaf(0.3275911f, zz, 1.0f);
+          s.e[r] = -zz * zz * 1.44269504088896340736f;
         }
+        break;
+      case 2: s.t[0] = __builtin_amdgcn_rcpf(s.t[0]); s.t[1] = __builtin_amdgcn_rcpf(s.t[1]); break;
+      case 3: s.t[2] = __builtin_amdgcn_rcpf(s.t[2]); s.t[3] = __builtin_amdgcn_rcpf(s.t[3]); break;
+      case 4: s.e[0] = __builtin_amdgcn_exp2f(s.e[0]); s.e[1] = __builtin_amdgcn_exp2f(s.e[1]); break;
+      case 5: s.e[2] = __builtin_amdgcn_exp2f(s.e[2]); s.e[3] = __builtin_amdgcn_exp2f(s.e[3]); break;
+      case 6:
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.q[r] = fmaf(fmaf(1.061405429f, s.t[r], -1.453152027f), s.t[r], 1.421413741f);
+        break;
+      case 7:
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.q[r] = fmaf(fmaf(s.q[r], s.t[r], -0.284496736f), s.t[r], 0.254829592f);
+        break;
+      case 8:
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.q[r] = 0.5f * (s.q[r] * s.t[r] * s.e[r]);   // erfc(z) / 2
+        break;
+      case 9:
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.v[r] = s.v[r] >= 0.0f ? s.v[r] * (1.0f - s.q[r]) : s.v[r] * s.q[r];
+        break;
+      case 10: {
+        const uint32_t words[4] = {s.c0, s.c1, s.c2, s.c3};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s.v[r];
+          if (do_drop) v = (words[r] >= p.drop_thr) ? v * p.drop_scale : 0.0f;
+          s.v[r] = v * SX;
+        }
+        break;
+      }
+      default: {
+        _Float16* Hh = Hs + (hc & 1) * (2 * TN * HC);
+        _Float16* Hl = Hh + TN * HC;
+        f16x4 vh, vl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const _Float16 hv = (_Float16)s.v[r];
+          vh[r] = hv;
+          vl[r] = (_Float16)(s.v[r] - (float)hv);
+        }
+        // local k of these 4 values: 32 wave + 8 g4 + 4 h .. +3  ->  16-byte chunk 4 wave + g4, half h
+        const int off = hs_off(px, 4 * wave + g4) + 4 * h;
+        *reinterpret_cast<f16x4*>(Hh + off) = vh;
+        *reinterpret_cast<f16x4*>(Hl + off) = vl;
       }
     }
-    __syncthreads();   // the only barrier per chunk (the other hidden buffer is rewritten one barrier later)
-    if (hc == NCH - 1 && p.add) {
-      // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested one fc2 phase
-      // ahead of their use; older than every later ring refill, so waiting for them does not drain the ring
-      const float* ag = p.add + (long)z * p.add_bs + (long)(tid >> 4) * p.HW + e_off;
+  };
+  auto chain_piece = [&](int hc, int j, int g4) {
+    Piece s;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) rres[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
-    }
-    // ---- fc2 partial: output rows 64 wave .. +64 += W2[:, chunk] . hidden chunk
-#pragma unroll
-    for (int t = 0; t < KSC; ++t) {
-      f16x8 bh[2], bl[2];
+    for (int st = 0; st < 12; ++st) chain_stage(s, st, hc, j, g4);
+  };
+  // fc2 of chunk hc2 (output rows 64 wave .. +64 += W2[:, chunk] . hidden chunk from LDS), optionally with the chain
+  // of chunk hc2 + 1 interleaved: k-step t carries piece t, one stage per MFMA, each (MFMA, stage) pair fenced
+  auto fc2 = [&](int hc2, auto with_chain) {
+    constexpr bool CHAIN = decltype(with_chain)::value;
+    const _Float16* Hh = Hs + (hc2 & 1) * (2 * TN * HC);
+    const _Float16* Hl = Hh + TN * HC;
+    f16x8 bh[2][2], bl[2][2];
+    auto ldb = [&](int set, int t) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int off = hs_off(32 * j + l31, 2 * t + h);
-        bh[j] = *reinterpret_cast<const f16x8*>(Hh + off);
-        bl[j] = *reinterpret_cast<const f16x8*>(Hl + off);
+        bh[set][j] = *reinterpret_cast<const f16x8*>(Hh + off);
+        bl[set][j] = *reinterpret_cast<const f16x8*>(Hl + off);
       }
+    };
+    ldb(0, 0);
+#pragma unroll
+    for (int t = 0; t < KSC; ++t) {
+      const int c = t & 1;
+      if (t + 1 < KSC) ldb(c ^ 1, t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      Piece ps;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        const int pos = KS1 + 2 * t + mi, s = pos % RING;
+        const int s = 2 * t + mi;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], oacc[mi][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], oacc[mi][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], oacc[mi][j], 0, 0, 0);
-        r_hi[s] = wp[pos * GROUP_F8];
-        r_lo[s] = wp[pos * GROUP_F8 + 64];
+        for (int k = 0; k < 6; ++k) {
+          const int j = k & 1;
+          const f16x8 a = (k < 2) ? r_lo[s] : r_hi[s];
+          const f16x8 b = (k >= 2 && k < 4) ? bl[c][j] : bh[c][j];
+          oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, oacc[mi][j], 0, 0, 0);
+          if constexpr (CHAIN) {
+            chain_stage(ps, 6 * mi + k, hc2 + 1, t >> 2, t & 3);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        r_hi[s] = wp[s * gstr];
+        r_lo[s] = wp[s * gstr + 64];
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    wp += GPC * GROUP_F8;
+    wp += wstep;
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  load_bias(0);
+  fc1();
+#pragma unroll
+  for (int pc = 0; pc < 8; ++pc) chain_piece(0, pc >> 2, pc & 3);
+  __syncthreads();
+  load_bias(1);
+  fc1();
+#pragma unroll 1
+  for (int hc = 1; hc < NCH; ++hc) {
+    fc2(hc - 1, T_{});          // || chain(hc)
+    __syncthreads();
+    if (hc < NCH - 1) {
+      load_bias(hc + 1);
+      fc1();
+    }
   }
+  if (p.add) {
+    // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested one fc2 phase
+    // ahead of their use; older than every later ring refill, so waiting for them does not drain the ring
+    const float* ag = p.add + (long)z * p.add_bs + (long)(tid >> 4) * p.HW + e_off;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rres[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+  }
+  fc2(NCH - 1, F_{});
 
   // ---- epilogue: bias, dropout, drop-path scale in accumulator layout -> LDS [256 rows][64 px] (the x tile's storage:
   //      every wave passed the last chunk's barrier after its final x read), then residual add + 16-byte row stores
@@ -351,11 +463,21 @@ extern "C" int sdy_mlp_h3_pack(const float* w1_host, const float* w2_host, int E
   std::vector<_Float16> buf((size_t)4 * (NGROUPS + RING) * gh, (_Float16)0.0f);
   for (int w = 0; w < 4; ++w) {
     _Float16* d = buf.data() + (size_t)w * (NGROUPS + RING) * gh;
-    for (int hc = 0; hc < NCH; ++hc) {
-      for (int ks = 0; ks < KS1; ++ks, d += gh) put_group(d, w1_host, ME, 4 * hc + w, ks, s1);   // hidden rows 128hc+32w
+    auto put_fc1 = [&](int hc) {   // hidden rows 128 hc + 32 w .. +32, all of K = E
+      for (int ks = 0; ks < KS1; ++ks, d += gh) put_group(d, w1_host, ME, 4 * hc + w, ks, s1);
+    };
+    auto put_fc2 = [&](int hc) {   // output rows 64 w .. +64, K = hidden chunk hc
       for (int t = 0; t < KSC; ++t)
         for (int mi = 0; mi < 2; ++mi, d += gh) put_group(d, w2_host, MH, 2 * w + mi, KSC * hc + t, s2);
+    };
+    // block order of the kernel's chunk pipeline
+    put_fc1(0);
+    put_fc1(1);
+    for (int hc = 1; hc < NCH; ++hc) {
+      put_fc2(hc - 1);
+      if (hc < NCH - 1) put_fc1(hc + 1);
     }
+    put_fc2(NCH - 1);
   }
   SDY_HIP_TRY(hipMemcpy(packed_dev, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   *scale1 = s1;
@@ -387,14 +509,20 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   p.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFu); p.seed_hi = (uint32_t)(a->seed >> 32);
   p.stream1 = a->stream_fc1; p.stream2 = a->stream_fc2; p.call = a->call; p.batch_offset = a->batch_offset;
   p.batch_scale = a->batch_scale;
+  { const char* e = std::getenv("SDY_MLP_DBG"); p.dbg = e ? std::atoi(e) : 0; }
   dim3 grid((a->HW + TN - 1) / TN, a->B);
   constexpr size_t smem = (size_t)(2 * TN * ME + 4 * TN * HC) * sizeof(_Float16);
   static bool attr_done = false;
   if (!attr_done) {
-    SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)smem));
+    SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL(mlp_h3_kernel, grid, dim3(256), smem, (hipStream_t)stream, p);
+  if (p.drop_thr != 0u)
+    hipLaunchKernelGGL(mlp_h3_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(mlp_h3_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, p);
   return sdy_launch_status();
 }
