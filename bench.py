@@ -32,6 +32,7 @@ NLAT, NLON = 180, 360
 EMBED, LAYERS = 256, 8
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: BF16/FP16 MFMA dense peak
+MLP_TRAFFIC_B25 = 5.656e9   # bytes per launch, PMC passes at B = 25 (profiles/r1f/pmc_traffic_mlp.txt)
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E peak (6.3 TB/s measured with a float4 copy)
 
 
@@ -69,8 +70,9 @@ def one_pass(exp, x0, forcings):
 
 
 def roofline_probe(device, B, reps=5):
-    """Dominant kernel = the MLP fc1 GEMM (gemm_f32_kernel<2,2,false,false,1>): 256 -> 512 channels over B*HW pixels.
-    Algorithmic flops per launch = 2*E*hid*HW*B (DESIGN.md 'Kernels').  Timed with HIP events on the launch stream."""
+    """Dominant kernel, timed with HIP events on the launch stream.
+    gemm_mode h3 (default): the fused MLP kernel `mlp_h3_kernel` (fc1 256->512 + GELU + fc2 512->256 in one launch).
+    gemm_mode f32: the fp32-MFMA fc1 GEMM.  Algorithmic flops / bytes per launch: DESIGN.md 'Kernels'."""
     import torch
 
     import sdy_amd
@@ -81,40 +83,49 @@ def roofline_probe(device, B, reps=5):
     bias = torch.randn(hid, device=device) * 0.1
     pa = torch.rand(B, EMBED, device=device) + 0.5
     pd = torch.randn(B, EMBED, device=device) * 0.1
-    wt = w.t().contiguous()
-    out = torch.empty(B, hid, NLAT, NLON, device=device)
-    kw = dict(pre_affine=(pa, pd), gelu=True, kernel_tag=1, out=out, wt_prepared=wt)
     h3 = os.environ.get("SDY_GEMM_MODE", "h3") == "h3"
     if h3:
-        kw["h3_prepared"] = sdy_amd.ops.pack_h3(w, device)
-    sdy_amd.ops.conv1x1(x, w, bias, **kw)
+        w2 = torch.randn(EMBED, hid, device=device) / 22.0
+        b2 = torch.randn(EMBED, device=device) * 0.1
+        res = torch.randn(B, EMBED, NLAT, NLON, device=device)
+        out = torch.empty_like(x)
+        prep = sdy_amd.ops.pack_mlp_h3(w, w2, device)
+        run = lambda: sdy_amd.ops.mlp_fused(x, w, bias, w2, b2, pre_affine=(pa, pd), add=res, out=out, prepared=prep)
+    else:
+        wt = w.t().contiguous()
+        out = torch.empty(B, hid, NLAT, NLON, device=device)
+        kw = dict(pre_affine=(pa, pd), gelu=True, kernel_tag=1, out=out, wt_prepared=wt)
+        run = lambda: sdy_amd.ops.conv1x1(x, w, bias, **kw)
+    run()
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        sdy_amd.ops.conv1x1(x, w, bias, **kw)
+        run()
     e1.record()
     torch.cuda.synchronize(device)
     ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * EMBED * hid * HW * B
-    achieved = flops / (ms * 1e-3) / 1e12
     if not h3:
+        flops = 2.0 * EMBED * hid * HW * B
+        achieved = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                 "kernel": "gemm_f32_kernel<2,2,false,false,1>, MLP fc1 256->512, B=%d" % B,
                 "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
-    # Split-precision path: 3 f16 MFMA passes put the machine balance at (2500/3 TF) / 8 TB/s = 104 flop/B; the unfused fc1
-    # has 2*256*512 / (3*256*4) = 85 flop/B, so its roofline is HBM.  Algorithmic bytes per launch: read x (1 tensor of
-    # B*256*HW fp32) + write hidden (2 tensors).  `traffic` = FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 PMC passes
-    # of this kernel at B = 25 (profiles/r1d/pmc_traffic.txt); it equals the algorithmic bytes within 3 %.
+    # Fused MLP: algorithmic flops 2 * 2*E*hid per pixel, algorithmic bytes 3 tensors of B*E*HW fp32 (x, residual, out):
+    # 170 flop/B.  Split precision issues 3 f16 MFMA passes, so the machine balance is (2500/3 TF) / 8 TB/s = 104 flop/B:
+    # the kernel is matrix-bound.  `achieved` counts the algorithmic flops ONCE against the dense f16 peak (the 3-pass
+    # ceiling is peak / 3).  `traffic`: FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 PMC passes at B = 25
+    # (profiles/r1f/pmc_traffic_mlp.txt).
+    flops = 4.0 * EMBED * hid * HW * B
     alg_bytes = 3.0 * B * EMBED * HW * 4
-    gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": 5.032e9 if B == 25 else None,
-            "kernel": "gemm_h3_kernel<2,2,0,1> (3-pass split-f16 MFMA), MLP fc1 256->512, B=%d" % B,
-            "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": flops,
-            "mfma_view": {"achieved_tflops": round(achieved, 2), "peak_tflops": PEAK_F16_MFMA_TFLOPS,
-                          "note": "algorithmic flops counted once; the kernel issues 3 f16 MFMA passes (ceiling peak/3)"}}
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": MLP_TRAFFIC_B25 if B == 25 else None,
+            "kernel": "mlp_h3_kernel<false> (fused MLP 256->512->256, 3-pass split-f16 MFMA), B=%d" % B,
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+            "three_pass_ceiling_frac": round(3.0 * achieved / PEAK_F16_MFMA_TFLOPS, 4),
+            "hbm_view": {"achieved_gbs": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak_gbs": PEAK_HBM_GBS}}
 
 
 def cpu_baseline(fora, fcfg):
