@@ -79,6 +79,10 @@ struct sdy_sht_plan {
   void* d_pct_h3 = nullptr;  // synthesis: rows = latitude, k = l
   float s_wq = 1.f, s_pct = 1.f;
   int h3_rows_fwd = 0, h3_k_fwd = 0, h3_rows_inv = 0, h3_k_inv = 0;
+  // grids with nlat, lmax <= 192: fragment-stream tables of the skinny Legendre kernel (leg_h3.hip)
+  void* d_wq_frag = nullptr;
+  void* d_pct_frag = nullptr;
+  float s_wq_frag = 1.f, s_pct_frag = 1.f;
 };
 
 static int env_gemm_mode() {
@@ -163,6 +167,23 @@ extern "C" int sdy_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, in
     if (e == hipSuccess) e = hipMemcpy(p->d_pct_h3, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     if (e != hipSuccess) { sdy_sht_plan_destroy(p); return (int)e; }
   }
+  if (gemm_mode == 1 && sdy_leg_h3_supported(lmax, nlat) && sdy_leg_h3_supported(nlat, lmax)) {
+    struct Ctx { const float* t; int nlat, lmax, Lpad4, Kpad4; } cx{nullptr, nlat, lmax, p->Lpad4, p->Kpad4};
+    e = hipMalloc(&p->d_wq_frag, sdy_leg_h3_table_bytes(mtr));
+    if (e == hipSuccess) e = hipMalloc(&p->d_pct_frag, sdy_leg_h3_table_bytes(mtr));
+    if (e != hipSuccess) { sdy_sht_plan_destroy(p); return (int)e; }
+    cx.t = wqT.data();
+    r = sdy_leg_h3_pack(mtr, lmax, nlat, [](void* c, int m, int l, int k) {
+      const Ctx* x = static_cast<const Ctx*>(c);
+      return x->t[((size_t)m * x->nlat + k) * x->Lpad4 + l];
+    }, &cx, p->d_wq_frag, &p->s_wq_frag);
+    cx.t = pf.data();
+    if (r == SDY_OK) r = sdy_leg_h3_pack(mtr, nlat, lmax, [](void* c, int m, int k, int l) {
+      const Ctx* x = static_cast<const Ctx*>(c);
+      return x->t[((size_t)m * x->lmax + l) * x->Kpad4 + k];
+    }, &cx, p->d_pct_frag, &p->s_pct_frag);
+    if (r != SDY_OK) { sdy_sht_plan_destroy(p); return r; }
+  }
   p->fft.tw = p->d_tw;
   p->fft.pw = p->d_pw;
   *out = p;
@@ -177,6 +198,8 @@ extern "C" void sdy_sht_plan_destroy(sdy_sht_plan* p) {
   if (p->d_pw) (void)hipFree(p->d_pw);
   if (p->d_wq_h3) (void)hipFree(p->d_wq_h3);
   if (p->d_pct_h3) (void)hipFree(p->d_pct_h3);
+  if (p->d_wq_frag) (void)hipFree(p->d_wq_frag);
+  if (p->d_pct_frag) (void)hipFree(p->d_pct_frag);
   delete p;
 }
 
@@ -217,6 +240,10 @@ extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* C
   g.C = Cs; g.ldc = p->mtr * N; g.sC = N;
   g.M = p->Lpad4; g.M_store = p->lmax; g.N = N; g.K = p->nlat; g.nbatch = p->mtr;
   g.tri_mode = SDY_TRI_LEG_FWD; g.tile = SDY_TILE_64x128;
+  static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
+  if (p->d_wq_frag && !no_frag)
+    return sdy_leg_h3_launch(p->d_wq_frag, p->s_wq_frag, p->mtr, Xf, N, (long)p->nlat * N, Cs, (long)p->mtr * N, N, p->lmax,
+                             p->nlat, N, SDY_TRI_LEG_FWD, (hipStream_t)stream);
   if (p->gemm_mode == 1)
     return sdy_gemm_h3_launch(g, p->d_wq_h3, p->h3_rows_fwd, p->h3_k_fwd, (long)p->h3_rows_fwd * p->h3_k_fwd,
                               (long)p->mtr * p->h3_rows_fwd * p->h3_k_fwd, p->s_wq, 0, (hipStream_t)stream);
@@ -233,6 +260,10 @@ extern "C" int sdy_legendre_inv(const sdy_sht_plan* p, const float* Cs, float* Y
   g.C = Yf; g.ldc = N; g.sC = (long)p->nlat * N;
   g.M = p->Kpad4; g.M_store = p->nlat; g.N = N; g.K = p->lmax; g.nbatch = p->mtr;
   g.tri_mode = SDY_TRI_LEG_INV; g.tile = SDY_TILE_64x128;
+  static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
+  if (p->d_pct_frag && !no_frag)
+    return sdy_leg_h3_launch(p->d_pct_frag, p->s_pct_frag, p->mtr, Cs, (long)p->mtr * N, N, Yf, N, (long)p->nlat * N, p->nlat,
+                             p->lmax, N, SDY_TRI_LEG_INV, (hipStream_t)stream);
   if (p->gemm_mode == 1)
     return sdy_gemm_h3_launch(g, p->d_pct_h3, p->h3_rows_inv, p->h3_k_inv, (long)p->h3_rows_inv * p->h3_k_inv,
                               (long)p->mtr * p->h3_rows_inv * p->h3_k_inv, p->s_pct, 0, (hipStream_t)stream);

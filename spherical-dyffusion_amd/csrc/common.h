@@ -108,5 +108,13 @@ int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, in
 int sdy_gemm_h3_ws_launch(const GemmParams& p, const void* packed, int rows_pad, int Kpad, long plane_halfs, float w_scale,
                           hipStream_t stream);
 
+// ---- skinny Legendre GEMM with the table streamed as MFMA fragments (leg_h3.hip), rows and K <= 192
+typedef float (*sdy_leg_value_fn)(void* ctx, int z, int row, int k);
+int sdy_leg_h3_supported(int rows, int K);
+size_t sdy_leg_h3_table_bytes(int nz);
+int sdy_leg_h3_pack(int nz, int rows, int K, sdy_leg_value_fn value, void* ctx, void* dev, float* scale);
+int sdy_leg_h3_launch(const void* table, float scale, int nz, const float* X, long ldx, long sX, float* C, long ldc, long sC,
+                      int M_store, int K, int N, int tri, hipStream_t stream);
+
 // ---- host tables (tables.cpp) --------------------------------------------------------------------------
 int sdy_factor_radices(int n, int* radices, int* nstages);  // n = prod(radices), radices in {4,2,3,5}
