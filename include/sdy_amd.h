@@ -154,7 +154,8 @@ size_t sdy_h3_pack_bytes(int Cout, int Cin);
 int sdy_h3_pack_weight(const float* w_host, int Cout, int Cin, void* packed_dev, float* scale);
 
 /* Fused MLP of one SFNO block (src/models/sfno/layers.py:73-80 as called from src/models/sfno/sfnonet.py:313-335):
- *   out[b] = batch_scale[b] * dropout2( W2 . dropout1( GELU( W1 . (pa[b]*x[b] + pd[b]) + b1 ) ) + b2 ) + add[b]
+ *   out[b] = batch_scale[b] * dropout2( W2 . dropout1( GELU( W1 . (pa[b]*x[b] + pd[b]) + b1 ) ) + b2 )
+ *            + (add_a[b]*add[b] + add_d[b])
  * in ONE launch; the hidden activation stays on the compute unit (never written to HBM).  Split-fp16 arithmetic and
  * Philox stream identical to two sdy_conv1x1 calls with (stream_fc1, stream_fc2).  Supported shape: E = 256,
  * hidden = 512 (sdy_mlp_h3_supported); anything else returns SDY_ERR_UNSUPPORTED and the caller uses sdy_conv1x1. */
@@ -165,6 +166,8 @@ typedef struct sdy_mlp_args {
   const float* b1; const float* b2;                  /* dev [hidden], dev [E] */
   float* out;      long out_bstride;   /* dev (B, E, HW) */
   const float* add; long add_bstride;  /* dev (B, E, HW) residual or NULL */
+  const float* add_a; const float* add_d; /* dev [B*E] each or NULL: the residual is add_a*add + add_d (a norm folded
+                                           into its consumer instead of being materialised) */
   int B, E, hidden, HW;
   float drop_p;                        /* 0 = no dropout */
   uint64_t seed; uint32_t call; uint32_t stream_fc1; uint32_t stream_fc2; uint32_t batch_offset;

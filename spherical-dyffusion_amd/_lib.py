@@ -48,6 +48,7 @@ class SdyMlpArgs(C.Structure):
         ("b1", C.c_void_p), ("b2", C.c_void_p),
         ("out", C.c_void_p), ("out_bstride", C.c_long),
         ("add", C.c_void_p), ("add_bstride", C.c_long),
+        ("add_a", C.c_void_p), ("add_d", C.c_void_p),
         ("B", C.c_int), ("E", C.c_int), ("hidden", C.c_int), ("HW", C.c_int),
         ("drop_p", C.c_float),
         ("seed", C.c_uint64), ("call", C.c_uint32), ("stream_fc1", C.c_uint32), ("stream_fc2", C.c_uint32),

@@ -729,7 +729,7 @@ extern "C" const char* sdy_sfno_missing(const sdy_sfno* n) { return n ? n->missi
 
 namespace {
 struct WsLayout {
-  size_t cat, xa, xb, xn, y, hid, xf, cs, cs2, ca, cd, ss, dp, trep, total;
+  size_t cat, xa, xb, xn, y, hid, xf, cs, cs2, ca, cd, ca1, cd1, ss, dp, trep, total;
 };
 WsLayout ws_layout(const sdy_sfno* n, int B) {
   const sdy_sfno_config& c = n->cfg;
@@ -748,6 +748,8 @@ WsLayout ws_layout(const sdy_sfno* n, int B) {
   w.cs2 = take(cs_floats(n->plan_data, B, (int)E));
   w.ca = take((size_t)B * E);
   w.cd = take((size_t)B * E);
+  w.ca1 = take((size_t)B * E);
+  w.cd1 = take((size_t)B * E);
   w.ss = take((size_t)B * c.num_layers * 2 * E);
   w.dp = take((size_t)B * c.num_layers);
   w.trep = take((size_t)B * (c.with_time_emb ? c.time_dim : 1));
@@ -781,6 +783,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   float* ws = a->ws;
   float *cat = ws + w.cat, *xa = ws + w.xa, *xb = ws + w.xb, *xn = ws + w.xn, *y = ws + w.y, *hid = ws + w.hid;
   float *Xf = ws + w.xf, *Cs = ws + w.cs, *Cs2 = ws + w.cs2, *ca = ws + w.ca, *cd = ws + w.cd;
+  float *ca1 = ws + w.ca1, *cd1 = ws + w.cd1;
   float *ss = ws + w.ss, *dp = ws + w.dp, *trep = ws + w.trep;
 
   // ---- input concat (BaseModel.concat_condition_if_needed, _base_model.py:166-192) into the tail of the big-skip
@@ -825,11 +828,18 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     const sdy_sht_plan* pin = (i == 0) ? n->plan_data : n->plan_lg;
     const sdy_sht_plan* pout = (i == L - 1) ? n->plan_data : n->plan_lg;
     const bool scale_residual = pin != pout;  // s2convolutions.py:79-83
+    const float pm = (drop && c.dropout_mlp > 0.f) ? c.dropout_mlp : 0.f;
+    static const bool no_fused = std::getenv("SDY_NO_FUSED_MLP") != nullptr;
+    const bool fused_mlp = bw.mlp && !no_fused && !(pm > 0.f && a->keep_masks);
+    // The block's residual is norm0(x) (or its SHT round trip when the grids differ).  With the fused MLP kernel the
+    // normalised tensor is never materialised: its two consumers (inner skip, final residual add) apply a*x + d to `cur`.
+    const bool lazy_norm = fused_mlp && !scale_residual;
     // norm0 + time scale/shift folded into a*x+d (sfnonet.py:292,298-299)
     SDY_TRY(sdy_instnorm_coeffs_launch(cur, B, E, HW, bw.n0w.p, bw.n0b.p, c.with_time_emb ? ss + (size_t)i * 2 * E : nullptr,
                                        (long)L * 2 * E, 1e-6f, ca, cd, stream));
     // SpectralConvS2.forward (s2convolutions.py:158-193)
-    SDY_TRY(sdy_fft_launch_fwd(pin->fft, cur, ca, cd, scale_residual ? nullptr : xn, Xf, B, E, pin->nlat, pin->mtr, stream));
+    SDY_TRY(sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, B, E, pin->nlat,
+                               pin->mtr, stream));
     SDY_TRY(sdy_legendre_fwd(pin, Xf, Cs, B, E, stream));
     if (scale_residual) {  // residual = inverse_transform(forward_transform(x))
       SDY_TRY(sdy_legendre_inv(pout, Cs, Xf, B, E, stream));
@@ -843,23 +853,25 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
     conv_reset();
-    cv.x = xn; cv.x_bstride = (long)E * HW; use_w(bw.skw); cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
+    cv.x = lazy_norm ? cur : xn; cv.x_bstride = lazy_norm ? ((cur == cat) ? cat_bs : (long)E * HW) : (long)E * HW;
+    if (lazy_norm) { cv.pa = ca; cv.pd = cd; }
+    use_w(bw.skw); cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
     cv.Cin = E; cv.Cout = E; cv.bias = bw.skb.p; cv.add = y; cv.add_bstride = (long)E * HW; cv.add_mode = 1; cv.act = 1; cv.kernel_tag = 3;
     SDY_TRY(sdy_conv1x1(&cv, stream));
     // norm1 (sfnonet.py:313-320) folded into the fc1 prologue
-    SDY_TRY(sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca, cd, stream));
+    SDY_TRY(sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
     // MLP (layers.py:73-80): fc1 + GELU + dropout
-    const float pm = (drop && c.dropout_mlp > 0.f) ? c.dropout_mlp : 0.f;
     float* dst = (i == L - 1) ? cat : nxt;
     const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;
-    static const bool no_fused = std::getenv("SDY_NO_FUSED_MLP") != nullptr;
-    if (bw.mlp && !no_fused && !(pm > 0.f && a->keep_masks)) {
+    if (fused_mlp) {
       // fc1 + GELU + dropout + fc2 + dropout + DropPath + residual in one launch: the hidden activation stays on the CU
       sdy_mlp_args ma;
       std::memset(&ma, 0, sizeof(ma));
-      ma.x = y; ma.x_bstride = (long)E * HW; ma.pa = ca; ma.pd = cd;
+      ma.x = y; ma.x_bstride = (long)E * HW; ma.pa = ca1; ma.pd = cd1;
       ma.w = bw.mlp; ma.w1_scale = bw.mlp_s1; ma.w2_scale = bw.mlp_s2; ma.b1 = bw.b1.p; ma.b2 = bw.b2.p;
-      ma.out = dst; ma.out_bstride = dst_bs; ma.add = xn; ma.add_bstride = (long)E * HW;
+      ma.out = dst; ma.out_bstride = dst_bs;
+      if (lazy_norm) { ma.add = cur; ma.add_bstride = (long)E * HW; ma.add_a = ca; ma.add_d = cd; }
+      else { ma.add = xn; ma.add_bstride = (long)E * HW; }
       ma.B = B; ma.E = E; ma.hidden = Hd; ma.HW = HW;
       ma.drop_p = pm; ma.seed = a->seed; ma.call = a->call; ma.stream_fc1 = 2u * i; ma.stream_fc2 = 2u * i + 1u;
       ma.batch_offset = a->batch_offset;
@@ -868,7 +880,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     } else {
       conv_reset();
       cv.x = y; cv.x_bstride = (long)E * HW; use_w(bw.w1); cv.ldw = Hd; cv.out = hid; cv.out_bstride = (long)Hd * HW;
-      cv.Cin = E; cv.Cout = Hd; cv.pa = ca; cv.pd = cd; cv.bias = bw.b1.p; cv.act = 1; cv.kernel_tag = 1;
+      cv.Cin = E; cv.Cout = Hd; cv.pa = ca1; cv.pd = cd1; cv.bias = bw.b1.p; cv.act = 1; cv.kernel_tag = 1;
       cv.drop_p = pm; cv.stream_id = 2u * i; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i] : nullptr;
       SDY_TRY(sdy_conv1x1(&cv, stream));
       // fc2 + dropout, DropPath, + residual (sfnonet.py:325-335)

@@ -56,6 +56,7 @@ struct MlpParams {
   const float* b1; const float* b2;
   float* out; long out_bs;
   const float* add; long add_bs;
+  const float* add_a; const float* add_d;  // optional per-(b, row) affine of the residual: add_a * add + add_d
   int HW;
   float s1, s2;                            // accumulator scales: 1 / (w_scale * SX)
   uint32_t drop_thr; float drop_scale;
@@ -164,8 +165,9 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[mi][j][r] = 0.0f;
   f32x4 rres[16];
+  float ra[16], rd[16];   // optional affine of the residual rows
 #pragma unroll
-  for (int i = 0; i < 16; ++i) rres[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 16; ++i) { rres[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ra[i] = 1.0f; rd[i] = 0.0f; }
   const int e_col = n0 + 4 * (tid & 15);                    // store phase: first pixel of this thread's quad
   const bool e_ok = full || e_col < p.HW;
   const long e_off = e_ok ? e_col : 0;
@@ -375,6 +377,13 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     const float* ag = p.add + (long)z * p.add_bs + (long)(tid >> 4) * p.HW + e_off;
 #pragma unroll
     for (int i = 0; i < 16; ++i) rres[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+    if (p.add_a) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        ra[i] = p.add_a[(long)z * ME + (tid >> 4) + 16 * i];
+        rd[i] = p.add_d[(long)z * ME + (tid >> 4) + 16 * i];
+      }
+    }
   }
   fc2(NCH - 1, F_{});
 
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       const float* os = Os + (tid >> 4) * TN + 4 * (tid & 15);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(os + 16 * i * TN) + rres[i];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(os + 16 * i * TN) + (rres[i] * ra[i] + rd[i]);
         *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
       }
     }
@@ -489,7 +498,7 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   if (!a || !a->x || !a->w || !a->b1 || !a->b2 || !a->out) return SDY_ERR_ARG;
   if (a->B <= 0 || a->HW <= 0) return SDY_ERR_ARG;
   if (!sdy_mlp_h3_supported(a->E, a->hidden)) return SDY_ERR_UNSUPPORTED;
-  if ((a->pa == nullptr) != (a->pd == nullptr)) return SDY_ERR_ARG;
+  if ((a->pa == nullptr) != (a->pd == nullptr) || (a->add_a == nullptr) != (a->add_d == nullptr)) return SDY_ERR_ARG;
   if ((a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3) || (a->add && (a->add_bstride & 3))) return SDY_ERR_ALIGN;
   if (a->drop_p < 0.0f || a->drop_p >= 1.0f) return SDY_ERR_ARG;
   if (a->B > 65535) return SDY_ERR_UNSUPPORTED;
@@ -498,6 +507,7 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   p.w = reinterpret_cast<const f16x8*>(a->w);
   p.b1 = a->b1; p.b2 = a->b2;
   p.out = a->out; p.out_bs = a->out_bstride; p.add = a->add; p.add_bs = a->add_bstride;
+  p.add_a = a->add ? a->add_a : nullptr; p.add_d = a->add ? a->add_d : nullptr;
   p.HW = a->HW;
   p.s1 = 1.0f / (a->w1_scale * SX);
   p.s2 = 1.0f / (a->w2_scale * SX);

@@ -172,7 +172,7 @@ def mlp_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Ten
               pre_affine=None, add: Optional[torch.Tensor] = None, drop_p: float = 0.0, seed: int = 0, call: int = 0,
               stream_fc1: int = 0, stream_fc2: int = 1, batch_offset: int = 0,
               batch_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              prepared=None) -> torch.Tensor:
+              prepared=None, add_affine=None) -> torch.Tensor:
     """The block's MLP (`src/models/sfno/layers.py:73-80`) with the norm affine, both dropouts, DropPath scale and the
     residual add in one launch (include/sdy_amd.h, sdy_mlp_h3).  Same arithmetic and dropout stream as
     conv1x1(fc1, gelu, stream_fc1) -> conv1x1(fc2, stream_fc2, add_mode=2)."""
@@ -198,6 +198,10 @@ def mlp_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Ten
         ad = _aux(add, x.device)
         a.add, a.add_bstride = ptr(ad), E * H * W
         keep.append(ad)
+        if add_affine is not None:      # residual = add_affine[0][b, c] * add + add_affine[1][b, c]
+            ra, rd = _aux(add_affine[0], x.device), _aux(add_affine[1], x.device)
+            a.add_a, a.add_d = ptr(ra), ptr(rd)
+            keep += [ra, rd]
     a.B, a.E, a.hidden, a.HW = B, E, hidden, H * W
     a.drop_p = drop_p
     a.seed, a.call, a.stream_fc1, a.stream_fc2, a.batch_offset = seed, call, stream_fc1, stream_fc2, batch_offset

@@ -264,6 +264,13 @@ def test_mlp_fused_matches_fp64_and_unfused(sdy, B, H, W, drop):
     if drop > 0:   # identical masks: without residual / drop-path exactly the same elements are zero
         f0 = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2, stream_fc1=2 * layer, stream_fc2=2 * layer + 1, **kw).cpu()
         assert torch.equal(f0 == 0, k2 == 0), "fc2 dropout mask differs from the Philox oracle"
+    # residual given as an affine of another tensor (norm folded into its consumer)
+    ra, rd = 1 + 0.3 * torch.randn(B, E, generator=g), 0.3 * torch.randn(B, E, generator=g)
+    got = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2, pre_affine=(pa.cuda(), pd.cuda()), add=res.cuda(),
+                            add_affine=(ra.cuda(), rd.cuda()), stream_fc1=2 * layer, stream_fc2=2 * layer + 1,
+                            batch_scale=bs.cuda(), **kw)
+    ref_aff = o * bs.double()[:, None, None, None] + res.double() * ra.double()[:, :, None, None] + rd.double()[:, :, None, None]
+    assert rel_l2(got, ref_aff) < TOL_OP
     # no affine / no residual / no scale
     got = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2)
     ref = F.conv2d(F.gelu(F.conv2d(x.double(), w1.double(), b1.double())), w2.double(), b2.double())
