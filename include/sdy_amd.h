@@ -172,7 +172,13 @@ typedef struct sdy_mlp_args {
   float drop_p;                        /* 0 = no dropout */
   uint64_t seed; uint32_t call; uint32_t stream_fc1; uint32_t stream_fc2; uint32_t batch_offset;
   const float* batch_scale;            /* dev [B] or NULL (drop-path scale) */
+  double* stats;                       /* dev [B*E*2] or NULL: (sum, sum of squares) over HW of every output plane are
+                                          ADDED here (InstanceNorm statistics of the next block, sfnonet.py:292): zero
+                                          it before the launch, turn it into coefficients with sdy_instnorm_from_stats */
 } sdy_mlp_args;
+/* (sum, sumsq) statistics -> the same per-(b,c) affine coefficients as sdy_instnorm_coeffs; clears `stats` for reuse. */
+int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, const float* gamma, const float* beta,
+                            const float* scale_shift, long ss_bstride, float eps, float* a_out, float* d_out, void* stream);
 int sdy_mlp_h3_supported(int E, int hidden);
 size_t sdy_mlp_h3_pack_bytes(int E, int hidden);
 /* w1_host: (hidden, E) row-major = mlp.fwd.0.weight;  w2_host: (E, hidden) row-major = mlp.fwd.{2|3}.weight.

@@ -54,6 +54,7 @@ class SdyMlpArgs(C.Structure):
         ("seed", C.c_uint64), ("call", C.c_uint32), ("stream_fc1", C.c_uint32), ("stream_fc2", C.c_uint32),
         ("batch_offset", C.c_uint32),
         ("batch_scale", C.c_void_p),
+        ("stats", C.c_void_p),
     ]
 
 
@@ -133,6 +134,8 @@ SIGNATURES = {
     "sdy_instnorm_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_conv1x1": (C.c_int, [C.POINTER(SdyConvArgs), C.c_void_p]),
+    "sdy_instnorm_from_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_long, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_mlp_h3_supported": (C.c_int, [C.c_int, C.c_int]),
     "sdy_mlp_h3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sdy_mlp_h3_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float),

@@ -729,7 +729,7 @@ extern "C" const char* sdy_sfno_missing(const sdy_sfno* n) { return n ? n->missi
 
 namespace {
 struct WsLayout {
-  size_t cat, xa, xb, xn, y, hid, xf, cs, cs2, ca, cd, ca1, cd1, ss, dp, trep, total;
+  size_t cat, xa, xb, xn, y, hid, xf, cs, cs2, ca, cd, ca1, cd1, st0, ss, dp, trep, total;
 };
 WsLayout ws_layout(const sdy_sfno* n, int B) {
   const sdy_sfno_config& c = n->cfg;
@@ -750,6 +750,7 @@ WsLayout ws_layout(const sdy_sfno* n, int B) {
   w.cd = take((size_t)B * E);
   w.ca1 = take((size_t)B * E);
   w.cd1 = take((size_t)B * E);
+  w.st0 = take((size_t)B * E * 4);   // (sum, sumsq) doubles of the next block's norm0, filled by the fused MLP epilogue
   w.ss = take((size_t)B * c.num_layers * 2 * E);
   w.dp = take((size_t)B * c.num_layers);
   w.trep = take((size_t)B * (c.with_time_emb ? c.time_dim : 1));
@@ -784,6 +785,9 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   float *cat = ws + w.cat, *xa = ws + w.xa, *xb = ws + w.xb, *xn = ws + w.xn, *y = ws + w.y, *hid = ws + w.hid;
   float *Xf = ws + w.xf, *Cs = ws + w.cs, *Cs2 = ws + w.cs2, *ca = ws + w.ca, *cd = ws + w.cd;
   float *ca1 = ws + w.ca1, *cd1 = ws + w.cd1;
+  double* st0 = reinterpret_cast<double*>(ws + w.st0);   // take() rounds offsets to 64 floats: 8-byte aligned
+  bool have_st0 = false;                                  // statistics of `cur` are waiting in st0
+  SDY_HIP_TRY(hipMemsetAsync(st0, 0, (size_t)B * E * 2 * sizeof(double), stream));
   float *ss = ws + w.ss, *dp = ws + w.dp, *trep = ws + w.trep;
 
   // ---- input concat (BaseModel.concat_condition_if_needed, _base_model.py:166-192) into the tail of the big-skip
@@ -835,8 +839,13 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     // normalised tensor is never materialised: its two consumers (inner skip, final residual add) apply a*x + d to `cur`.
     const bool lazy_norm = fused_mlp && !scale_residual;
     // norm0 + time scale/shift folded into a*x+d (sfnonet.py:292,298-299)
-    SDY_TRY(sdy_instnorm_coeffs_launch(cur, B, E, HW, bw.n0w.p, bw.n0b.p, c.with_time_emb ? ss + (size_t)i * 2 * E : nullptr,
-                                       (long)L * 2 * E, 1e-6f, ca, cd, stream));
+    if (have_st0)   // statistics were accumulated by the previous block's MLP epilogue: no pass over `cur`
+      SDY_TRY(sdy_instnorm_from_stats(st0, B, E, HW, bw.n0w.p, bw.n0b.p, c.with_time_emb ? ss + (size_t)i * 2 * E : nullptr,
+                                      (long)L * 2 * E, 1e-6f, ca, cd, stream));
+    else
+      SDY_TRY(sdy_instnorm_coeffs_launch(cur, B, E, HW, bw.n0w.p, bw.n0b.p, c.with_time_emb ? ss + (size_t)i * 2 * E : nullptr,
+                                         (long)L * 2 * E, 1e-6f, ca, cd, stream));
+    have_st0 = false;
     // SpectralConvS2.forward (s2convolutions.py:158-193)
     SDY_TRY(sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, B, E, pin->nlat,
                                pin->mtr, stream));
@@ -876,6 +885,8 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       ma.drop_p = pm; ma.seed = a->seed; ma.call = a->call; ma.stream_fc1 = 2u * i; ma.stream_fc2 = 2u * i + 1u;
       ma.batch_offset = a->batch_offset;
       if (drop && n->tm.dp_rate[i] > 0.f) ma.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
+      static const bool no_stats = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
+      if (i < L - 1 && !no_stats) { ma.stats = st0; have_st0 = true; }   // the next block's norm0 statistics
       SDY_TRY(sdy_mlp_h3(&ma, stream));
     } else {
       conv_reset();

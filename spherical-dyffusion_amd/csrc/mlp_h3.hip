@@ -57,12 +57,13 @@ struct MlpParams {
   float* out; long out_bs;
   const float* add; long add_bs;
   const float* add_a; const float* add_d;  // optional per-(b, row) affine of the residual: add_a * add + add_d
-  int HW;
+  int HW, B;
   float s1, s2;                            // accumulator scales: 1 / (w_scale * SX)
   uint32_t drop_thr; float drop_scale;
   uint32_t seed_lo, seed_hi, stream1, stream2, call, batch_offset;
   const float* batch_scale;
-  int dbg;                                 // timing experiments only (SDY_MLP_DBG): bit 0 = weight stream pinned to one block
+  double* stats;                           // optional [B][ME][2]: sum and sum of squares of the stored output rows
+  unsigned long long* stamps;              // timing experiments only (SDY_MLP_STAMPS): per-phase s_memtime of one wave
 };
 
 // 4-bit slot swizzle of pixel row px: injective on each ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}
@@ -81,75 +82,100 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
   _Float16* Xs_lo = Xs_hi + TN * ME;
   _Float16* Hs = Xs_lo + TN * ME;          // [buf][hi | lo][px][HC]
+  float* Cf = reinterpret_cast<float*>(Hs + 4 * TN * HC);   // per-image coefficients: pa | pd | add_a | add_d, [4][ME]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int z = blockIdx.y;
-  const int n0 = blockIdx.x * TN;
-  const bool full = n0 + TN <= p.HW;   // workgroup-uniform
+  int h = lane >> 5, l31 = lane & 31;
+  // Persistent workgroup (one per CU): tiles t = blockIdx.x, + gridDim.x, ...; tile t = (image z, 64-pixel slice n0).
+  // The NEXT tile's pixels (and its norm coefficients) are requested into registers while this tile computes, so no
+  // tile after the first waits for HBM, and there is no workgroup launch gap between tiles.
+  const int tpi = (p.HW + TN - 1) / TN;
+  const int ntiles = tpi * p.B;
+  int z = 0, n0 = 0;
+  bool full = true;
 
-  // ---- weight ring: slot s holds group (chunk, s); refilled for the next chunk right after its use
+  // ---- weight ring: slot s holds group s of the block being consumed; refilled for the next block right after its use
   f16x8 r_hi[RING], r_lo[RING];
-  const f16x8* __restrict__ wp = p.w + (size_t)wave * (NGROUPS + RING) * GROUP_F8 + lane;
+  const f16x8* __restrict__ wbase = p.w + (size_t)wave * (NGROUPS + RING) * GROUP_F8 + lane;
+  const f16x8* __restrict__ wp = wbase;
 #pragma unroll
   for (int s = 0; s < RING; ++s) {
     r_hi[s] = wp[s * GROUP_F8];
     r_lo[s] = wp[s * GROUP_F8 + 64];
   }
-  const int wstep = (p.dbg & 1) ? 0 : RING * GROUP_F8;
-  const int gstr = (p.dbg & 2) ? 0 : GROUP_F8;
-  wp += wstep;   // from here on wp[i * GROUP_F8] is group i of the block AFTER the one being consumed
+  wp += RING * GROUP_F8;   // from here on wp[i * GROUP_F8] is group i of the block AFTER the one being consumed
 
-  // ---- phase 0: x tile -> LDS (fp16 hi / lo, [px][k])
-  {
-    const int q = tid & 15, o = tid >> 4;   // pixel quad, channel octets o and o + 16
-    // ragged last tile: clamp the address (branch-free loads keep exact vmcnt counts) and zero the values afterwards
-    const bool ok = full || (n0 + 4 * q < p.HW);
-    const float* __restrict__ xg = p.x + (long)z * p.x_bs + (ok ? n0 + 4 * q : 0);
-    f32x4 xr[2][8];
+  // ---- x tile prefetch: thread = (pixel quad q, channel octets o and o + 16)
+  int q0 = tid & 15, o0 = tid >> 4;
+  f32x4 xr[2][8];
+  auto prefetch_x = [&](int t) {
+    const int zz = t / tpi, nn = (t - zz * tpi) * TN;
+    // ragged last slice of an image: clamp the address (branch-free loads keep exact vmcnt counts), zero at conversion
+    const bool ok = nn + 4 * q0 < p.HW;
+    const float* __restrict__ xg = p.x + (long)zz * p.x_bs + (ok ? nn + 4 * q0 : 0);
 #pragma unroll
     for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int ch = 8 * (o + 16 * oc) + e;
+        const int ch = 8 * (o0 + 16 * oc) + e;
         xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)ch * p.HW);
       }
-    if (!ok) {
+  };
+  // per-image coefficient table in LDS (norm affine of x, affine of the residual): rewritten only when the image changes
+  auto load_coeffs = [&](int zz) {
+    const long c = (long)zz * ME + tid;
+    Cf[tid] = p.pa ? p.pa[c] * SX : SX;
+    Cf[ME + tid] = p.pa ? p.pd[c] * SX : 0.0f;
+    Cf[2 * ME + tid] = p.add_a ? p.add_a[c] : 1.0f;
+    Cf[3 * ME + tid] = p.add_a ? p.add_d[c] : 0.0f;
+  };
+  if ((int)blockIdx.x < ntiles) load_coeffs((int)blockIdx.x / tpi);
+  __syncthreads();
+  if ((int)blockIdx.x < ntiles) prefetch_x(blockIdx.x);
+  // per-thread partial statistics of the output rows this thread stores (rows tid / 16 + 16 i), flushed per image
+  float psum[16], psq[16];
 #pragma unroll
-      for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xr[oc][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  for (int i = 0; i < 16; ++i) { psum[i] = 0.0f; psq[i] = 0.0f; }
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // lane-derived indices are laundered once per tile: otherwise every LDS address of the unrolled loops below is hoisted
+  // out of the tile loop (~160 registers of loop invariants, spilled and reloaded from scratch inside the MFMA loops)
+  asm volatile("" : "+v"(l31), "+v"(h), "+v"(q0), "+v"(o0));
+  const int tile_it = (tile - (int)blockIdx.x) / (int)gridDim.x;
+  auto stamp = [&](int i) {
+    if (p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= 2 && tile_it < 6)
+      p.stamps[(tile_it - 2) * 16 + i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+  z = tile / tpi;
+  n0 = (tile - z * tpi) * TN;
+  full = n0 + TN <= p.HW;   // workgroup-uniform
+
+  // ---- phase 0: x tile (already in registers) -> LDS (fp16 hi / lo, [px][k])
+  {
+    const bool ok = full || (n0 + 4 * q0 < p.HW);
 #pragma unroll
     for (int oc = 0; oc < 2; ++oc) {
-      const int c0 = 8 * (o + 16 * oc);
       float av[8], dv[8];
-      if (p.pa) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * ME + c0);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * ME + c0 + 4);
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.pd + (long)z * ME + c0);
-        const f32x4 d1 = *reinterpret_cast<const f32x4*>(p.pd + (long)z * ME + c0 + 4);
+      {
+        const int c0 = 8 * (o0 + 16 * oc);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(Cf + c0), a1 = *reinterpret_cast<const f32x4*>(Cf + c0 + 4);
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(Cf + ME + c0), d1 = *reinterpret_cast<const f32x4*>(Cf + ME + c0 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          av[e] = a0[e] * SX; av[e + 4] = a1[e] * SX;
-          dv[e] = d0[e] * SX; dv[e + 4] = d1[e] * SX;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { av[e] = SX; dv[e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { av[e] = a0[e]; av[e + 4] = a1[e]; dv[e] = d0[e]; dv[e + 4] = d1[e]; }
       }
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) {
-        const int px = 4 * q + pp;
+        const int px = 4 * q0 + pp;
         f16x8 vh, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float v = fmaf(xr[oc][e][pp], av[e], dv[e]);
+          const float v = ok ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
           const _Float16 hv = (_Float16)v;
           vh[e] = hv;
           vl[e] = (_Float16)(v - (float)hv);
         }
-        const int off = xs_off(px, o + 16 * oc);
+        const int off = xs_off(px, o0 + 16 * oc);
         *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
         *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
       }
@@ -157,17 +183,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   }
   __syncthreads();
 
-  f32x16 oacc[2][2];   // this wave's 64 output rows x 64 px
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[mi][j][r] = 0.0f;
+  f32x16 oacc[2][2];   // this wave's 64 output rows x 64 px (zeroed right before the first fc2: not live earlier)
   f32x4 rres[16];
-  float ra[16], rd[16];   // optional affine of the residual rows
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { rres[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ra[i] = 1.0f; rd[i] = 0.0f; }
   const int e_col = n0 + 4 * (tid & 15);                    // store phase: first pixel of this thread's quad
   const bool e_ok = full || e_col < p.HW;
   const long e_off = e_ok ? e_col : 0;
@@ -213,14 +230,14 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks], bl[c][j], acc[j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks], bh[c][j], acc[j], 0, 0, 0);
-      r_hi[ks] = wp[ks * gstr];
-      r_lo[ks] = wp[ks * gstr + 64];
+      r_hi[ks] = wp[ks * GROUP_F8];
+      r_lo[ks] = wp[ks * GROUP_F8 + 64];
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next k-step's LDS reads first
       __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // then the MFMAs
       __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // then the ring refill
       __builtin_amdgcn_sched_barrier(0);   // keep the refill here: the scheduler otherwise sinks it next to its use
     }
-    wp += wstep;
+    wp += RING * GROUP_F8;
   };
   // One eighth of chain(hc): 4 accumulator values (tile j, row group g4): bias + exact-erf GELU (same arithmetic as
   // gelu_erf in common.h) + Philox dropout, x16, fp16 hi/lo split -> LDS.  Cut into 12 stages of a few VALU instructions
@@ -345,47 +362,60 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        r_hi[s] = wp[s * gstr];
-        r_lo[s] = wp[s * gstr + 64];
+        r_hi[s] = wp[s * GROUP_F8];
+        r_lo[s] = wp[s * GROUP_F8 + 64];
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    wp += wstep;
+    wp += RING * GROUP_F8;
   };
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
 
+  stamp(1);   // x tile in LDS
   load_bias(0);
   fc1();
+  stamp(2);
 #pragma unroll
   for (int pc = 0; pc < 8; ++pc) chain_piece(0, pc >> 2, pc & 3);
+  stamp(3);
   __syncthreads();
+  stamp(4);
   load_bias(1);
   fc1();
+  stamp(5);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[mi][j][r] = 0.0f;
 #pragma unroll 1
   for (int hc = 1; hc < NCH; ++hc) {
     fc2(hc - 1, T_{});          // || chain(hc)
+    stamp(4 + 2 * hc);
     __syncthreads();
     if (hc < NCH - 1) {
       load_bias(hc + 1);
       fc1();
     }
+    stamp(5 + 2 * hc);
   }
-  if (p.add) {
-    // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested one fc2 phase
-    // ahead of their use; older than every later ring refill, so waiting for them does not drain the ring
-    const float* ag = p.add + (long)z * p.add_bs + (long)(tid >> 4) * p.HW + e_off;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) rres[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
-    if (p.add_a) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        ra[i] = p.add_a[(long)z * ME + (tid >> 4) + 16 * i];
-        rd[i] = p.add_d[(long)z * ME + (tid >> 4) + 16 * i];
-      }
-    }
+  wp = wbase;   // the refills of the last block fetch block 0 again: the ring is ready for the next tile
+  asm volatile("" : "+v"(wp));   // (laundered: otherwise the 16 refill addresses become loop invariants in VGPRs)
+  {
+    const int nt = tile + (int)gridDim.x;
+    prefetch_x(nt < ntiles ? nt : tile);   // next tile's pixels; past the end a harmless re-read keeps it branch-free
   }
   fc2(NCH - 1, F_{});
+  stamp(12);
+  {
+    // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested before
+    // the epilogue arithmetic, which covers most of their latency
+    const float* ag = (p.add ? p.add + (long)z * p.add_bs : p.x + (long)z * p.x_bs) + (long)(tid >> 4) * p.HW + e_off;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rres[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+  }
 
   // ---- epilogue: bias, dropout, drop-path scale in accumulator layout -> LDS [256 rows][64 px] (the x tile's storage:
   //      every wave passed the last chunk's barrier after its final x read), then residual add + 16-byte row stores
@@ -419,17 +449,58 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         }
       }
     }
+    stamp(13);
     __syncthreads();
+    stamp(14);
     if (e_ok) {
       float* og = p.out + (long)z * p.out_bs + (long)(tid >> 4) * p.HW + e_col;
       const float* os = Os + (tid >> 4) * TN + 4 * (tid & 15);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(os + 16 * i * TN) + (rres[i] * ra[i] + rd[i]);
+        const int row = (tid >> 4) + 16 * i;
+        f32x4 v = *reinterpret_cast<const f32x4*>(os + 16 * i * TN);
+        if (p.add) v += rres[i] * Cf[2 * ME + row] + Cf[3 * ME + row];
         *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
+        if (p.stats) {
+          psum[i] += (v.x + v.y) + (v.z + v.w);
+          psq[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+      }
+    }
+    // InstanceNorm statistics of what was just stored, for the NEXT block's norm0: the per-thread partials cover the
+    // few tiles this workgroup owns of one image; at the image's last tile here they are summed over the 16 lanes that
+    // share a row (fp64) and added to the global (sum, sum of squares) with one atomic pair per row
+    if (p.stats) {
+      const int nt = tile + (int)gridDim.x;
+      if (nt >= ntiles || nt / tpi != z) {   // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          double s1 = psum[i], s2 = psq[i];
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) {
+            s1 += __shfl_xor(s1, m, 64);
+            s2 += __shfl_xor(s2, m, 64);
+          }
+          if ((tid & 15) == 0) {
+            double* st = p.stats + ((long)z * ME + (tid >> 4) + 16 * i) * 2;
+            __hip_atomic_fetch_add(st, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(st + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          psum[i] = 0.0f; psq[i] = 0.0f;
+        }
       }
     }
   }
+  stamp(15);
+  __syncthreads();   // the store phase is done with the LDS tile: the next x tile goes to the same storage
+  {
+    const int nt = tile + (int)gridDim.x;
+    if (nt < ntiles && nt / tpi != z) {   // workgroup-uniform
+      load_coeffs(nt / tpi);
+      __syncthreads();
+    }
+  }
+  }   // tile loop
 }
 
 // power-of-two scale that puts max|w| in [2^12, 2^13) (same rule as the other split-fp16 packers)
@@ -454,6 +525,15 @@ void put_group(_Float16* dst, const float* w, int K, int mt, int ks, float s) {
 }
 
 }  // namespace
+
+static unsigned long long* g_stamps = nullptr;
+// timing experiments: 4 tiles x 16 phase stamps of wave 0 of workgroup 3 (valid after a launch with SDY_MLP_STAMPS set)
+extern "C" int sdy_mlp_h3_debug_stamps(unsigned long long* host64) {
+  if (!g_stamps || !host64) return SDY_ERR_STATE;
+  SDY_HIP_TRY(hipDeviceSynchronize());
+  SDY_HIP_TRY(hipMemcpy(host64, g_stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return SDY_OK;
+}
 
 extern "C" int sdy_mlp_h3_supported(int E, int hidden) { return (E == ME && hidden == MH) ? 1 : 0; }
 
@@ -508,7 +588,7 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   p.b1 = a->b1; p.b2 = a->b2;
   p.out = a->out; p.out_bs = a->out_bstride; p.add = a->add; p.add_bs = a->add_bstride;
   p.add_a = a->add ? a->add_a : nullptr; p.add_d = a->add ? a->add_d : nullptr;
-  p.HW = a->HW;
+  p.HW = a->HW; p.B = a->B;
   p.s1 = 1.0f / (a->w1_scale * SX);
   p.s2 = 1.0f / (a->w2_scale * SX);
   if (a->drop_p > 0.0f) {
@@ -519,9 +599,21 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   p.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFu); p.seed_hi = (uint32_t)(a->seed >> 32);
   p.stream1 = a->stream_fc1; p.stream2 = a->stream_fc2; p.call = a->call; p.batch_offset = a->batch_offset;
   p.batch_scale = a->batch_scale;
-  { const char* e = std::getenv("SDY_MLP_DBG"); p.dbg = e ? std::atoi(e) : 0; }
-  dim3 grid((a->HW + TN - 1) / TN, a->B);
-  constexpr size_t smem = (size_t)(2 * TN * ME + 4 * TN * HC) * sizeof(_Float16);
+  p.stats = a->stats;
+  p.stamps = nullptr;
+  if (std::getenv("SDY_MLP_STAMPS")) {
+    if (!g_stamps) SDY_HIP_TRY(hipMalloc(&g_stamps, 64 * sizeof(unsigned long long)));
+    p.stamps = g_stamps;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    SDY_HIP_TRY(hipGetDevice(&dev));
+    SDY_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const long ntiles = (long)((a->HW + TN - 1) / TN) * a->B;
+  dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));   // persistent: one workgroup per CU (128 KB of LDS each)
+  constexpr size_t smem = (size_t)(2 * TN * ME + 4 * TN * HC) * sizeof(_Float16) + 4 * ME * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel<false>),

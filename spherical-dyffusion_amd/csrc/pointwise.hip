@@ -60,6 +60,34 @@ __global__ __launch_bounds__(256) void instnorm_coeffs_kernel(const float* __res
   }
 }
 
+// Same coefficients from statistics accumulated by a producer kernel's epilogue (mlp_h3.hip): stats[b][c] = (sum, sumsq).
+__global__ __launch_bounds__(256) void instnorm_from_stats_kernel(double* __restrict__ stats, int BC, int C, int HW,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   const float* __restrict__ ss, long ss_stride, float eps,
+                                                                   float* __restrict__ a_out, float* __restrict__ d_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= BC) return;
+  const int b = i / C, c = i - b * C;
+  const double S = stats[2 * (long)i], S2 = stats[2 * (long)i + 1];
+  stats[2 * (long)i] = 0.0;
+  stats[2 * (long)i + 1] = 0.0;
+  const double mean = S / HW;
+  double var = S2 / HW - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float a = gamma[c] * rstd;
+  float d = beta[c] - (float)mean * a;
+  if (ss) {
+    const float sc = ss[(long)b * ss_stride + c] + 1.0f;
+    const float sh_ = ss[(long)b * ss_stride + C + c];
+    a = a * sc;
+    d = d * sc + sh_;
+  }
+  a_out[i] = a;
+  d_out[i] = d;
+}
+
 // ---- channel concat (torch.cat(dim=1)) ------------------------------------------------------------------
 struct ConcatArgs {
   const float* src[4];
@@ -400,6 +428,15 @@ int sdy_instnorm_coeffs_launch(const float* x, int B, int C, int HW, const float
   if (HW & 3) return SDY_ERR_ALIGN;
   hipLaunchKernelGGL(instnorm_coeffs_kernel, dim3(C, B), dim3(256), 0, stream, x, C, HW, gamma, beta, ss, ss_stride,
                      eps, a, d);
+  return sdy_launch_status();
+}
+
+extern "C" int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, const float* gamma, const float* beta,
+                                       const float* ss, long ss_stride, float eps, float* a, float* d, void* stream) {
+  if (!stats || !gamma || !beta || !a || !d || B <= 0 || C <= 0 || HW <= 0) return SDY_ERR_ARG;
+  const int BC = B * C;
+  hipLaunchKernelGGL(instnorm_from_stats_kernel, dim3((BC + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, BC, C, HW,
+                     gamma, beta, ss, ss_stride, eps, a, d);
   return sdy_launch_status();
 }
 

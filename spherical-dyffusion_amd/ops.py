@@ -172,7 +172,7 @@ def mlp_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Ten
               pre_affine=None, add: Optional[torch.Tensor] = None, drop_p: float = 0.0, seed: int = 0, call: int = 0,
               stream_fc1: int = 0, stream_fc2: int = 1, batch_offset: int = 0,
               batch_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              prepared=None, add_affine=None) -> torch.Tensor:
+              prepared=None, add_affine=None, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The block's MLP (`src/models/sfno/layers.py:73-80`) with the norm affine, both dropouts, DropPath scale and the
     residual add in one launch (include/sdy_amd.h, sdy_mlp_h3).  Same arithmetic and dropout stream as
     conv1x1(fc1, gelu, stream_fc1) -> conv1x1(fc2, stream_fc2, add_mode=2)."""
@@ -209,9 +209,28 @@ def mlp_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Ten
         bs = _aux(batch_scale, x.device)
         a.batch_scale = ptr(bs)
         keep.append(bs)
+    if stats is not None:       # (B, E, 2) float64 on the device, zeroed by the caller: (sum, sumsq) of `out` are added
+        assert stats.dtype == torch.float64 and stats.is_cuda and stats.is_contiguous() and stats.numel() == B * E * 2
+        a.stats = ptr(stats)
     with torch.cuda.device(x.device):
         check(lib.sdy_mlp_h3(C.byref(a), current_stream()), "sdy_mlp_h3")
     return out
+
+
+def instnorm_from_stats(stats: torch.Tensor, HW: int, gamma: torch.Tensor, beta: torch.Tensor, scale_shift=None,
+                        eps: float = 1e-6):
+    """(B, C, 2) float64 (sum, sumsq) statistics written by a producer epilogue -> the (a, d) of `instnorm_coeffs`;
+    clears `stats`."""
+    B, Cc = stats.shape[0], stats.shape[1]
+    dev = stats.device
+    g, b_ = _aux(gamma, dev), _aux(beta, dev)
+    ss = _aux(scale_shift, dev) if scale_shift is not None else None
+    a = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+    d = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.sdy_instnorm_from_stats(ptr(stats), B, Cc, HW, ptr(g), ptr(b_), ptr(ss), 2 * Cc if ss is not None else 0,
+                                          eps, ptr(a), ptr(d), current_stream()), "sdy_instnorm_from_stats")
+    return a, d
 
 
 def cold_update(x_s: torch.Tensor, x_ip_next: torch.Tensor, x_ip_s: Optional[torch.Tensor]) -> torch.Tensor:

@@ -271,6 +271,18 @@ def test_mlp_fused_matches_fp64_and_unfused(sdy, B, H, W, drop):
                             batch_scale=bs.cuda(), **kw)
     ref_aff = o * bs.double()[:, None, None, None] + res.double() * ra.double()[:, :, None, None] + rd.double()[:, :, None, None]
     assert rel_l2(got, ref_aff) < TOL_OP
+    # statistics of the stored output (the next block's InstanceNorm) from the epilogue
+    st = torch.zeros(B, E, 2, dtype=torch.float64, device="cuda")
+    got_s = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2, pre_affine=(pa.cuda(), pd.cuda()), add=res.cuda(),
+                              stream_fc1=2 * layer, stream_fc2=2 * layer + 1, batch_scale=bs.cuda(), stats=st, **kw)
+    gd = got_s.double().cpu()
+    want = torch.stack([gd.sum((2, 3)), (gd * gd).sum((2, 3))], -1)
+    assert torch.allclose(st.cpu(), want, rtol=1e-5, atol=1e-6 * H * W)
+    gamma, beta = 1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    a_s, d_s = sdy.ops.instnorm_from_stats(st, H * W, gamma, beta)
+    a_r, d_r = sdy.ops.instnorm_coeffs(got_s, gamma, beta)
+    assert rel_l2(a_s, a_r) < 1e-5 and rel_l2(d_s, d_r) < 1e-5
+    assert float(st.abs().max()) == 0.0, "statistics buffer must be cleared for reuse"
     # no affine / no residual / no scale
     got = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2)
     ref = F.conv2d(F.gelu(F.conv2d(x.double(), w1.double(), b1.double())), w2.double(), b2.double())
