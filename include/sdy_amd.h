@@ -144,12 +144,22 @@ typedef struct sdy_conv_args {
   const void* w_h3;                  /* dev, optional: weight packed by sdy_h3_pack_weight -> the GEMM runs on the f16
                                         matrix cores in split precision (3 passes, fp32-class accuracy); wt may be NULL */
   float w_h3_scale;                  /* scale returned by sdy_h3_pack_weight */
+  const void* w_frag;                /* dev, optional, Cin == Cout == 256 only: weight packed by sdy_conv256_h3_pack -> the
+                                        persistent fragment-stream kernel (no dropout / batch_scale / keep_mask) */
+  float w_frag_scale;
+  double* stats;                     /* dev [B*Cout*2] or NULL, w_frag path only: (sum, sum of squares) over HW of every
+                                        output plane are ADDED here (zero it first; sdy_instnorm_from_stats turns them into
+                                        the next InstanceNorm's coefficients) */
 } sdy_conv_args;
 int sdy_conv1x1(const sdy_conv_args* args, void* stream);
 
 /* Split-precision weight packing for sdy_conv1x1 (w_h3): host (Cout, Cin) row-major fp32 -> dev fp16 hi|lo planes,
  * [Mpad][Kpad] each (Mpad = 128 for Cout <= 128, else Cout rounded up to 256; Kpad = Cin rounded up to 64), multiplied by a power of two
  * (*scale) chosen so that max|w|*scale is in [2^12, 2^13). */
+/* 256 -> 256 weight (Cout, Cin) row-major -> per-wave MFMA fragment stream for sdy_conv_args.w_frag */
+int sdy_conv256_h3_supported(int Cin, int Cout);
+size_t sdy_conv256_h3_pack_bytes(void);
+int sdy_conv256_h3_pack(const float* w_host, void* packed_dev, float* scale);
 size_t sdy_h3_pack_bytes(int Cout, int Cin);
 int sdy_h3_pack_weight(const float* w_host, int Cout, int Cin, void* packed_dev, float* scale);
 

@@ -37,6 +37,9 @@ class SdyConvArgs(C.Structure):
         ("kernel_tag", C.c_int),
         ("w_h3", C.c_void_p),
         ("w_h3_scale", C.c_float),
+        ("w_frag", C.c_void_p),
+        ("w_frag_scale", C.c_float),
+        ("stats", C.c_void_p),
     ]
 
 
@@ -141,6 +144,9 @@ SIGNATURES = {
     "sdy_mlp_h3_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float),
                                   C.POINTER(C.c_float)]),
     "sdy_mlp_h3": (C.c_int, [C.POINTER(SdyMlpArgs), C.c_void_p]),
+    "sdy_conv256_h3_supported": (C.c_int, [C.c_int, C.c_int]),
+    "sdy_conv256_h3_pack_bytes": (C.c_size_t, []),
+    "sdy_conv256_h3_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "sdy_h3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sdy_h3_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "sdy_sfno_create": (C.c_int, [C.POINTER(SdySfnoConfig), C.POINTER(C.c_void_p)]),

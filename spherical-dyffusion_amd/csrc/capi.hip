@@ -387,13 +387,16 @@ extern "C" int sdy_h3_pack_weight(const float* w, int Cout, int Cin, void* packe
 }
 
 extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
-  if (!a || !a->x || (!a->wt && !a->w_h3) || !a->out) return SDY_ERR_ARG;
+  if (!a || !a->x || (!a->wt && !a->w_h3 && !a->w_frag) || !a->out) return SDY_ERR_ARG;
   if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->HW <= 0) return SDY_ERR_ARG;
   if (!a->w_h3 && a->ldw < a->Cout) return SDY_ERR_ARG;
   if ((a->pa == nullptr) != (a->pd == nullptr)) return SDY_ERR_ARG;
   if (a->add_mode != 0 && !a->add) return SDY_ERR_ARG;
   if ((!a->w_h3 && (a->ldw & 3)) || (a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3)) return SDY_ERR_ALIGN;
   if (a->drop_p < 0.0f || a->drop_p >= 1.0f) return SDY_ERR_ARG;
+  if (a->w_frag && sdy_conv256_h3_supported(a->Cin, a->Cout) && a->drop_p == 0.0f && !a->keep_mask && !a->batch_scale)
+    return sdy_conv256_h3_launch(a, (hipStream_t)stream);
+  if (a->stats) return SDY_ERR_UNSUPPORTED;   // statistics come from the persistent kernel only
   GemmParams g{};
   g.A = a->wt; g.lda = a->ldw; g.sA = 0;
   g.B = a->x; g.ldb = a->HW; g.sB = a->x_bstride;
@@ -448,6 +451,9 @@ struct DevBuf {
   // split-fp16 copy of a conv weight (gemm_mode 1)
   void* h3 = nullptr;
   float h3_scale = 1.0f;
+  // fragment stream of the persistent 256 -> 256 kernel (conv_h3.hip)
+  void* frag = nullptr;
+  float frag_scale = 1.0f;
 };
 
 struct BlockW {
@@ -501,8 +507,10 @@ static int dev_upload_T(DevBuf& b, const float* host, int out, int in, int ld) {
 static void dev_free(DevBuf& b) {
   if (b.p) (void)hipFree(b.p);
   if (b.h3) (void)hipFree(b.h3);
+  if (b.frag) (void)hipFree(b.frag);
   b.p = nullptr;
   b.h3 = nullptr;
+  b.frag = nullptr;
   b.set = false;
 }
 // conv weight: fp32 transposed copy (gemm_mode 0 path, also kept for reference) + split-fp16 pack (gemm_mode 1)
@@ -513,6 +521,10 @@ static int dev_upload_conv(DevBuf& b, const float* host, int out, int in, int ld
     b.h3 = nullptr;
     SDY_HIP_TRY(hipMalloc(&b.h3, sdy_h3_pack_bytes(out, in)));
     SDY_TRY(sdy_h3_pack_weight(host, out, in, b.h3, &b.h3_scale));
+    if (sdy_conv256_h3_supported(in, out)) {
+      if (!b.frag) SDY_HIP_TRY(hipMalloc(&b.frag, sdy_conv256_h3_pack_bytes()));
+      SDY_TRY(sdy_conv256_h3_pack(host, b.frag, &b.frag_scale));
+    }
   }
   return SDY_OK;
 }
@@ -729,7 +741,7 @@ extern "C" const char* sdy_sfno_missing(const sdy_sfno* n) { return n ? n->missi
 
 namespace {
 struct WsLayout {
-  size_t cat, xa, xb, xn, y, hid, xf, cs, cs2, ca, cd, ca1, cd1, st0, ss, dp, trep, total;
+  size_t cat, xa, xb, xn, y, hid, xf, cs, cs2, ca, cd, ca1, cd1, st0, st1, ss, dp, trep, total;
 };
 WsLayout ws_layout(const sdy_sfno* n, int B) {
   const sdy_sfno_config& c = n->cfg;
@@ -750,6 +762,7 @@ WsLayout ws_layout(const sdy_sfno* n, int B) {
   w.cd = take((size_t)B * E);
   w.ca1 = take((size_t)B * E);
   w.cd1 = take((size_t)B * E);
+  w.st1 = take((size_t)B * E * 4);   // same for norm1, filled by the inner-skip convolution's epilogue
   w.st0 = take((size_t)B * E * 4);   // (sum, sumsq) doubles of the next block's norm0, filled by the fused MLP epilogue
   w.ss = take((size_t)B * c.num_layers * 2 * E);
   w.dp = take((size_t)B * c.num_layers);
@@ -786,6 +799,8 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   float *Xf = ws + w.xf, *Cs = ws + w.cs, *Cs2 = ws + w.cs2, *ca = ws + w.ca, *cd = ws + w.cd;
   float *ca1 = ws + w.ca1, *cd1 = ws + w.cd1;
   double* st0 = reinterpret_cast<double*>(ws + w.st0);   // take() rounds offsets to 64 floats: 8-byte aligned
+  double* st1 = reinterpret_cast<double*>(ws + w.st1);
+  SDY_HIP_TRY(hipMemsetAsync(st1, 0, (size_t)B * E * 2 * sizeof(double), stream));
   bool have_st0 = false;                                  // statistics of `cur` are waiting in st0
   SDY_HIP_TRY(hipMemsetAsync(st0, 0, (size_t)B * E * 2 * sizeof(double), stream));
   float *ss = ws + w.ss, *dp = ws + w.dp, *trep = ws + w.trep;
@@ -808,7 +823,14 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
                               a->batch_offset, stream));
 
   sdy_conv_args cv;
-  auto use_w = [&](const DevBuf& b) { cv.wt = b.p; if (c.gemm_mode == 1) { cv.w_h3 = b.h3; cv.w_h3_scale = b.h3_scale; } };
+  static const bool no_frag = std::getenv("SDY_NO_CONV_FRAG") != nullptr;
+  auto use_w = [&](const DevBuf& b) {
+    cv.wt = b.p;
+    if (c.gemm_mode == 1) {
+      cv.w_h3 = b.h3; cv.w_h3_scale = b.h3_scale;
+      if (!no_frag) { cv.w_frag = b.frag; cv.w_frag_scale = b.frag_scale; }
+    }
+  };
   auto conv_reset = [&]() {
     std::memset(&cv, 0, sizeof(cv));
     cv.B = B; cv.HW = HW; cv.seed = a->seed; cv.call = a->call; cv.batch_offset = a->batch_offset;
@@ -866,9 +888,15 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     if (lazy_norm) { cv.pa = ca; cv.pd = cd; }
     use_w(bw.skw); cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
     cv.Cin = E; cv.Cout = E; cv.bias = bw.skb.p; cv.add = y; cv.add_bstride = (long)E * HW; cv.add_mode = 1; cv.act = 1; cv.kernel_tag = 3;
+    static const bool no_stats1 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
+    const bool stats1 = cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats1;
+    if (stats1) cv.stats = st1;
     SDY_TRY(sdy_conv1x1(&cv, stream));
-    // norm1 (sfnonet.py:313-320) folded into the fc1 prologue
-    SDY_TRY(sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+    // norm1 (sfnonet.py:313-320) folded into the fc1 prologue; its statistics come from the convolution's epilogue
+    if (stats1)
+      SDY_TRY(sdy_instnorm_from_stats(st1, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+    else
+      SDY_TRY(sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
     // MLP (layers.py:73-80): fc1 + GELU + dropout
     float* dst = (i == L - 1) ? cat : nxt;
     const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;

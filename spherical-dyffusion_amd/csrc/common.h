@@ -108,6 +108,9 @@ int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, in
 int sdy_gemm_h3_ws_launch(const GemmParams& p, const void* packed, int rows_pad, int Kpad, long plane_halfs, float w_scale,
                           hipStream_t stream);
 
+// ---- persistent 256 -> 256 convolution (conv_h3.hip)
+int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream);
+
 // ---- skinny Legendre GEMM with the table streamed as MFMA fragments (leg_h3.hip), rows and K <= 192
 typedef float (*sdy_leg_value_fn)(void* ctx, int z, int row, int k);
 int sdy_leg_h3_supported(int rows, int K);

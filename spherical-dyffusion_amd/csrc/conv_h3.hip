@@ -1,0 +1,291 @@
+// 256 -> 256 channel 1x1 convolution (the block's inner skip, the encoder's second layer) as a persistent split-fp16
+// kernel in the style of mlp_h3.hip:
+//   out[b] = act( W . (pa[b]*x[b] + pd[b]) + bias + add_pre[b] ) + add_post[b]        (+ InstanceNorm statistics of out)
+//   * one workgroup owns 64 pixels and all 256 output rows; the activation tile is fetched once, split hi/lo and
+//     parked in LDS ([px][k], XOR-swizzled); wave w computes rows 64w .. 64w+63 (2 x 2 MFMA tiles, K = 256);
+//   * the weight never touches LDS: packed per wave as a linear stream of MFMA A-fragment pairs (hi, lo) in consumption
+//     order, L2 -> registers through an 8-group ring;
+//   * the epilogue goes through LDS so that the addend loads and the stores are 16-byte row segments, applies
+//     bias / addend / GELU there, and keeps per-thread (sum, sum of squares) of what it stores: the workgroup is
+//     persistent (tiles blockIdx.x, + gridDim.x, ...), so the statistics cost one fp64 atomic pair per row and IMAGE
+//     instead of one per tile -- the next InstanceNorm (norm1) needs no pass of its own over the tensor.
+// 64 KB of LDS and <= 256 VGPRs: two workgroups per CU cover each other's load / epilogue phases.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int CE = 256;          // channels in = out
+constexpr int CTN = 64;          // pixels per tile
+constexpr int CKS = CE / 16;     // k-steps
+constexpr int CRING = 8;         // groups in flight (4 k-steps x 2 m-tiles)
+constexpr int CGPW = 2 * CKS;    // groups per wave
+constexpr int CGROUP = 2 * 64;   // f16x8 elements per group
+constexpr float CSX = 16.0f;
+
+struct ConvParams {
+  const float* x; long x_bs;
+  const float* pa; const float* pd;
+  const f16x8* w;                  // [4 waves][CGPW groups][hi | lo][64 lanes]
+  const float* bias;
+  const float* add; long add_bs; int add_mode;   // 1: before the activation, 2: after it
+  int act;
+  float* out; long out_bs;
+  double* stats;
+  int HW, B;
+  float out_scale;
+};
+
+__device__ __forceinline__ int cv_swz(int px) { return (px & 15) ^ (((px >> 4) & 1) * 3); }
+__device__ __forceinline__ int cv_off(int px, int c) { return px * CE + (((c & 16) | ((c ^ cv_swz(px)) & 15)) << 3); }
+
+__global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CTN * CE * 2];   // 64 KB
+  _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
+  _Float16* Xs_lo = Xs_hi + CTN * CE;
+  float* Os = reinterpret_cast<float*>(smem);   // epilogue: [256 rows][64 px] fp32 (aliases the x tile)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int h = lane >> 5, l31 = lane & 31;
+  int q0 = tid & 15, o0 = tid >> 4;
+  const int tpi = (p.HW + CTN - 1) / CTN;
+  const int ntiles = tpi * p.B;
+
+  f16x8 r_hi[CRING], r_lo[CRING];
+  const f16x8* __restrict__ wbase = p.w + (size_t)wave * CGPW * CGROUP + lane;
+  const f16x8* __restrict__ wp = wbase;
+#pragma unroll
+  for (int s = 0; s < CRING; ++s) {
+    r_hi[s] = wp[s * CGROUP];
+    r_lo[s] = wp[s * CGROUP + 64];
+  }
+  wp += CRING * CGROUP;
+
+  float psum[16], psq[16];   // statistics partials of the rows this thread stores (rows tid / 16 + 16 i)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { psum[i] = 0.0f; psq[i] = 0.0f; }
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // laundered per tile: keeps the unrolled loops' LDS addresses from being hoisted into (spilled) loop invariants
+    asm volatile("" : "+v"(l31), "+v"(h), "+v"(q0), "+v"(o0));
+    const int z = tile / tpi;
+    const int n0 = (tile - z * tpi) * CTN;
+    const bool full = n0 + CTN <= p.HW;
+
+    // ---- phase 0: x tile -> LDS (fp16 hi / lo, [px][k]); thread = (pixel quad q0, channel octets o0 and o0 + 16)
+    {
+      const bool ok = full || (n0 + 4 * q0 < p.HW);
+      const float* __restrict__ xg = p.x + (long)z * p.x_bs + (ok ? n0 + 4 * q0 : 0);
+      f32x4 xr[2][8];
+#pragma unroll
+      for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)(8 * (o0 + 16 * oc) + e) * p.HW);
+#pragma unroll
+      for (int oc = 0; oc < 2; ++oc) {
+        const int c0 = 8 * (o0 + 16 * oc);
+        float av[8], dv[8];
+        if (p.pa) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * CE + c0);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * CE + c0 + 4);
+          const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.pd + (long)z * CE + c0);
+          const f32x4 d1 = *reinterpret_cast<const f32x4*>(p.pd + (long)z * CE + c0 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            av[e] = a0[e] * CSX; av[e + 4] = a1[e] * CSX;
+            dv[e] = d0[e] * CSX; dv[e + 4] = d1[e] * CSX;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { av[e] = CSX; dv[e] = 0.f; }
+        }
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          f16x8 vh, vl;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = ok ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
+            const _Float16 hv = (_Float16)v;
+            vh[e] = hv;
+            vl[e] = (_Float16)(v - (float)hv);
+          }
+          const int off = cv_off(4 * q0 + pp, o0 + 16 * oc);
+          *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
+          *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA phase: rows 64 wave .. +64, all 64 px, K = 256
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.0f;
+#pragma unroll 1
+    for (int kb = 0; kb < CKS / 4; ++kb) {
+      if (kb == CKS / 4 - 1) {   // the refills of the last block fetch block 0 again: ring ready for the next tile
+        wp = wbase;
+        asm volatile("" : "+v"(wp));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ks = 4 * kb + i;
+        f16x8 bh[2], bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int off = cv_off(32 * j + l31, 2 * ks + h);
+          bh[j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
+          bl[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int s = 2 * i + mi;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[mi][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], acc[mi][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], acc[mi][j], 0, 0, 0);
+          r_hi[s] = wp[s * CGROUP];
+          r_lo[s] = wp[s * CGROUP + 64];
+          __builtin_amdgcn_sched_barrier(0);   // keep the refill here (the scheduler otherwise sinks it next to its use)
+        }
+      }
+      wp += CRING * CGROUP;
+    }
+
+    // ---- epilogue: accumulators -> LDS [row][px]; bias / addend / GELU / statistics on 16-byte row segments
+    __syncthreads();   // every wave is done reading the x tile
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 64 * wave + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
+          Os[row * CTN + 32 * j + l31] = acc[mi][j][r] * p.out_scale;
+        }
+    __syncthreads();
+    {
+      const int col = n0 + 4 * q0;
+      if (full || col < p.HW) {
+        const long roff = (long)o0 * p.HW + col;
+        float* og = p.out + (long)z * p.out_bs + roff;
+        const float* ag = p.add ? p.add + (long)z * p.add_bs + roff : nullptr;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = o0 + 16 * i;
+          f32x4 v = *reinterpret_cast<const f32x4*>(Os + row * CTN + 4 * q0);
+          if (p.bias) v += p.bias[row];
+          f32x4 av = {0.f, 0.f, 0.f, 0.f};
+          if (ag) av = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+          if (p.add_mode == 1) v += av;
+          if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          }
+          if (p.add_mode == 2) v += av;
+          *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
+          psum[i] += (v.x + v.y) + (v.z + v.w);
+          psq[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+      }
+    }
+    // statistics flush at this workgroup's last tile of the image (see mlp_h3.hip)
+    if (p.stats) {
+      const int nt = tile + (int)gridDim.x;
+      if (nt >= ntiles || nt / tpi != z) {   // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          double s1 = psum[i], s2 = psq[i];
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) {
+            s1 += __shfl_xor(s1, m, 64);
+            s2 += __shfl_xor(s2, m, 64);
+          }
+          if (q0 == 0) {
+            double* st = p.stats + ((long)z * CE + o0 + 16 * i) * 2;
+            __hip_atomic_fetch_add(st, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(st + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          psum[i] = 0.0f; psq[i] = 0.0f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { psum[i] = 0.0f; psq[i] = 0.0f; }
+    }
+    __syncthreads();   // the store phase is done with the LDS tile
+  }
+}
+
+}  // namespace
+
+extern "C" int sdy_conv256_h3_supported(int Cin, int Cout) { return (Cin == CE && Cout == CE) ? 1 : 0; }
+
+extern "C" size_t sdy_conv256_h3_pack_bytes(void) { return (size_t)4 * CGPW * CGROUP * sizeof(f16x8); }
+
+// w_host: (256, 256) row-major (Cout, Cin)
+extern "C" int sdy_conv256_h3_pack(const float* w_host, void* dev, float* scale) {
+  if (!w_host || !dev || !scale) return SDY_ERR_ARG;
+  float mx = 0.f;
+  for (int i = 0; i < CE * CE; ++i) mx = std::fmax(mx, std::fabs(w_host[i]));
+  float s = 1.0f;
+  if (mx > 0.f && std::isfinite(mx)) {
+    int e;
+    std::frexp(mx, &e);
+    s = std::ldexp(1.0f, 13 - e);
+  }
+  const size_t gh = (size_t)CGROUP * 8;
+  std::vector<_Float16> buf((size_t)4 * CGPW * gh);
+  _Float16* d = buf.data();
+  for (int w = 0; w < 4; ++w)
+    for (int ks = 0; ks < CKS; ++ks)
+      for (int mi = 0; mi < 2; ++mi, d += gh)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int e = 0; e < 8; ++e) {
+            const float v = w_host[(size_t)(64 * w + 32 * mi + (ln & 31)) * CE + 16 * ks + 8 * (ln >> 5) + e] * s;
+            const _Float16 hv = (_Float16)v;
+            d[ln * 8 + e] = hv;
+            d[64 * 8 + ln * 8 + e] = (_Float16)(v - (float)hv);
+          }
+  SDY_HIP_TRY(hipMemcpy(dev, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  *scale = s;
+  return SDY_OK;
+}
+
+int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
+  if (!a || !a->x || !a->w_frag || !a->out || a->B <= 0 || a->HW <= 0) return SDY_ERR_ARG;
+  if (!sdy_conv256_h3_supported(a->Cin, a->Cout)) return SDY_ERR_UNSUPPORTED;
+  if (a->drop_p > 0.f || a->keep_mask || a->batch_scale) return SDY_ERR_UNSUPPORTED;
+  if ((a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3) || (a->add_mode && (a->add_bstride & 3))) return SDY_ERR_ALIGN;
+  ConvParams p;
+  p.x = a->x; p.x_bs = a->x_bstride; p.pa = a->pa; p.pd = a->pd;
+  p.w = reinterpret_cast<const f16x8*>(a->w_frag);
+  p.bias = a->bias;
+  p.add = a->add_mode ? a->add : nullptr; p.add_bs = a->add_bstride; p.add_mode = a->add_mode;
+  p.act = a->act;
+  p.out = a->out; p.out_bs = a->out_bstride;
+  p.stats = a->stats;
+  p.HW = a->HW; p.B = a->B;
+  p.out_scale = 1.0f / (a->w_frag_scale * CSX);
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    SDY_HIP_TRY(hipGetDevice(&dev));
+    SDY_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const long ntiles = (long)((a->HW + CTN - 1) / CTN) * a->B;
+  const long want = 2L * n_cu;   // two workgroups per CU
+  dim3 grid((unsigned)(ntiles < want ? ntiles : want));
+  hipLaunchKernelGGL(conv_h3_kernel, grid, dim3(256), 0, stream, p);
+  return sdy_launch_status();
+}

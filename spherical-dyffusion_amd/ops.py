@@ -83,7 +83,7 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
             drop_p: float = 0.0, keep_mask: Optional[torch.Tensor] = None, seed: int = 0, call: int = 0,
             stream_id: int = 0, batch_offset: int = 0, batch_scale: Optional[torch.Tensor] = None,
             kernel_tag: int = 0, out: Optional[torch.Tensor] = None, wt_prepared=None, h3: bool = False,
-            h3_prepared=None) -> torch.Tensor:
+            h3_prepared=None, frag_prepared=None, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nn.Conv2d(kernel_size=1) with the block's fused prologue/epilogue (see include/sdy_amd.h, sdy_conv1x1).
     x (B,Cin,H,W), weight (Cout,Cin[,1,1])."""
     x = _f32c(x)
@@ -132,6 +132,12 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
         keep.append(km)
     a.seed, a.call, a.stream_id, a.batch_offset = seed, call, stream_id, batch_offset
     a.kernel_tag = kernel_tag
+    if frag_prepared is not None:   # persistent 256 -> 256 kernel (pack_conv256); the only path that can emit statistics
+        a.w_frag, a.w_frag_scale = ptr(frag_prepared[0]), frag_prepared[1]
+        keep.append(frag_prepared[0])
+    if stats is not None:       # (B, Cout, 2) float64 on the device, zeroed by the caller: (sum, sumsq) of `out` are added
+        assert stats.dtype == torch.float64 and stats.is_cuda and stats.is_contiguous() and stats.numel() == B * Cout * 2
+        a.stats = ptr(stats)
     if batch_scale is not None:
         bs = _aux(batch_scale, x.device)
         a.batch_scale = ptr(bs)
@@ -139,6 +145,18 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     with torch.cuda.device(x.device):
         check(lib.sdy_conv1x1(C.byref(a), current_stream()), "sdy_conv1x1")
     return out
+
+
+def pack_conv256(weight: torch.Tensor, device):
+    """(256, 256) fp32 weight -> (per-wave MFMA fragment stream, scale) for conv1x1(..., frag_prepared=...)."""
+    w = weight.detach().to("cpu", torch.float32).reshape(weight.shape[0], -1).contiguous()
+    if not lib.sdy_conv256_h3_supported(w.shape[1], w.shape[0]):
+        raise NotImplementedError("the persistent conv kernel supports 256 -> 256 channels only")
+    buf = torch.empty(lib.sdy_conv256_h3_pack_bytes(), dtype=torch.uint8, device=device)
+    sc = C.c_float()
+    with torch.cuda.device(device):
+        check(lib.sdy_conv256_h3_pack(ptr(w), ptr(buf), C.byref(sc)), "sdy_conv256_h3_pack")
+    return buf, sc.value
 
 
 def pack_h3(weight: torch.Tensor, device):

@@ -293,3 +293,38 @@ def test_mlp_fused_rejects_other_shapes(sdy):
     x = torch.zeros(1, 64, 8, 16).cuda()
     with pytest.raises(NotImplementedError):
         sdy.ops.mlp_fused(x, torch.zeros(128, 64), torch.zeros(128), torch.zeros(64, 128), torch.zeros(64))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 20, 36), (1, 45, 64), (3, 6, 36)])
+def test_conv256_persistent_kernel_and_statistics(sdy, B, H, W):
+    """conv_h3_kernel (256 -> 256, persistent, weight as MFMA fragment stream) == the reference conv with the block's
+    inner-skip epilogue GELU(conv + bias + add), the encoder's post-add, and the InstanceNorm statistics of its output."""
+    g = _gen(31)
+    F = torch.nn.functional
+    E = 256
+    x = torch.randn(B, E, H, W, generator=g) * 1.4 + 0.1
+    w = torch.randn(E, E, 1, 1, generator=g) / np.sqrt(E)
+    b = 0.1 * torch.randn(E, generator=g)
+    add = torch.randn(B, E, H, W, generator=g)
+    pa, pd = 1 + 0.2 * torch.randn(B, E, generator=g), 0.2 * torch.randn(B, E, generator=g)
+    frag = sdy.ops.pack_conv256(w, "cuda")
+    st = torch.zeros(B, E, 2, dtype=torch.float64, device="cuda")
+    out = sdy.ops.conv1x1(x.cuda(), w, b, pre_affine=(pa.cuda(), pd.cuda()), add=add.cuda(), add_mode=1, gelu=True,
+                          frag_prepared=frag, stats=st)
+    xd = x.double() * pa.double()[:, :, None, None] + pd.double()[:, :, None, None]
+    ref = F.gelu(F.conv2d(xd, w.double(), b.double()) + add.double())
+    assert rel_l2(out, ref) < TOL_OP
+    od = out.double().cpu()
+    want = torch.stack([od.sum((2, 3)), (od * od).sum((2, 3))], -1)
+    assert torch.allclose(st.cpu(), want, rtol=1e-5, atol=1e-6 * H * W)
+    gamma, beta = 1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    a_s, d_s = sdy.ops.instnorm_from_stats(st, H * W, gamma, beta)
+    a_r, d_r = sdy.ops.instnorm_coeffs(out, gamma, beta)
+    assert rel_l2(a_s, a_r) < 1e-5 and rel_l2(d_s, d_r) < 1e-5
+    # encoder form: no bias, broadcast post-add, no activation
+    pe = torch.randn(1, E, H, W, generator=g)
+    out2 = sdy.ops.conv1x1(x.cuda(), w, None, add=pe.cuda(), add_mode=2, frag_prepared=frag)
+    assert rel_l2(out2, F.conv2d(x.double(), w.double()) + pe.double()) < TOL_OP
+    # same result as the tile GEMM
+    out3 = sdy.ops.conv1x1(x.cuda(), w, None, add=pe.cuda(), add_mode=2, h3=True)
+    assert rel_l2(out2, out3) < 5e-6
