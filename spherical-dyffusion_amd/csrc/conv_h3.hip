@@ -7,10 +7,11 @@
 //     order, L2 -> registers through an 8-group ring;
 //   * the epilogue goes through LDS so that the addend loads and the stores are 16-byte row segments, applies
 //     bias / addend / GELU there, and keeps per-thread (sum, sum of squares) of what it stores: the workgroup is
-//     persistent (tiles blockIdx.x, + gridDim.x, ...), so the statistics cost one fp64 atomic pair per row and IMAGE
+//     persistent (a contiguous range of tiles), so the statistics cost one fp64 atomic pair per row and IMAGE
 //     instead of one per tile -- the next InstanceNorm (norm1) needs no pass of its own over the tensor.
-// 64 KB of LDS and <= 256 VGPRs: two workgroups per CU cover each other's load / epilogue phases.
+// One workgroup per CU, software-pipelined over its tiles (see the tile loop).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -38,12 +39,13 @@ struct ConvParams {
   double* stats;
   int HW, B;
   float out_scale;
+  unsigned long long* stamps;    // timing experiments only (SDY_CONV_STAMPS)
 };
 
 __device__ __forceinline__ int cv_swz(int px) { return (px & 15) ^ (((px >> 4) & 1) * 3); }
 __device__ __forceinline__ int cv_off(int px, int c) { return px * CE + (((c & 16) | ((c ^ cv_swz(px)) & 15)) << 3); }
 
-__global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CTN * CE * 2];   // 64 KB
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
   _Float16* Xs_lo = Xs_hi + CTN * CE;
@@ -54,6 +56,11 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvParams p) {
   int q0 = tid & 15, o0 = tid >> 4;
   const int tpi = (p.HW + CTN - 1) / CTN;
   const int ntiles = tpi * p.B;
+  // contiguous tile range per workgroup: a workgroup then crosses an image boundary at most ~once, so the per-image
+  // flush of the statistics (and the reload of per-image coefficients) is rare instead of every few tiles
+  const int t_per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * t_per;
+  const int t_end = (t_begin + t_per < ntiles) ? t_begin + t_per : ntiles;
 
   f16x8 r_hi[CRING], r_lo[CRING];
   const f16x8* __restrict__ wbase = p.w + (size_t)wave * CGPW * CGROUP + lane;
@@ -65,26 +72,54 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvParams p) {
   }
   wp += CRING * CGROUP;
 
-  float psum[16], psq[16];   // statistics partials of the rows this thread stores (rows tid / 16 + 16 i)
+  float brow[16];            // bias of the rows this thread stores (rows tid / 16 + 16 i): the same for every tile
+#pragma unroll
+  for (int i = 0; i < 16; ++i) brow[i] = p.bias ? p.bias[o0 + 16 * i] : 0.0f;
+  float psum[16], psq[16];   // statistics partials of those rows
 #pragma unroll
   for (int i = 0; i < 16; ++i) { psum[i] = 0.0f; psq[i] = 0.0f; }
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Software pipeline over tiles (one workgroup per CU, full register budget).  Loads are issued ONE per step, never as
+  // a burst: a wave that issues more than the CU can keep in flight stalls at issue until HBM has delivered (a burst of
+  // 32 KB per wave measured 9-20k idle cycles).  Tile t+1's pixels (xr) ride on tile t's MFMA groups, tile t+1's addend
+  // rows (addn) on tile t's store loop; both are consumed a full phase later.
+  f32x4 xr[2][8], addv[16], addn[16];
+  auto x_ptr = [&](int t) {
+    const int zz = t / tpi, nn = (t - zz * tpi) * CTN;
+    return p.x + (long)zz * p.x_bs + ((nn + 4 * q0 < p.HW) ? nn + 4 * q0 : 0);   // ragged slice: clamped, zeroed later
+  };
+  auto add_ptr = [&](int t) {
+    const int zz = t / tpi, nn = (t - zz * tpi) * CTN;
+    const int cc = nn + 4 * q0;
+    return (p.add ? p.add + (long)zz * p.add_bs : p.x + (long)zz * p.x_bs) + (long)o0 * p.HW + (cc < p.HW ? cc : 0);
+  };
+  if (t_begin < t_end) {
+    const float* xg = x_ptr(t_begin);
+    const float* ag = add_ptr(t_begin);
+#pragma unroll
+    for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)(8 * (o0 + 16 * oc) + e) * p.HW);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) addv[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+  }
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
     // laundered per tile: keeps the unrolled loops' LDS addresses from being hoisted into (spilled) loop invariants
     asm volatile("" : "+v"(l31), "+v"(h), "+v"(q0), "+v"(o0));
+    const int tile_it = tile - t_begin;
+    auto stamp = [&](int i) {
+      if (p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= 2 && tile_it < 6)
+        p.stamps[(tile_it - 2) * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     const int z = tile / tpi;
     const int n0 = (tile - z * tpi) * CTN;
     const bool full = n0 + CTN <= p.HW;
 
-    // ---- phase 0: x tile -> LDS (fp16 hi / lo, [px][k]); thread = (pixel quad q0, channel octets o0 and o0 + 16)
+    // ---- phase 0: x tile (already in registers) -> LDS (fp16 hi / lo, [px][k]); thread = (pixel quad q0, octets o0, o0 + 16)
     {
       const bool ok = full || (n0 + 4 * q0 < p.HW);
-      const float* __restrict__ xg = p.x + (long)z * p.x_bs + (ok ? n0 + 4 * q0 : 0);
-      f32x4 xr[2][8];
-#pragma unroll
-      for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)(8 * (o0 + 16 * oc) + e) * p.HW);
 #pragma unroll
       for (int oc = 0; oc < 2; ++oc) {
         const int c0 = 8 * (o0 + 16 * oc);
@@ -120,7 +155,14 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvParams p) {
       }
     }
     __syncthreads();
-
+    stamp(1);
+    const int col = n0 + 4 * q0;
+    const bool c_ok = full || col < p.HW;
+    const long roff = (long)o0 * p.HW + (c_ok ? col : 0);
+    const int tnext = (tile + 1 < t_end) ? tile + 1 : tile;   // past the end: a harmless re-read
+    const float* xnext = x_ptr(tnext);
+    const float* anext = add_ptr(tnext);
+    stamp(2);
     // ---- MFMA phase: rows 64 wave .. +64, all 64 px, K = 256
     f32x16 acc[2][2];
 #pragma unroll
@@ -129,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvParams p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.0f;
-#pragma unroll 1
+#pragma unroll
     for (int kb = 0; kb < CKS / 4; ++kb) {
       if (kb == CKS / 4 - 1) {   // the refills of the last block fetch block 0 again: ring ready for the next tile
         wp = wbase;
@@ -156,14 +198,20 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvParams p) {
           for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], acc[mi][j], 0, 0, 0);
           r_hi[s] = wp[s * CGROUP];
           r_lo[s] = wp[s * CGROUP + 64];
-          __builtin_amdgcn_sched_barrier(0);   // keep the refill here (the scheduler otherwise sinks it next to its use)
+          if ((s & 1) == 0) {   // one pixel load of the next tile per two weight groups
+            const int g = (8 * kb + s) >> 1;   // 0..15
+            xr[g >> 3][g & 7] = *reinterpret_cast<const f32x4*>(xnext + (long)(8 * (o0 + 16 * (g >> 3)) + (g & 7)) * p.HW);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // keep the loads here (the scheduler otherwise sinks them next to their use)
         }
       }
       wp += CRING * CGROUP;
     }
 
+    stamp(3);
     // ---- epilogue: accumulators -> LDS [row][px]; bias / addend / GELU / statistics on 16-byte row segments
-    __syncthreads();   // every wave is done reading the x tile
+    __syncthreads();
+    stamp(4);   // every wave is done reading the x tile
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -174,35 +222,32 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvParams p) {
           Os[row * CTN + 32 * j + l31] = acc[mi][j][r] * p.out_scale;
         }
     __syncthreads();
-    {
-      const int col = n0 + 4 * q0;
-      if (full || col < p.HW) {
-        const long roff = (long)o0 * p.HW + col;
-        float* og = p.out + (long)z * p.out_bs + roff;
-        const float* ag = p.add ? p.add + (long)z * p.add_bs + roff : nullptr;
+    stamp(5);
+    if (c_ok) {
+      float* og = p.out + (long)z * p.out_bs + roff;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = o0 + 16 * i;
-          f32x4 v = *reinterpret_cast<const f32x4*>(Os + row * CTN + 4 * q0);
-          if (p.bias) v += p.bias[row];
-          f32x4 av = {0.f, 0.f, 0.f, 0.f};
-          if (ag) av = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
-          if (p.add_mode == 1) v += av;
-          if (p.act == 1) {
+      for (int i = 0; i < 16; ++i) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(Os + (o0 + 16 * i) * CTN + 4 * q0);
+        v += brow[i];
+        if (p.add_mode == 1) v += addv[i];
+        if (p.act == 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-          }
-          if (p.add_mode == 2) v += av;
-          *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
-          psum[i] += (v.x + v.y) + (v.z + v.w);
-          psq[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
+        if (p.add_mode == 2) v += addv[i];
+        *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
+        addn[i] = *reinterpret_cast<const f32x4*>(anext + (long)(16 * i) * p.HW);   // next tile's addend row, one per step
+        psum[i] += (v.x + v.y) + (v.z + v.w);
+        psq[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
       }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) addv[i] = addn[i];
+    stamp(6);
     // statistics flush at this workgroup's last tile of the image (see mlp_h3.hip)
     if (p.stats) {
-      const int nt = tile + (int)gridDim.x;
-      if (nt >= ntiles || nt / tpi != z) {   // workgroup-uniform
+      const int nt = tile + 1;
+      if (nt >= t_end || nt / tpi != z) {   // workgroup-uniform
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           double s1 = psum[i], s2 = psq[i];
@@ -223,11 +268,20 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { psum[i] = 0.0f; psq[i] = 0.0f; }
     }
+    stamp(7);
     __syncthreads();   // the store phase is done with the LDS tile
   }
 }
 
 }  // namespace
+
+static unsigned long long* g_cstamps = nullptr;
+extern "C" int sdy_conv256_h3_debug_stamps(unsigned long long* host64) {
+  if (!g_cstamps || !host64) return SDY_ERR_STATE;
+  SDY_HIP_TRY(hipDeviceSynchronize());
+  SDY_HIP_TRY(hipMemcpy(host64, g_cstamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return SDY_OK;
+}
 
 extern "C" int sdy_conv256_h3_supported(int Cin, int Cout) { return (Cin == CE && Cout == CE) ? 1 : 0; }
 
@@ -277,6 +331,11 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   p.stats = a->stats;
   p.HW = a->HW; p.B = a->B;
   p.out_scale = 1.0f / (a->w_frag_scale * CSX);
+  p.stamps = nullptr;
+  if (std::getenv("SDY_CONV_STAMPS")) {
+    if (!g_cstamps) SDY_HIP_TRY(hipMalloc(&g_cstamps, 64 * sizeof(unsigned long long)));
+    p.stamps = g_cstamps;
+  }
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -284,7 +343,7 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
     SDY_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
   const long ntiles = (long)((a->HW + CTN - 1) / CTN) * a->B;
-  const long want = 2L * n_cu;   // two workgroups per CU
+  const long want = n_cu;   // persistent: one workgroup per CU
   dim3 grid((unsigned)(ntiles < want ? ntiles : want));
   hipLaunchKernelGGL(conv_h3_kernel, grid, dim3(256), 0, stream, p);
   return sdy_launch_status();

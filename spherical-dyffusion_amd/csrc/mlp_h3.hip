@@ -86,11 +86,16 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int h = lane >> 5, l31 = lane & 31;
-  // Persistent workgroup (one per CU): tiles t = blockIdx.x, + gridDim.x, ...; tile t = (image z, 64-pixel slice n0).
+  // Persistent workgroup (one per CU): a contiguous range of tiles; tile t = (image z, 64-pixel slice n0).
   // The NEXT tile's pixels (and its norm coefficients) are requested into registers while this tile computes, so no
   // tile after the first waits for HBM, and there is no workgroup launch gap between tiles.
   const int tpi = (p.HW + TN - 1) / TN;
   const int ntiles = tpi * p.B;
+  // contiguous tile range per workgroup: a workgroup then crosses an image boundary at most ~once, so the per-image
+  // flush of the statistics (and the reload of per-image coefficients) is rare instead of every few tiles
+  const int t_per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * t_per;
+  const int t_end = (t_begin + t_per < ntiles) ? t_begin + t_per : ntiles;
   int z = 0, n0 = 0;
   bool full = true;
 
@@ -129,19 +134,19 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     Cf[2 * ME + tid] = p.add_a ? p.add_a[c] : 1.0f;
     Cf[3 * ME + tid] = p.add_a ? p.add_d[c] : 0.0f;
   };
-  if ((int)blockIdx.x < ntiles) load_coeffs((int)blockIdx.x / tpi);
+  if (t_begin < t_end) load_coeffs(t_begin / tpi);
   __syncthreads();
-  if ((int)blockIdx.x < ntiles) prefetch_x(blockIdx.x);
+  if (t_begin < t_end) prefetch_x(t_begin);
   // per-thread partial statistics of the output rows this thread stores (rows tid / 16 + 16 i), flushed per image
   float psum[16], psq[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { psum[i] = 0.0f; psq[i] = 0.0f; }
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = t_begin; tile < t_end; ++tile) {
   // lane-derived indices are laundered once per tile: otherwise every LDS address of the unrolled loops below is hoisted
   // out of the tile loop (~160 registers of loop invariants, spilled and reloaded from scratch inside the MFMA loops)
   asm volatile("" : "+v"(l31), "+v"(h), "+v"(q0), "+v"(o0));
-  const int tile_it = (tile - (int)blockIdx.x) / (int)gridDim.x;
+  const int tile_it = tile - t_begin;
   auto stamp = [&](int i) {
     if (p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= 2 && tile_it < 6)
       p.stamps[(tile_it - 2) * 16 + i] = __builtin_amdgcn_s_memtime();
@@ -404,8 +409,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   wp = wbase;   // the refills of the last block fetch block 0 again: the ring is ready for the next tile
   asm volatile("" : "+v"(wp));   // (laundered: otherwise the 16 refill addresses become loop invariants in VGPRs)
   {
-    const int nt = tile + (int)gridDim.x;
-    prefetch_x(nt < ntiles ? nt : tile);   // next tile's pixels; past the end a harmless re-read keeps it branch-free
+    const int nt = tile + 1;
+    prefetch_x(nt < t_end ? nt : tile);   // next tile's pixels; past the end a harmless re-read keeps it branch-free
   }
   fc2(NCH - 1, F_{});
   stamp(12);
@@ -471,8 +476,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     // few tiles this workgroup owns of one image; at the image's last tile here they are summed over the 16 lanes that
     // share a row (fp64) and added to the global (sum, sum of squares) with one atomic pair per row
     if (p.stats) {
-      const int nt = tile + (int)gridDim.x;
-      if (nt >= ntiles || nt / tpi != z) {   // workgroup-uniform
+      const int nt = tile + 1;
+      if (nt >= t_end || nt / tpi != z) {   // workgroup-uniform
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           double s1 = psum[i], s2 = psq[i];
@@ -494,8 +499,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   stamp(15);
   __syncthreads();   // the store phase is done with the LDS tile: the next x tile goes to the same storage
   {
-    const int nt = tile + (int)gridDim.x;
-    if (nt < ntiles && nt / tpi != z) {   // workgroup-uniform
+    const int nt = tile + 1;
+    if (nt < t_end && nt / tpi != z) {   // workgroup-uniform
       load_coeffs(nt / tpi);
       __syncthreads();
     }
