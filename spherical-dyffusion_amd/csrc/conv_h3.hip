@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
   float brow[16];            // bias of the rows this thread stores (rows tid / 16 + 16 i): the same for every tile
 #pragma unroll
   for (int i = 0; i < 16; ++i) brow[i] = p.bias ? p.bias[o0 + 16 * i] : 0.0f;
-  float psum[16], psq[16];   // statistics partials of those rows
+  double psum[16], psq[16];   // fp64: sums of fp32 per-tile partials are then exact, i.e. independent of the tiling   // statistics partials of those rows
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { psum[i] = 0.0f; psq[i] = 0.0f; }
+  for (int i = 0; i < 16; ++i) { psum[i] = 0.0; psq[i] = 0.0; }
 
   // Software pipeline over tiles (one workgroup per CU, full register budget).  Loads are issued ONE per step, never as
   // a burst: a wave that issues more than the CU can keep in flight stalls at issue until HBM has delivered (a burst of
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
         }
     __syncthreads();
     stamp(5);
-    if (c_ok) {
+    {
       float* og = p.out + (long)z * p.out_bs + roff;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -235,10 +235,13 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
         if (p.add_mode == 2) v += addv[i];
-        *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
-        addn[i] = *reinterpret_cast<const f32x4*>(anext + (long)(16 * i) * p.HW);   // next tile's addend row, one per step
-        psum[i] += (v.x + v.y) + (v.z + v.w);
-        psq[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        if (c_ok) *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
+        // next tile's addend row, one per step (every lane: a lane beyond a ragged tile's edge still owns pixels of the next)
+        addn[i] = *reinterpret_cast<const f32x4*>(anext + (long)(16 * i) * p.HW);
+        if (c_ok) {
+          psum[i] += (double)((v.x + v.y) + (v.z + v.w));
+          psq[i] += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+        }
       }
     }
 #pragma unroll
@@ -261,12 +264,12 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
             __hip_atomic_fetch_add(st, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(st + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          psum[i] = 0.0f; psq[i] = 0.0f;
+          psum[i] = 0.0; psq[i] = 0.0;
         }
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { psum[i] = 0.0f; psq[i] = 0.0f; }
+      for (int i = 0; i < 16; ++i) { psum[i] = 0.0; psq[i] = 0.0; }
     }
     stamp(7);
     __syncthreads();   // the store phase is done with the LDS tile

@@ -21,7 +21,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int LM = 192;          // rows per workgroup (>= lmax, nlat)
-constexpr int LKP = 256;         // LDS row length in halfs (k padded so that the MLP kernel's swizzle applies)
+constexpr int LKP = 192;         // LDS row length in halfs (384 B = 24 chunks of 8 k)
 constexpr int LTN = 64;          // columns per workgroup
 constexpr int LKS = 12;          // k-steps of 16
 constexpr int LRING = 8;         // groups in flight = one block of 4 k-steps x 2 m-tiles
@@ -38,11 +38,13 @@ struct LegParams {
   float out_scale;
 };
 
-__device__ __forceinline__ int lg_swz(int px) { return (px & 15) ^ (((px >> 4) & 1) * 3); }
-__device__ __forceinline__ int lg_off(int px, int c) { return px * LKP + (((c & 16) | ((c ^ lg_swz(px)) & 15)) << 3); }
+// 384-byte rows: the 16-byte slot of (px, chunk c) in the 256-byte bank row is (8 * (px & 1) + c) mod 16.  XOR-ing the low
+// 3 bits of c with (px >> 1) & 7 makes the 16 pixels of every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,
+// 28-31}) land on 16 different slots: conflict-free fragment reads, 48 KB per workgroup, three workgroups per CU.
+__device__ __forceinline__ int lg_off(int px, int c) { return px * LKP + (((c & ~7) | ((c ^ (px >> 1)) & 7)) << 3); }
 
-__global__ __launch_bounds__(192, 2) void leg_h3_kernel(const LegParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * LTN * LKP * 2];   // 64 KB
+__global__ __launch_bounds__(192, 3) void leg_h3_kernel(const LegParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * LTN * LKP * 2];   // 48 KB
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
   _Float16* Xs_lo = Xs_hi + LTN * LKP;
   float* Os = reinterpret_cast<float*>(smem);   // epilogue: [192 rows][64 cols] fp32 = 48 KB (aliases the x tile)

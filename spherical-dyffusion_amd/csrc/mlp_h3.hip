@@ -138,9 +138,9 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   __syncthreads();
   if (t_begin < t_end) prefetch_x(t_begin);
   // per-thread partial statistics of the output rows this thread stores (rows tid / 16 + 16 i), flushed per image
-  float psum[16], psq[16];
+  double psum[16], psq[16];   // fp64: sums of fp32 per-tile partials are then exact, i.e. independent of the tiling
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { psum[i] = 0.0f; psq[i] = 0.0f; }
+  for (int i = 0; i < 16; ++i) { psum[i] = 0.0; psq[i] = 0.0; }
 
   for (int tile = t_begin; tile < t_end; ++tile) {
   // lane-derived indices are laundered once per tile: otherwise every LDS address of the unrolled loops below is hoisted
@@ -467,8 +467,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         if (p.add) v += rres[i] * Cf[2 * ME + row] + Cf[3 * ME + row];
         *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
         if (p.stats) {
-          psum[i] += (v.x + v.y) + (v.z + v.w);
-          psq[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          psum[i] += (double)((v.x + v.y) + (v.z + v.w));
+          psq[i] += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
         }
       }
     }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
             __hip_atomic_fetch_add(st, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(st + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          psum[i] = 0.0f; psq[i] = 0.0f;
+          psum[i] = 0.0; psq[i] = 0.0;
         }
       }
     }

@@ -223,7 +223,7 @@ def test_conv1x1_split_fp16_mode(sdy, B, Cin, Cout, H, W):
         assert err < 5e-6, f"scale {s}: {err:.3e}"
 
 
-@pytest.mark.parametrize("B,H,W,drop", [(2, 8, 40, 0.0), (2, 8, 40, 0.1), (1, 45, 64, 0.1), (3, 6, 36, 0.25)])
+@pytest.mark.parametrize("B,H,W,drop", [(2, 8, 40, 0.0), (2, 8, 40, 0.1), (1, 45, 64, 0.1), (3, 6, 36, 0.25), (3, 87, 96, 0.1)])
 def test_mlp_fused_matches_fp64_and_unfused(sdy, B, H, W, drop):
     """sdy_mlp_h3 (hidden activation kept on the CU) == fc1 -> GELU -> dropout -> fc2 -> dropout -> drop-path scale ->
     + residual, against an fp64 restatement with the Philox oracle's masks, and against the two-launch path."""
@@ -295,9 +295,10 @@ def test_mlp_fused_rejects_other_shapes(sdy):
         sdy.ops.mlp_fused(x, torch.zeros(128, 64), torch.zeros(128), torch.zeros(64, 128), torch.zeros(64))
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 20, 36), (1, 45, 64), (3, 6, 36)])
+@pytest.mark.parametrize("B,H,W", [(2, 20, 36), (1, 45, 64), (3, 6, 36), (3, 87, 96)])
 def test_conv256_persistent_kernel_and_statistics(sdy, B, H, W):
-    """conv_h3_kernel (256 -> 256, persistent, weight as MFMA fragment stream) == the reference conv with the block's
+    """(the last shape has 393 tiles, ragged image edges included: several tiles per persistent workgroup)
+    conv_h3_kernel (256 -> 256, persistent, weight as MFMA fragment stream) == the reference conv with the block's
     inner-skip epilogue GELU(conv + bias + add), the encoder's post-add, and the InstanceNorm statistics of its output."""
     g = _gen(31)
     F = torch.nn.functional
