@@ -143,6 +143,12 @@ class MultiHorizonForecastingDYffusion(_BaseExperiment):
             if condition:
                 self._net.disable_inference_dropout()
 
+    def set_batch_offset(self, offset: int) -> None:
+        """Global index of the first trajectory of the batches that follow: keys the dropout streams of both networks, so a
+        trajectory's draws do not depend on how members / initial conditions are grouped or sharded."""
+        self.model.model.batch_offset = int(offset)                      # forecaster SFNO (no dropout today)
+        self.model.interpolator.model.batch_offset = int(offset)         # interpolator SFNO
+
     def get_preds_at_t_for_batch(self, batch: Dict[str, Tensor], horizon, split: str = "predict", ensemble: bool = False,
                                  is_autoregressive: bool = False, prepare_inputs: bool = True, **kwargs):
         """forecasting_multi_horizon.py:331-381 (cache_preds branch: DYffusion predicts all horizons at once)."""

@@ -40,6 +40,7 @@ def _build(hack=False, dropout=True, nlat=32, nlon=64, E=16, L=2, C=6, n_forc=2,
                     mask_fn=masks if dropout else None)
 
     oracle = OracleDYffusion(ora_f, ora_i, timesteps=horizon, hack_for_imprecise_interpolation=hack)
+    oracle._calls, oracle._masks = calls, masks      # the window-driver test replays per-member dropout streams
     return exp, oracle, cs, n_forc
 
 
@@ -136,3 +137,67 @@ def test_stepper_interpolating_prescriber_matches_oracle():
         err = rel_l2(out.gen_data[n], gen[n])
         assert err < TOL, f"{n}: {err:.3e}"
     assert abs(float(out.metrics["loss"]) - metrics["loss"]) < 1e-3 * metrics["loss"]
+
+
+def test_window_driver_batched_members_match_serial_oracle():
+    """run_inference with dropout ON: 3 members x 2 samples batched on the device over two windows == the oracle's
+    serial member loop, every trajectory (member m, sample s) drawing the Philox stream of global row m * n_sample + s."""
+    import types
+
+    import sdy_amd
+    from oracle.loop import run_inference as oracle_run
+    from oracle.stepper import run_on_batch
+
+    exp, oracle, cs, n_forc = _build(hack=True, dropout=True)
+    in_names = ["HGTsfc"] + [f"v{i}" for i in range(1, cs)]
+    out_names, forcing_names = in_names[1:], ["f0", "f1"]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n_sample, members, n_mem, n_total = 2, 3, 6, 12
+    means = {n: float(torch.randn((), generator=g)) for n in in_names + forcing_names}
+    stds = {n: float(torch.rand((), generator=g) + 0.5) for n in in_names + forcing_names}
+    series = {n: torch.randn(n_sample, n_total + 1, 32, 64, generator=g) * stds[n] + means[n] for n in in_names + forcing_names}
+    windows = [{k: v[:, i * n_mem:(i + 1) * n_mem + 1] for k, v in series.items()} for i in range(n_total // n_mem)]
+    tm = {k: torch.tensor(v) for k, v in means.items()}
+    ts = {k: torch.tensor(v) for k, v in stds.items()}
+    state = {"window": -1, "last_member": members}
+
+    class OMod:
+        true_horizon = 6
+        from contextlib import nullcontext
+        ema_scope = inference_dropout_scope = staticmethod(nullcontext)
+
+        def __init__(self):
+            self.cache = None
+
+        def get_preds_at_t_for_batch(self, batch, horizon, **kw):
+            if horizon == 1:
+                self.cache = oracle.sample(batch["dynamics"], static_condition=batch["static_condition"])
+            return {f"t{horizon}_preds_normed": self.cache[f"t{horizon}_preds"]}
+
+    def rob(data, m):
+        if m <= state["last_member"] and m == 0:
+            state["window"] += 1
+        state["last_member"] = m
+        oracle._calls["n"] = 10 * state["window"]          # 10 interpolator calls per horizon-6 pass = per window
+        oracle._masks.batch_offset = m * n_sample
+        return run_on_batch(data, OMod(), in_names, out_names, forcing_names, tm, ts, n_mem, None, hack=True)
+
+    wref, aref = oracle_run(windows, rob, n_total, n_mem, members)
+    got = []
+
+    class W:
+        def append_batch(self, target, prediction, start_timestep, start_sample, batch_times=None):
+            got.append((start_timestep, {k: v.clone() for k, v in prediction.items()}))
+
+    stepper = sdy_amd.MultiStepStepper(exp, in_names + forcing_names, out_names, forcing_names, means, stds, None)
+    loader = [types.SimpleNamespace(data=w, times=None) for w in windows]
+    sdy_amd.run_inference(None, stepper, loader, n_total, n_mem, members, writer=W())
+    assert [c[0] for c in got] == [c[0] for c in wref]
+    for (_, pr), (_, pg) in zip(wref, got):
+        for n in out_names:
+            assert pg[n].shape == pr[n].shape == (members, n_sample, pr[n].shape[2], 32, 64)
+            err = rel_l2(pg[n], pr[n])
+            assert err < TOL, f"{n}: {err:.3e}"
+    # members really differ (dropout streams are per trajectory)
+    v = got[0][1][out_names[0]]
+    assert float((v[0] - v[1]).abs().max()) > 1e-3

@@ -144,3 +144,59 @@ def test_stepper_vs_reference():
     v = "v1"
     ref = (torch.from_numpy(z["data::" + v]) - float(z["mean::" + v])) / float(z["std::" + v])
     assert rel_l2(out.target_data_norm[v], ref) < 1e-6
+
+
+def test_window_driver_vs_reference():
+    """sdy_amd.run_inference (members batched on the device, carried state resident on the device) vs the reference's
+    own run_inference + WindowStitcher: 2 windows x 6 steps, 2 samples, 2 members (fixture fx_loop_tiny)."""
+    import types
+
+    import sdy_amd
+
+    z, zw = gu.load("fx_loop_tiny"), gu.load("fx_stepper_tiny")
+    fcfg = SFNOConfig(**json.loads(str(z["fcfg"])))
+    icfg = SFNOConfig(**json.loads(str(z["icfg"])))
+    names = {k: json.loads(str(z[k])) for k in ("in_names", "out_names", "forcing_names")}
+    n_forc = len(names["forcing_names"])
+    fnet = _net(fcfg, fcfg.in_chans - n_forc, n_forc, gu.state_dict(zw, "f::"))
+    inet = _net(icfg, icfg.in_chans - n_forc, n_forc, gu.state_dict(zw, "i::"))
+    exp = sdy_amd.MultiHorizonForecastingDYffusion(
+        fnet, sdy_amd.InterpolationExperiment(inet, horizon=6), horizon=6,
+        diffusion_config=dict(hack_for_imprecise_interpolation=True, enable_interpolator_dropout=False))
+    pr = json.loads(str(z["prescriber"]))
+    stepper = sdy_amd.MultiStepStepper(
+        exp, names["in_names"] + names["forcing_names"], names["out_names"], names["forcing_names"],
+        means={k[6:]: float(z[k]) for k in z.files if k.startswith("mean::")},
+        stds={k[5:]: float(z[k]) for k in z.files if k.startswith("std::")},
+        prescriber=sdy_amd.Prescriber(pr["prescribed_name"], pr["mask_name"], pr["mask_value"], pr["interpolate"]))
+    series = {k[8:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("series::")}
+    n_total, n_mem, members = int(z["n_total"]), int(z["n_mem_steps"]), int(z["members"])
+    windows = [types.SimpleNamespace(data={k: v[:, i * n_mem:(i + 1) * n_mem + 1] for k, v in series.items()}, times=None)
+               for i in range(n_total // n_mem)]
+
+    for host in (False, True):
+        wcalls, acalls = [], []
+
+        class W:
+            def append_batch(self, target, prediction, start_timestep, start_sample, batch_times=None):
+                wcalls.append((start_timestep, {k: v.clone() for k, v in prediction.items()},
+                               {k: v.shape for k, v in target.items()}, next(iter(prediction.values())).device.type))
+
+        class A:
+            def record_batch(self, loss, target_data, gen_data, target_data_norm, gen_data_norm, i_time_start=0):
+                acalls.append((loss, i_time_start))
+
+        timers = sdy_amd.run_inference(A(), stepper, types.SimpleNamespace(loader=windows), n_total, n_mem, members,
+                                       writer=W(), host_outputs=host)
+        assert {"data_loading", "run_on_batch", "writer_and_aggregator"} <= set(timers)
+        assert [c[0] for c in wcalls] == [int(v) for v in z["starts"]]
+        assert [c[1] for c in acalls] == [int(v) for v in z["i_time_starts"]]
+        assert all(c[3] == ("cpu" if host else "cuda") for c in wcalls)
+        for w, (_, pred, tshapes, _) in enumerate(wcalls):
+            for n in names["out_names"]:
+                want = torch.from_numpy(z[f"pred{w}::{n}"])
+                assert pred[n].shape == want.shape
+                assert rel_l2(pred[n], want) < TOL_TIGHT, (w, n)
+            assert all(s[1] == want.shape[2] for s in tshapes.values())
+        for (loss, _), want in zip(acalls, z["losses"]):
+            assert abs(loss - float(want)) < 1e-4 * max(1.0, abs(float(want)))

@@ -136,6 +136,55 @@ def test_stepper_matches_reference():
             assert abs(metrics[k[8:]] - float(z[k])) < 1e-4 * max(1.0, abs(float(z[k]))), k
 
 
+def _loop_fixture():
+    z, zw = gu.load("fx_loop_tiny"), gu.load("fx_stepper_tiny")    # the loop fixture reuses the stepper fixture's weights
+    names = {k: json.loads(str(z[k])) for k in ("in_names", "out_names", "forcing_names")}
+    series = {k[8:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("series::")}
+    means = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mean::")}
+    stds = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("std::")}
+    n_total, n_mem, members = int(z["n_total"]), int(z["n_mem_steps"]), int(z["members"])
+    windows = [{k: v[:, i * n_mem:(i + 1) * n_mem + 1] for k, v in series.items()} for i in range(n_total // n_mem)]
+    return z, zw, names, series, means, stds, n_total, n_mem, members, windows
+
+
+def test_window_driver_matches_reference():
+    """oracle/loop.py vs the reference's own run_inference + WindowStitcher (fixture fx_loop_tiny: 2 windows x 6 steps,
+    2 samples, 2 members)."""
+    from contextlib import nullcontext
+
+    from oracle.loop import run_inference
+    from oracle.stepper import run_on_batch
+
+    z, zw, names, series, means, stds, n_total, n_mem, members, windows = _loop_fixture()
+    smp, _ = _sampler(_ZWrap(zw, hack=1))
+
+    class Mod:
+        true_horizon = 6
+        ema_scope = inference_dropout_scope = staticmethod(nullcontext)
+
+        def __init__(self):
+            self.cache = None
+
+        def get_preds_at_t_for_batch(self, batch, horizon, **kw):
+            if horizon == 1:
+                self.cache = smp.sample(batch["dynamics"], static_condition=batch["static_condition"])
+            return {f"t{horizon}_preds_normed": self.cache[f"t{horizon}_preds"]}
+
+    pres = json.loads(str(z["prescriber"]))
+    rob = lambda data, m: run_on_batch(data, Mod(), names["in_names"], names["out_names"], names["forcing_names"],  # noqa: E731
+                                       means, stds, n_mem, pres, hack=True)
+    wcalls, acalls = run_inference(windows, rob, n_total, n_mem, members)
+    assert [c[0] for c in wcalls] == [int(v) for v in z["starts"]]
+    assert [c[1] for c in acalls] == [int(v) for v in z["i_time_starts"]]
+    for w, (_, pred) in enumerate(wcalls):
+        for n in names["out_names"]:
+            want = torch.from_numpy(z[f"pred{w}::{n}"])
+            assert pred[n].shape == want.shape
+            assert rel_l2(pred[n], want) < 5e-6, (w, n)
+    for (loss, _), want in zip(acalls, z["losses"]):
+        assert abs(loss - float(want)) < 1e-4 * max(1.0, abs(float(want)))
+
+
 class _ZWrap:
     """npz view with an overridable scalar (the stepper fixture has no 'hack'/'dropout' entries)."""
 

@@ -260,6 +260,88 @@ def gen_stepper(tag="fx_stepper_tiny"):
     print(f"{tag}: loss {float(stepped.metrics['loss']):.5f}, gen vars {sorted(stepped.gen_data)[:3]}..., saved")
 
 
+def gen_loop(tag="fx_loop_tiny"):
+    """The reference's own window driver `run_inference` + `WindowStitcher` (src/ace_inference/inference/loop.py:26-264):
+    two windows of 6 steps, 2 samples, 2 ensemble members (dropout off: the fixture pins the stitching / carry-over /
+    stacking logic, the stochastic part is covered by the device-vs-oracle tests)."""
+    import types
+
+    import src.ace_inference.inference.loop as L
+    from src.ace_inference.core.aggregator.null import NullAggregator
+    from src.ace_inference.core.normalizer import StandardNormalizer
+    from src.ace_inference.core.prescriber import Prescriber
+    from src.ace_inference.core.stepper_multistep import run_on_batch_multistep
+    from src.ace_inference.training.utils.darcy_loss import LpLoss
+    from src.utilities.packer import Packer
+
+    C, n_forc, H, W, E, Lr = 6, 2, 32, 64, 16, 2
+    fc, ipol, fcfg, icfg, fsd, isd, cs = build_experiments(C, n_forc, H, W, E, Lr, True, False, 11, 22)
+    in_names = ["HGTsfc"] + [f"v{i}" for i in range(1, cs)]
+    out_names = in_names[1:]
+    forcing_names = [f"f{i}" for i in range(n_forc)]
+    mask_name = "ocean_fraction"
+    n_total, n_mem_steps, B, members = 12, 6, 2, 2
+    g = torch.Generator(device="cpu").manual_seed(777)
+    names = in_names + forcing_names
+    means = {n: torch.randn((), generator=g) * 3.0 for n in names}
+    stds = {n: torch.rand((), generator=g) * 2.0 + 0.5 for n in names}
+    series = {n: torch.randn(B, n_total + 1, H, W, generator=g) * stds[n] + means[n] for n in names}
+    series[mask_name] = torch.rand(B, n_total + 1, H, W, generator=g)
+    pres = Prescriber(prescribed_name="v2", mask_name=mask_name, mask_value=1, interpolate=False)
+    axis = -3
+
+    class _Stepper:   # what run_inference needs of MultiStepStepper: .module and .run_on_batch
+        module = fc
+
+        def run_on_batch(self, data, optimization, n_forward_steps=1, aggregator=None):
+            return run_on_batch_multistep(
+                data=data, module=fc, normalizer=StandardNormalizer(means, stds), in_packer=Packer(in_names, axis=axis),
+                out_packer=Packer(out_names, axis=axis), forcings_packer=Packer(forcing_names, axis=axis),
+                optimization=optimization, loss_obj=LpLoss(), prescriber=pres,
+                aggregator=aggregator if aggregator is not None else NullAggregator(), n_forward_steps=n_forward_steps)
+
+    class _Times:   # the only thing the loop does with xr.DataArray times: .isel(time=slice(1, None))
+        def __init__(self, idx):
+            self.idx = list(idx)
+
+        def isel(self, time):
+            return _Times(self.idx[time])
+
+    windows = [types.SimpleNamespace(data={k: v[:, i * n_mem_steps:(i + 1) * n_mem_steps + 1].clone() for k, v in series.items()},
+                                     times=_Times(range(i * n_mem_steps, (i + 1) * n_mem_steps + 1)))
+               for i in range(n_total // n_mem_steps)]
+    data = types.SimpleNamespace(loader=windows, sigma_coordinates=None)
+    rec = []
+
+    class _Writer:
+        def append_batch(self, target, prediction, start_timestep, start_sample, batch_times=None):
+            rec.append((int(start_timestep), {k: v.clone() for k, v in prediction.items()},
+                        {k: v.clone() for k, v in target.items()}))
+
+    losses = []
+
+    class _Agg:   # (with the reference's NullAggregator an ensemble run dies on `stepped.metrics["loss"]`, loop.py:145,209)
+        def record_batch(self, loss, target_data, gen_data, target_data_norm, gen_data_norm, i_time_start=0):
+            losses.append((float(loss), int(i_time_start)))
+
+    L.compute_derived_quantities = lambda d, s: d     # derived variables are outside the fixture's scope
+    L.run_inference(_Agg(), _Stepper(), data, n_total, n_mem_steps, members, "cpu", writer=_Writer())
+    out = dict(in_names=json.dumps(in_names), out_names=json.dumps(out_names), forcing_names=json.dumps(forcing_names),
+               prescriber=json.dumps(pres.get_state()), n_total=np.array(n_total), n_mem_steps=np.array(n_mem_steps),
+               members=np.array(members), fcfg=json.dumps(fcfg.__dict__), icfg=json.dumps(icfg.__dict__),
+               starts=np.array([r[0] for r in rec]), losses=np.array([l[0] for l in losses]),
+               i_time_starts=np.array([l[1] for l in losses]))
+    # network weights: identical to fx_stepper_tiny.npz (same build_experiments seeds), not stored twice
+    out.update({"series::" + k: v.numpy() for k, v in series.items()})
+    out.update({"mean::" + k: v.numpy() for k, v in means.items()})
+    out.update({"std::" + k: v.numpy() for k, v in stds.items()})
+    for w, (st, pred, tgt) in enumerate(rec):
+        out.update({f"pred{w}::" + k: v.numpy() for k, v in pred.items()})
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"{tag}: writer calls at {[r[0] for r in rec]}, prediction shapes "
+          f"{[tuple(next(iter(r[1].values())).shape) for r in rec]}, saved")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # C1: one block, 32x64, 8 channels (BASELINE.json configs[0])
@@ -278,5 +360,6 @@ if __name__ == "__main__":
     with open(os.path.join(OUT, "fx_trace.json"), "w") as f:
         json.dump(t1, f)
     gen_stepper()
+    gen_loop()
     sizes = {n: os.path.getsize(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT))}
     print(sizes)

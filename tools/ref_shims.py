@@ -156,8 +156,22 @@ def install():
             return TensorDict({n: (v.to(*a, **k) if hasattr(v, "to") else v) for n, v in self.items()})
 
     _module("tensordict", TensorDict=TensorDict, TensorDictBase=TensorDict)
-    _module("wandb", run=None, Table=_Anything, Image=_Anything, Video=_Anything)
+    _module("wandb", run=None, Table=_Anything, Image=_Anything, Video=_Anything, Histogram=_Anything, Object3D=_Anything,
+            Audio=_Anything, Html=_Anything, plot=_Anything)
     # imported (not used on the sampling path) by src/ace_inference/core/stepper_multistep.py and friends
+    def _curry(f=None, *a, **k):   # toolz.curry as used by derived_variables.py: `@register()` with no arguments
+        if f is None or not callable(f):
+            return lambda g: _curry(g)
+        import functools
+
+        @functools.wraps(f)
+        def wrapper(*args, **kwargs):
+            if not args and not kwargs:
+                return wrapper
+            return f(*args, **kwargs)
+        return wrapper
+
+    _module("toolz", curry=_curry)
     _module("dacite", from_dict=lambda *a, **k: None, Config=_Anything)
     _module("netCDF4", Dataset=_Anything)
     _module("h5py", File=_Anything)
