@@ -200,3 +200,58 @@ def test_window_driver_vs_reference():
             assert all(s[1] == want.shape[2] for s in tshapes.values())
         for (loss, _), want in zip(acalls, z["losses"]):
             assert abs(loss - float(want)) < 1e-4 * max(1.0, abs(float(want)))
+
+
+def test_checkpoint_ingestion_reproduces_reference_stepper():
+    """checkpoint.stepper_from_state on Lightning-shaped checkpoints (key layout + hyper-parameters recorded from the
+    reference's experiments, fx_ckpt_layout.json; weights of fx_stepper_tiny): the loaded stepper reproduces the
+    reference's run_on_batch_multistep outputs, from the raw weights and from the EMA shadows (raw weights corrupted)."""
+    import os
+
+    import sdy_amd
+
+    z = gu.load("fx_stepper_tiny")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "fx_ckpt_layout.json")) as f:
+        lay = json.load(f)
+    fsd, isd = gu.state_dict(z, "f::"), gu.state_dict(z, "i::")
+    names = {k: json.loads(str(z[k])) for k in ("in_names", "out_names", "forcing_names")}
+    pr = json.loads(str(z["prescriber"]))
+
+    def ckpt(kind, weights, prefix, ema):
+        hp = json.loads(json.dumps(lay[kind]["hyper_parameters"]))
+        hp["use_ema"] = ema
+        if kind == "forecaster":     # the data module of the stepper fixture (HGTsfc input-only, prescriber)
+            hp["datamodule_config"].update(in_names=names["in_names"], out_names=names["out_names"],
+                                           forcing_names=names["forcing_names"],
+                                           prescriber=dict(_target_="x.Prescriber", **pr))
+            hp["diffusion_config"]["enable_interpolator_dropout"] = False
+        else:
+            hp["model_config"].update(dropout_mlp=0.0, drop_path_rate=0.0)
+        keys = lay[kind]["state_dict_keys"]
+        sd = {}
+        for k in keys:
+            w = weights.get(k[len(prefix):])
+            if w is None:    # fc2 is index 2 (no dropout layer) in the stepper fixture, index 3 in the layout fixture
+                w = weights[k[len(prefix):].replace("mlp.fwd.3", "mlp.fwd.2")]
+                k = k.replace("mlp.fwd.3", "mlp.fwd.2")
+            sd[k] = w.clone()
+        if ema:
+            handle = "model." if kind == "forecaster" else ""
+            for k in list(sd):
+                sd["model_ema." + (handle + k[len(prefix):]).replace(".", "")] = sd[k].clone()
+                sd[k] = torch.randn_like(sd[k])          # the raw weights must not be used
+            sd["model_ema.decay"] = torch.tensor(0.9999)
+        return {"hyper_parameters": hp, "state_dict": sd}
+
+    means = {k[6:]: float(z[k]) for k in z.files if k.startswith("mean::")}
+    stds = {k[5:]: float(z[k]) for k in z.files if k.startswith("std::")}
+    data = {k[6:]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("data::")}
+    n_steps = int(z["n_steps"])
+    for ema in (False, True):
+        stepper = sdy_amd.checkpoint.stepper_from_state(ckpt("forecaster", fsd, "model.model.", ema),
+                                                        ckpt("interpolator", isd, "model.", ema), means, stds, (32, 64))
+        assert stepper.prescriber is not None and stepper.prescriber.prescribed_name == pr["prescribed_name"]
+        out = stepper.run_on_batch(data, None, n_forward_steps=n_steps)
+        for n in names["out_names"]:
+            e = rel_l2(out.gen_data[n], torch.from_numpy(z["gen::" + n]))
+            assert e < TOL_TIGHT, f"ema={ema} {n}: {e:.3e}"

@@ -124,3 +124,41 @@ def test_stepper_host_validation(sdy):
             true_horizon = 6
             model = None
         sdy.MultiStepStepper(M(), ["a", "f"], ["a"], ["f"], {}, {}).run_on_batch({"a": torch.zeros(1, 2, 4, 8)}, None, 1)
+
+
+def test_checkpoint_weight_selection_follows_lightning_layout():
+    """checkpoint.select_weights against the key layout of the reference's own experiments (fx_ckpt_layout.json: state_dict
+    keys and LitEma buffer names recorded from the reference): raw vs EMA selection, interpolator keys skipped."""
+    import json
+    import os
+
+    import torch
+
+    from sdy_amd.checkpoint import select_weights
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "fx_ckpt_layout.json")) as f:
+        lay = json.load(f)
+    fk = lay["forecaster"]["state_dict_keys"]
+    assert all(k.startswith("model.model.") for k in fk)
+    sd = {k: torch.full((2,), float(i)) for i, k in enumerate(fk)}
+    sd["model.interpolator.model.pos_embed"] = torch.zeros(2)          # stray interpolator key: ignored under model.model.
+    for name, buf in lay["forecaster"]["ema_names"].items():             # name is relative to experiment.model (DYffusion)
+        sd["model_ema." + buf] = sd["model." + name] + 1000.0
+    sd["model_ema.decay"] = torch.tensor(0.9999)
+    sd["model_ema.num_updates"] = torch.tensor(7)
+    raw = select_weights(sd, "model.model.", "model.", use_ema=False)
+    ema = select_weights(sd, "model.model.", "model.", use_ema=True)
+    assert sorted(raw) == sorted(k[len("model.model."):] for k in fk) == sorted(ema)
+    assert all(float(ema[k][0]) == float(raw[k][0]) + 1000.0 for k in raw)
+    # interpolation experiment: the network is experiment.model, EMA names relative to it
+    ik = lay["interpolator"]["state_dict_keys"]
+    isd = {k: torch.full((1,), float(i)) for i, k in enumerate(ik)}
+    for k in ik:
+        isd["model_ema." + k[len("model."):].replace(".", "")] = isd[k] - 500.0
+    iema = select_weights(isd, "model.", "", use_ema=True)
+    assert all(float(iema[k[len("model."):]][0]) == float(isd[k][0]) - 500.0 for k in ik)
+    import pytest
+    with pytest.raises(KeyError):
+        select_weights({"foo.bar": torch.zeros(1)}, "model.model.", "model.", False)
+    with pytest.raises(KeyError):
+        select_weights({k: v for k, v in sd.items() if "model_ema" not in k}, "model.model.", "model.", True)

@@ -342,6 +342,40 @@ def gen_loop(tag="fx_loop_tiny"):
           f"{[tuple(next(iter(r[1].values())).shape) for r in rec]}, saved")
 
 
+def gen_ckpt_layout(tag="fx_ckpt_layout"):
+    """What a Lightning checkpoint of the two reference experiments looks like (no tensors: key names and
+    hyper-parameters only): `state_dict` keys of `MultiHorizonForecastingDYffusion` / `InterpolationExperiment`, the
+    `LitEma` buffer name of every parameter (src/models/modules/ema.py:20-27) and the `hyper_parameters` dictionaries
+    (`_base_experiment.py:75-100`).  The weights of the matching fixture are those of fx_stepper_tiny."""
+    from src.models.modules.ema import LitEma
+
+    fc, ipol, fcfg, icfg, fsd, isd, cs = build_experiments(6, 2, 32, 64, 16, 2, True, True, 11, 22)
+
+    def clean(o):
+        if isinstance(o, dict):
+            return {k: clean(v) for k, v in o.items() if k != "interpolator"}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, (int, float, str, bool)) or o is None:
+            return o
+        return None
+
+    def ema_map(handle):
+        e = LitEma(handle, decay=0.9999)
+        return dict(e.m_name2s_name)
+
+    out = {
+        "forecaster": {"hyper_parameters": clean(dict(fc.hparams)),
+                       "state_dict_keys": [k for k in fc.state_dict().keys() if not k.startswith("model.interpolator")],
+                       "ema_names": ema_map(fc.model), "ema_extra": ["decay", "num_updates"]},
+        "interpolator": {"hyper_parameters": clean(dict(ipol.hparams)), "state_dict_keys": list(ipol.state_dict().keys()),
+                         "ema_names": ema_map(ipol.model), "ema_extra": ["decay", "num_updates"]},
+    }
+    with open(os.path.join(OUT, f"{tag}.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"{tag}: {len(out['forecaster']['state_dict_keys'])} + {len(out['interpolator']['state_dict_keys'])} keys, saved")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # C1: one block, 32x64, 8 channels (BASELINE.json configs[0])
@@ -361,5 +395,6 @@ if __name__ == "__main__":
         json.dump(t1, f)
     gen_stepper()
     gen_loop()
+    gen_ckpt_layout()
     sizes = {n: os.path.getsize(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT))}
     print(sizes)
