@@ -302,6 +302,15 @@ int sdy_init_timeline(const sdy_var_table* vars, int T1, int B, int HW, float* c
 int sdy_lp_rel_terms(const float* gen, const sdy_var_table* targets, int t, int T1, int B, int HW, double* terms,
                      void* stream);
 
+/* On-device ensemble diagnostics (src/ace_inference/core/metrics.py:32-54 weighted_mean, :107-132 RMSE, :135-144
+ * ensemble_spread, :158-208 weighted_crps, :84-104 bias), one pass over the ensemble.
+ *   pred: dev, member m of plane p at pred + m*member_stride + p*HW (M <= 64 members); truth: dev (n_planes, HW);
+ *   weights: dev (HW) area weights (any normalisation: the caller divides by their sum)
+ *   out[p][0..3] += sum_w (mean_m x - truth)^2 | sum_w var_m(x) (unbiased) | sum_w fair CRPS | sum_w (mean_m x - truth)
+ * out: dev double [n_planes*4], zeroed by the caller. */
+int sdy_ensemble_metrics(const float* pred, const float* truth, const float* weights, int M, long member_stride,
+                         int n_planes, int HW, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

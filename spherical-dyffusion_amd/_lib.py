@@ -137,6 +137,8 @@ SIGNATURES = {
     "sdy_instnorm_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_conv1x1": (C.c_int, [C.POINTER(SdyConvArgs), C.c_void_p]),
+    "sdy_ensemble_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p]),
     "sdy_instnorm_from_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_long, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_mlp_h3_supported": (C.c_int, [C.c_int, C.c_int]),

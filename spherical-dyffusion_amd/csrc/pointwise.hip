@@ -365,7 +365,74 @@ __global__ __launch_bounds__(256) void lp_terms_kernel(const float* __restrict__
   }
 }
 
+// ---- on-device ensemble diagnostics (src/ace_inference/core/metrics.py:32-54,107-208) -------------------------------
+// One pass over the ensemble: per (sample, time) plane p and pixel, the M member values stay in registers; the plane's
+// area-weighted sums of  (mean_m x - truth)^2,  var_m(x) (unbiased),  fair CRPS = mean_m|x - truth| - sum_{i,j}|x_i - x_j|
+// / (2 M (M - 1))  and  (mean_m x - truth)  are accumulated in fp64 (block reduce + one atomic per block and quantity).
+constexpr int ENS_MAX = 64;
+__global__ __launch_bounds__(256) void ens_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
+                                                           const float* __restrict__ w, int M, long member_stride, int HW,
+                                                           double* __restrict__ out) {
+  const int pl = blockIdx.y;
+  const float* pp = pred + (long)pl * HW;
+  const float* tp = truth + (long)pl * HW;
+  double a_se = 0.0, a_var = 0.0, a_crps = 0.0, a_bias = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float x[ENS_MAX];
+    float mean = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < M; ++m) {
+      x[m] = pp[(long)m * member_stride + i];
+      mean += x[m];
+    }
+    mean /= (float)M;
+    const float t = tp[i], wi = w[i];
+    float var = 0.f, skill = 0.f, pair = 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float d = x[m] - mean;
+      var += d * d;
+      skill += fabsf(x[m] - t);
+      for (int n = m + 1; n < M; ++n) pair += fabsf(x[m] - x[n]);
+    }
+    var = M > 1 ? var / (float)(M - 1) : 0.f;
+    const float crps = M > 1 ? skill / (float)M - pair / (float)(M * (M - 1)) : skill;   // 2 * pair / (2 M (M-1))
+    const float e = mean - t;
+    a_se += (double)wi * e * e;
+    a_var += (double)wi * var;
+    a_crps += (double)wi * crps;
+    a_bias += (double)wi * e;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a_se += __shfl_down(a_se, off, 64);
+    a_var += __shfl_down(a_var, off, 64);
+    a_crps += __shfl_down(a_crps, off, 64);
+    a_bias += __shfl_down(a_bias, off, 64);
+  }
+  __shared__ double sh[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[wave] = a_se; sh[4 + wave] = a_var; sh[8 + wave] = a_crps; sh[12 + wave] = a_bias;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int q = threadIdx.x;
+    atomicAdd(&out[4 * pl + q], sh[4 * q] + sh[4 * q + 1] + sh[4 * q + 2] + sh[4 * q + 3]);
+  }
+}
+
 }  // namespace
+
+extern "C" int sdy_ensemble_metrics(const float* pred, const float* truth, const float* weights, int M, long member_stride,
+                                    int n_planes, int HW, double* out, void* stream) {
+  if (!pred || !truth || !weights || !out || M < 1 || n_planes < 1 || HW < 1) return SDY_ERR_ARG;
+  if (M > ENS_MAX) return SDY_ERR_UNSUPPORTED;
+  int gx = (HW + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(ens_metrics_kernel, dim3(gx, n_planes), dim3(256), 0, (hipStream_t)stream, pred, truth, weights, M,
+                     member_stride, HW, out);
+  return sdy_launch_status();
+}
 
 extern "C" int sdy_norm_pack(const sdy_var_table* vars, int t, int T1, int B, int HW, float* out, void* stream) {
   if (!vars || !out || vars->nvars < 1 || vars->nvars > SDY_MAX_VARS || t < 0 || t >= T1 || B <= 0 || HW <= 0) return SDY_ERR_ARG;

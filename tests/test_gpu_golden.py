@@ -255,3 +255,29 @@ def test_checkpoint_ingestion_reproduces_reference_stepper():
         for n in names["out_names"]:
             e = rel_l2(out.gen_data[n], torch.from_numpy(z["gen::" + n]))
             assert e < TOL_TIGHT, f"ema={ema} {n}: {e:.3e}"
+
+
+def test_ensemble_metrics_vs_reference():
+    """sdy_amd.metrics.ensemble_metrics (one HIP pass over the ensemble) vs the reference's core/metrics.py outputs."""
+    import sdy_amd
+
+    z = gu.load("fx_metrics")
+    w = sdy_amd.metrics.spherical_area_weights(torch.from_numpy(z["lats"]), z["truth"].shape[-1])
+    assert torch.allclose(w, torch.from_numpy(z["weights"]), rtol=1e-6, atol=0)
+    got = sdy_amd.metrics.ensemble_metrics(torch.from_numpy(z["truth"]).cuda(), torch.from_numpy(z["pred"]).cuda(), w)
+    for k in ("rmse", "spread", "spread_skill_ratio", "crps", "bias"):
+        want = torch.from_numpy(z[k]).double()
+        assert got[k].shape == want.shape
+        assert torch.allclose(got[k].cpu(), want, rtol=2e-5, atol=2e-6), (k, got[k].cpu(), want)
+    # 25 members on the model grid against the oracle
+    from oracle.metrics import ensemble_metrics as oracle_metrics
+    g = torch.Generator(device="cpu").manual_seed(3)
+    truth = torch.randn(2, 180, 360, generator=g)
+    pred = truth[None] + 0.5 * torch.randn(25, 2, 180, 360, generator=g)
+    w = sdy_amd.metrics.spherical_area_weights(torch.linspace(-89.5, 89.5, 180), 360)
+    got = sdy_amd.metrics.ensemble_metrics(truth.cuda(), pred.cuda(), w)
+    ref = oracle_metrics(truth, pred, w)
+    for k in ref:
+        assert torch.allclose(got[k].cpu(), ref[k], rtol=1e-5, atol=1e-7), k
+    with pytest.raises(RuntimeError):
+        sdy_amd.metrics.ensemble_metrics(truth, pred, w)     # CPU tensors: no fallback

@@ -194,3 +194,15 @@ class _ZWrap:
 
     def __getitem__(self, k):
         return self.over[k] if k in self.over else self.z[k]
+
+
+def test_ensemble_metrics_match_reference():
+    """oracle/metrics.py vs the reference's own core/metrics.py functions (fixture fx_metrics)."""
+    from oracle.metrics import ensemble_metrics
+
+    z = gu.load("fx_metrics")
+    got = ensemble_metrics(torch.from_numpy(z["truth"]), torch.from_numpy(z["pred"]), torch.from_numpy(z["weights"]))
+    for k in ("rmse", "spread", "spread_skill_ratio", "crps", "bias"):
+        want = torch.from_numpy(z[k]).double()
+        assert got[k].shape == want.shape
+        assert torch.allclose(got[k], want, rtol=2e-5, atol=1e-6), k

@@ -376,6 +376,27 @@ def gen_ckpt_layout(tag="fx_ckpt_layout"):
     print(f"{tag}: {len(out['forecaster']['state_dict_keys'])} + {len(out['interpolator']['state_dict_keys'])} keys, saved")
 
 
+def gen_metrics(tag="fx_metrics"):
+    """The reference's own ensemble diagnostics (src/ace_inference/core/metrics.py) on a small ensemble."""
+    from src.ace_inference.core import metrics as M
+
+    g = torch.Generator(device="cpu").manual_seed(31)
+    E, S, T, H, W = 5, 2, 3, 16, 32
+    lats = torch.linspace(-84.375, 84.375, H)
+    w = M.spherical_area_weights(lats, W)
+    truth = torch.randn(S, T, H, W, generator=g) * 2.0 + 1.0
+    pred = truth[None] + torch.randn(E, S, T, H, W, generator=g) * 0.7 + 0.1
+    dim = (-2, -1)
+    out = dict(lats=lats.numpy(), weights=w.numpy(), truth=truth.numpy(), pred=pred.numpy(),
+               rmse=M.root_mean_squared_error(truth, pred.mean(0), w, dim=dim).numpy(),
+               spread=M.ensemble_spread(pred, w, dim=dim).numpy(),
+               spread_skill_ratio=M.spread_skill_ratio(truth, pred, w, dim=dim).numpy(),
+               crps=M.weighted_crps(truth, pred, w, dim=dim).numpy(),
+               bias=M.weighted_mean_bias(truth, pred.mean(0), w, dim=dim).numpy())
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"{tag}: crps[0] {out['crps'][0]}, saved")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # C1: one block, 32x64, 8 channels (BASELINE.json configs[0])
@@ -396,5 +417,6 @@ if __name__ == "__main__":
     gen_stepper()
     gen_loop()
     gen_ckpt_layout()
+    gen_metrics()
     sizes = {n: os.path.getsize(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT))}
     print(sizes)
