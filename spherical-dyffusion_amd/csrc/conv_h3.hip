@@ -17,6 +17,9 @@
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// explicit global address space: a pointer laundered through an empty asm loses its provenance, and hipcc then emits
+// FLAT loads, which also count in lgkmcnt -- every LDS-fragment wait became lgkmcnt(0), i.e. a wait for the weight refills
+typedef const f16x8 __attribute__((address_space(1)))* wptr_t;
 
 namespace {
 
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
   const int t_end = (t_begin + t_per < ntiles) ? t_begin + t_per : ntiles;
 
   f16x8 r_hi[CRING], r_lo[CRING];
-  const f16x8* __restrict__ wbase = p.w + (size_t)wave * CGPW * CGROUP + lane;
-  const f16x8* __restrict__ wp = wbase;
+  const wptr_t wbase = (wptr_t)(p.w + (size_t)wave * CGPW * CGROUP + lane);
+  wptr_t wp = wbase;
 #pragma unroll
   for (int s = 0; s < CRING; ++s) {
     r_hi[s] = wp[s * CGROUP];

@@ -32,6 +32,9 @@
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// explicit global address space: a pointer laundered through an empty asm loses its provenance, and hipcc then emits
+// FLAT loads, which also count in lgkmcnt -- every LDS-fragment wait became lgkmcnt(0), i.e. a wait for the weight refills
+typedef const f16x8 __attribute__((address_space(1)))* wptr_t;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -101,8 +104,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 
   // ---- weight ring: slot s holds group s of the block being consumed; refilled for the next block right after its use
   f16x8 r_hi[RING], r_lo[RING];
-  const f16x8* __restrict__ wbase = p.w + (size_t)wave * (NGROUPS + RING) * GROUP_F8 + lane;
-  const f16x8* __restrict__ wp = wbase;
+  const wptr_t wbase = (wptr_t)(p.w + (size_t)wave * (NGROUPS + RING) * GROUP_F8 + lane);
+  wptr_t wp = wbase;
 #pragma unroll
   for (int s = 0; s < RING; ++s) {
     r_hi[s] = wp[s * GROUP_F8];
@@ -237,9 +240,17 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks], bh[c][j], acc[j], 0, 0, 0);
       r_hi[ks] = wp[ks * GROUP_F8];
       r_lo[ks] = wp[ks * GROUP_F8 + 64];
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next k-step's LDS reads first
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // then the MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // then the ring refill
+      // one non-MFMA instruction per MFMA: each MFMA shadows ~24 issue cycles, bunched LDS reads / loads do not hide
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // next k-step's LDS read
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ring refill
+      }
       __builtin_amdgcn_sched_barrier(0);   // keep the refill here: the scheduler otherwise sinks it next to its use
     }
     wp += RING * GROUP_F8;
@@ -271,41 +282,49 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s.v[r] = acc[j][4 * g4 + r] * p.s1 + bv[g4][r];
         break;
+      // exact-erf GELU times SX in 20 instructions per value: with z = |v| / sqrt(2), t = 1 / (1 + p z) and
+      // Q = SX * erfc(z) / 2 = t * poly(t) * exp(-z^2) (A&S 7.1.26, coefficients pre-multiplied by SX / 2),
+      //   SX * gelu(v) = (SX/2) v + |v| (SX/2 - Q)          (both signs of v, no compare / select)
       case 1:
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float zz = fabsf(s.v[r]) * 0.70710678118654752440f;
-          s.t[r] = fmaf(0.3275911f, zz, 1.0f);
-          s.e[r] = -zz * zz * 1.44269504088896340736f;
+          s.t[r] = fmaf(0.3275911f * 0.70710678118654752440f, fabsf(s.v[r]), 1.0f);
+          s.e[r] = s.v[r] * s.v[r];
         }
         break;
-      case 2: s.t[0] = __builtin_amdgcn_rcpf(s.t[0]); s.t[1] = __builtin_amdgcn_rcpf(s.t[1]); break;
-      case 3: s.t[2] = __builtin_amdgcn_rcpf(s.t[2]); s.t[3] = __builtin_amdgcn_rcpf(s.t[3]); break;
+      case 2:
+        s.t[0] = __builtin_amdgcn_rcpf(s.t[0]); s.t[1] = __builtin_amdgcn_rcpf(s.t[1]);
+        s.e[0] *= -0.5f * 1.44269504088896340736f; s.e[1] *= -0.5f * 1.44269504088896340736f;
+        break;
+      case 3:
+        s.t[2] = __builtin_amdgcn_rcpf(s.t[2]); s.t[3] = __builtin_amdgcn_rcpf(s.t[3]);
+        s.e[2] *= -0.5f * 1.44269504088896340736f; s.e[3] *= -0.5f * 1.44269504088896340736f;
+        break;
       case 4: s.e[0] = __builtin_amdgcn_exp2f(s.e[0]); s.e[1] = __builtin_amdgcn_exp2f(s.e[1]); break;
       case 5: s.e[2] = __builtin_amdgcn_exp2f(s.e[2]); s.e[3] = __builtin_amdgcn_exp2f(s.e[3]); break;
       case 6:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s.q[r] = fmaf(fmaf(1.061405429f, s.t[r], -1.453152027f), s.t[r], 1.421413741f);
+        for (int r = 0; r < 4; ++r)
+          s.q[r] = fmaf(fmaf(1.061405429f * (0.5f * SX), s.t[r], -1.453152027f * (0.5f * SX)), s.t[r], 1.421413741f * (0.5f * SX));
         break;
       case 7:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s.q[r] = fmaf(fmaf(s.q[r], s.t[r], -0.284496736f), s.t[r], 0.254829592f);
+        for (int r = 0; r < 4; ++r)
+          s.q[r] = fmaf(fmaf(s.q[r], s.t[r], -0.284496736f * (0.5f * SX)), s.t[r], 0.254829592f * (0.5f * SX));
         break;
       case 8:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s.q[r] = 0.5f * (s.q[r] * s.t[r] * s.e[r]);   // erfc(z) / 2
+        for (int r = 0; r < 4; ++r) s.q[r] = s.q[r] * s.t[r] * s.e[r];   // Q
         break;
       case 9:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s.v[r] = s.v[r] >= 0.0f ? s.v[r] * (1.0f - s.q[r]) : s.v[r] * s.q[r];
+        for (int r = 0; r < 4; ++r) s.v[r] = fmaf(0.5f * SX, s.v[r], fabsf(s.v[r]) * (0.5f * SX - s.q[r]));
         break;
       case 10: {
-        const uint32_t words[4] = {s.c0, s.c1, s.c2, s.c3};
+        if (do_drop) {
+          const uint32_t words[4] = {s.c0, s.c1, s.c2, s.c3};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s.v[r];
-          if (do_drop) v = (words[r] >= p.drop_thr) ? v * p.drop_scale : 0.0f;
-          s.v[r] = v * SX;
+          for (int r = 0; r < 4; ++r) s.v[r] = (words[r] >= p.drop_thr) ? s.v[r] * p.drop_scale : 0.0f;
         }
         break;
       }
