@@ -15,3 +15,9 @@ int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, cons
                        int B, int C, int K, int mtr, hipStream_t stream);
 int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
                        hipStream_t stream);
+
+// nlon = 360 specialisation (fft360.hip); SDY_ERR_UNSUPPORTED when the shape does not fit
+int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
+                          int B, int C, int K, int mtr, hipStream_t stream);
+int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
+                          int mtr, hipStream_t stream);

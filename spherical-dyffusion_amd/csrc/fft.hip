@@ -12,6 +12,7 @@
 // Fused on the way in: the per-(b,c) affine a*x+d (InstanceNorm + time scale/shift, sfnonet.py:292,298-299) and the
 // optional store of the normalised field (the block's residual); on the way out: the filter bias
 // (s2convolutions.py:188-189).
+#include <cstdlib>
 #include "common.h"
 #include "fft.h"
 
@@ -420,10 +421,20 @@ __global__ __launch_bounds__(NT) void irfft_kernel(const SdyFftDesc f, const flo
 
 size_t fft_smem_bytes(const SdyFftDesc& f) { return ((size_t)4 * CB * f.S + 2 * f.n + 2 * (f.n + 1)) * sizeof(float); }
 
+// SDY_NO_FFT360=1 keeps the generic Stockham kernels for nlon = 360 too (A/B measurements)
+bool use_generic_only() {
+  static const bool v = [] { const char* e = getenv("SDY_NO_FFT360"); return e && e[0] == '1'; }();
+  return v;
+}
+
 }  // namespace
 
 int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                        int B, int C, int K, int mtr, hipStream_t stream) {
+  if (f.n == 180 && !use_generic_only()) {
+    const int rc = sdy_fft360_launch_fwd(f, x, a, d, xn_out, Xf, B, C, K, mtr, stream);
+    if (rc != SDY_ERR_UNSUPPORTED) return rc;
+  }
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = 4;   // latitude rings per workgroup on the pipelined (compile-time size) paths
@@ -441,6 +452,10 @@ int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, cons
 
 int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
                        hipStream_t stream) {
+  if (f.n == 180 && !use_generic_only()) {
+    const int rc = sdy_fft360_launch_inv(f, Yf, bias, y, B, C, K, mtr, stream);
+    if (rc != SDY_ERR_UNSUPPORTED) return rc;
+  }
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = 4;

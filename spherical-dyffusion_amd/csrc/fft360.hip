@@ -1,0 +1,398 @@
+// Longitude real FFT / inverse real FFT specialised for nlon = 360 (the production grid), gfx950.
+//
+// Same contract as the generic kernels in fft.hip (torch_harmonics' rfft / irfft calls, reference call sites
+// src/models/sfno/s2convolutions.py:165,168,186, plus the NCHW <-> m-major layout change):
+//   forward : Xf[m][k][b][ri][c] = 2*pi/N * rfft(a*x+d)[m]        (m < mtr)
+//   inverse : y[b][c][k][:]      = irfft(Yf[..], n=N) (+ bias[c])  (imag of the m=0 / Nyquist bins ignored)
+//
+// The generic Stockham kernel is instruction bound (PMC: ~900 VALU + 256 LDS instructions per wave and ring, nearly all
+// of it index arithmetic and 4-byte LDS accesses, 7 workgroup barriers per ring).  This kernel does the length-180
+// complex transform as TWO register-resident passes, 180 = 12 x 15:
+//   pass A: lane (row, a), a < 15: 12-point DFT over x[a + 15 b] (Good-Thomas 3 x 4, no inner twiddles), times
+//           w180^(a k1), written back in place;
+//   pass B: lane (row, k1), k1 < 12: 15-point DFT over the 15 consecutive values (Good-Thomas 3 x 5), written in natural
+//           order X[k1 + 12 k2].
+// Every LDS access is an 8-byte (re, im) word at "lane base + compile-time offset", complex arithmetic is written on
+// float2 so it maps to v_pk_*_f32, and the 11 pass-A twiddles live in registers for the life of the workgroup.  A wave owns
+// 4 of the workgroup's 16 rows for both passes, so no workgroup barrier sits between them: the only barriers are the two
+// around the transposing pass (the m-major side is written / read as 64-byte channel runs).  The real-FFT split (forward)
+// is folded into the m-major store pass and the merge (inverse) into the loads of pass A.
+//
+// LDS: 16 row slots x P = 200 complex words.  Channel 4*c4 + j of the workgroup sits in slot c4 + 4*j; wave w owns slots
+// 4w..4w+3 and pairs slots {0,2} / {1,3} in its two half-waves.  With P % 32 == 8 (in 8-byte words) every access pattern
+// below is bank-conflict free: pass A/B (two rows 16 words apart, lanes contiguous or at stride 15), the m-major pass
+// (8 consecutive m x 4 slots 8 words apart) and the 16-byte row I/O.
+#include "common.h"
+#include "fft.h"
+
+namespace {
+
+typedef float c2 __attribute__((ext_vector_type(2)));   // (re, im)
+
+constexpr int NH = 180;      // complex length
+constexpr int NLON = 360;
+constexpr int ROWS = 16;     // channels per workgroup
+constexpr int NT = 256;
+constexpr int P = 200;       // row pitch in complex words (>= 181, % 32 == 8)
+constexpr int Q4 = NLON / 4; // 16-byte pieces per row
+constexpr int RIT = (4 * Q4 + 63) / 64;   // row-I/O iterations of a wave over its 4 rows (6)
+constexpr int MIT = 3;                    // m-major iterations: m = mg + 64*it covers 0..191
+
+template <int SG>
+__device__ __forceinline__ c2 mul_i(c2 a) {   // (SG * i) * a
+  return SG > 0 ? c2{-a.y, a.x} : c2{a.y, -a.x};
+}
+__device__ __forceinline__ c2 cmul(c2 a, c2 w) { return a.xx * w + a.yy * c2{-w.y, w.x}; }
+__device__ __forceinline__ c2 cmul_conj(c2 a, c2 w) { return a.xx * c2{w.x, -w.y} + a.yy * c2{w.y, w.x}; }   // a * conj(w)
+
+// SG = -1: forward (exp(-2 pi i ..)), +1: inverse
+template <int SG>
+__device__ __forceinline__ void dft3(c2& v0, c2& v1, c2& v2) {
+  const float sn = 0.86602540378443864676f;
+  const c2 a = v1 + v2, b = v1 - v2;
+  const c2 m = v0 - 0.5f * a;
+  const c2 t = mul_i<SG>(sn * b);
+  v0 = v0 + a;
+  v1 = m + t;
+  v2 = m - t;
+}
+template <int SG>
+__device__ __forceinline__ void dft4(c2& v0, c2& v1, c2& v2, c2& v3) {
+  const c2 t0 = v0 + v2, t1 = v0 - v2, t2 = v1 + v3, t3 = mul_i<SG>(v1 - v3);
+  v0 = t0 + t2;
+  v1 = t1 + t3;
+  v2 = t0 - t2;
+  v3 = t1 - t3;
+}
+template <int SG>
+__device__ __forceinline__ void dft5(c2& v0, c2& v1, c2& v2, c2& v3, c2& v4) {
+  const float c1 = 0.30901699437494742410f, c2_ = -0.80901699437494742410f;
+  const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+  const c2 a1 = v1 + v4, a2 = v2 + v3, b1 = v1 - v4, b2 = v2 - v3;
+  const c2 r1 = v0 + c1 * a1 + c2_ * a2;
+  const c2 r2 = v0 + c2_ * a1 + c1 * a2;
+  const c2 i1 = mul_i<SG>(s1 * b1 + s2 * b2);
+  const c2 i2 = mul_i<SG>(s2 * b1 - s1 * b2);
+  v0 = v0 + a1 + a2;
+  v1 = r1 + i1;
+  v4 = r1 - i1;
+  v2 = r2 + i2;
+  v3 = r2 - i2;
+}
+template <int R, int SG>
+__device__ __forceinline__ void dft_small(c2* t) {
+  if constexpr (R == 3) dft3<SG>(t[0], t[1], t[2]);
+  if constexpr (R == 4) dft4<SG>(t[0], t[1], t[2], t[3]);
+  if constexpr (R == 5) dft5<SG>(t[0], t[1], t[2], t[3], t[4]);
+}
+
+// Good-Thomas DFT of length N1*N2 (coprime) on registers: input n lives in v[n]; afterwards output k lives in
+// v[pfa_slot<N1,N2>(k)].  All indices are compile-time after unrolling, so the permutations cost nothing.
+template <int N1, int N2>
+__host__ __device__ constexpr int pfa_slot(int k) { return (N2 * (k % N1) + N1 * (k % N2)) % (N1 * N2); }
+template <int N1, int N2, int SG>
+__device__ __forceinline__ void pfa(c2* v) {
+  constexpr int N = N1 * N2;
+#pragma unroll
+  for (int n2 = 0; n2 < N2; ++n2) {
+    c2 t[N1];
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) t[n1] = v[(N2 * n1 + N1 * n2) % N];
+    dft_small<N1, SG>(t);
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) v[(N2 * n1 + N1 * n2) % N] = t[n1];
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < N1; ++k1) {
+    c2 u[N2];
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) u[n2] = v[(N2 * k1 + N1 * n2) % N];
+    dft_small<N2, SG>(u);
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) v[(N2 * k1 + N1 * n2) % N] = u[n2];
+  }
+}
+
+// lane roles shared by both kernels
+struct Lane {
+  int wave, lane, t;       // t = lane & 15: the a / k1 index of the two passes
+  int slot;                // row slot of the two passes
+  c2* row;                 // its LDS row
+};
+__device__ __forceinline__ Lane lane_roles(c2* Z) {
+  Lane L;
+  L.wave = threadIdx.x >> 6;
+  L.lane = threadIdx.x & 63;
+  L.t = L.lane & 15;
+  const int rl = L.lane >> 4;
+  L.slot = 4 * L.wave + (rl & 1) * 2 + (rl >> 1);
+  L.row = Z + L.slot * P;
+  return L;
+}
+
+// passes A and B on the wave's own rows (in-order LDS of one wave: no workgroup barrier between them)
+template <int SG>
+__device__ __forceinline__ void pass_b(const Lane& L) {
+  __builtin_amdgcn_wave_barrier();
+  if (L.t < 12) {
+    c2 u[15];
+    const c2* src = L.row + 15 * L.t;
+#pragma unroll
+    for (int a = 0; a < 15; ++a) u[a] = src[a];
+    pfa<3, 5, SG>(u);
+    __builtin_amdgcn_wave_barrier();   // every lane's reads above precede the natural-order writes below
+    c2* dst = L.row + L.t;
+#pragma unroll
+    for (int k2 = 0; k2 < 15; ++k2) dst[12 * k2] = u[pfa_slot<3, 5>(k2)];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+template <int SG>
+__device__ __forceinline__ void pass_a_tail(const Lane& L, c2* v, const c2* T) {   // v[b] = x[a + 15 b] already loaded
+  pfa<3, 4, SG>(v);
+  c2* dst = L.row + L.t;
+  dst[0] = v[pfa_slot<3, 4>(0)];
+#pragma unroll
+  for (int k1 = 1; k1 < 12; ++k1) {
+    const c2 y = v[pfa_slot<3, 4>(k1)];
+    dst[15 * k1] = SG < 0 ? cmul(y, T[k1 - 1]) : cmul_conj(y, T[k1 - 1]);
+  }
+}
+__device__ __forceinline__ void load_pass_a_twiddles(const SdyFftDesc& f, const Lane& L, c2* T) {
+  const int a = L.t < 15 ? L.t : 0;
+  const c2* tw = reinterpret_cast<const c2*>(f.tw);   // exp(-2 pi i j / 180)
+#pragma unroll
+  for (int k1 = 1; k1 < 12; ++k1) T[k1 - 1] = tw[a * k1];   // a*k1 <= 154 < 180
+}
+
+// ----------------------------------------------------------------------------------------------------------- forward
+template <int KPW>
+__global__ __launch_bounds__(NT, 3) void rfft360_kernel(const SdyFftDesc f, const float* __restrict__ x,
+                                                        const float* __restrict__ pa, const float* __restrict__ pd,
+                                                        float* __restrict__ xn_out, float* __restrict__ Xf, int B, int C,
+                                                        int K, int mtr) {
+  __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
+  __shared__ c2 AD[ROWS];   // per-slot affine (a, d)
+  const Lane L = lane_roles(Z);
+  const int c0 = blockIdx.x * ROWS, b = blockIdx.z;
+  const int k_begin = blockIdx.y * KPW, k_end = min(K, k_begin + KPW);
+
+  if (threadIdx.x < ROWS) {
+    const int s = threadIdx.x, ch = c0 + 4 * (s & 3) + (s >> 2);
+    AD[s] = pa ? c2{pa[b * C + ch], pd[b * C + ch]} : c2{1.0f, 0.0f};
+  }
+  c2 T[11];
+  load_pass_a_twiddles(f, L, T);
+
+  // row I/O of the wave's own 4 slots: piece idx = lane + 64*it of 4*90, slot 4w + idx/90 holds channel 4*(idx/90) + w
+  const long ring = (long)NLON;
+  const float* xb = x + ((long)b * C + c0) * K * ring;
+  float* xnb = xn_out ? xn_out + ((long)b * C + c0) * K * ring : nullptr;
+  unsigned goff[RIT];   // float offset inside the (b, c0) block, ring 0
+  int loff[RIT];        // complex-word offset inside Z
+  int sl[RIT];
+#pragma unroll
+  for (int it = 0; it < RIT; ++it) {
+    const int idx = L.lane + 64 * it;
+    const int rloc = min(idx / Q4, 3), q = idx - rloc * Q4;
+    sl[it] = 4 * L.wave + rloc;
+    goff[it] = (unsigned)((4 * rloc + L.wave) * K) * NLON + 4 * q;
+    loff[it] = sl[it] * P + 2 * q;
+  }
+  const bool last_ok = L.lane + 64 * (RIT - 1) < 4 * Q4;
+
+  // m-major pass: thread (c4, mg) stores channels 4*c4..4*c4+3 of m = mg + 64*it
+  const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
+  const float scale = 6.28318530717958647692f / (float)NLON;
+  c2 W[MIT];        // -i * exp(-2 pi i m / N) * scale / 2
+  int am[MIT], an[MIT];
+#pragma unroll
+  for (int it = 0; it < MIT; ++it) {
+    const int m = min(mg + 64 * it, NH);
+    const c2 w = reinterpret_cast<const c2*>(f.pw)[m];
+    W[it] = c2{w.y, -w.x} * (0.5f * scale);
+    am[it] = c4 * P + (m == NH ? 0 : m);
+    an[it] = c4 * P + ((m == 0 || m == NH) ? 0 : NH - m);
+  }
+  const long mstride = (long)K * B * 2 * C;
+
+  f32x4 regs[RIT];
+  auto gload = [&](int k) {
+#pragma unroll
+    for (int it = 0; it < RIT; ++it)
+      if (it < RIT - 1 || last_ok) regs[it] = *reinterpret_cast<const f32x4*>(xb + goff[it] + (long)k * NLON);
+  };
+  gload(k_begin);
+  __syncthreads();   // AD
+
+  for (int k = k_begin; k < k_end; ++k) {
+    // ---- stage the wave's rows: affine, optional store of the normalised field, LDS image z[j] = x[2j] + i x[2j+1]
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      if (it < RIT - 1 || last_ok) {
+        const c2 ad = AD[sl[it]];
+        f32x4 v = regs[it] * ad.x + ad.y;
+        if (xnb) *reinterpret_cast<f32x4*>(xnb + goff[it] + (long)k * NLON) = v;
+        *reinterpret_cast<f32x4*>(Z + loff[it]) = v;
+      }
+    }
+    if (k + 1 < k_end) gload(k + 1);   // in flight under the two passes
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pass A
+    if (L.t < 15) {
+      c2 v[12];
+      const c2* src = L.row + L.t;
+#pragma unroll
+      for (int bb = 0; bb < 12; ++bb) v[bb] = src[15 * bb];
+      pass_a_tail<-1>(L, v, T);
+    }
+    pass_b<-1>(L);
+    __syncthreads();
+
+    // ---- split step + m-major stores: X[m] = h (A + conj B) + W (A - conj B), A = Z[m], B = Z[n - m]
+    float* Xk = Xf + ((long)k * B + b) * 2 * C + c0 + 4 * c4;
+#pragma unroll
+    for (int it = 0; it < MIT; ++it) {
+      const int m = mg + 64 * it;
+      if (m < mtr) {
+        f32x4 vr, vi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const c2 A = Z[am[it] + 4 * j * P], Bv = Z[an[it] + 4 * j * P];
+          const c2 S = c2{A.x + Bv.x, A.y - Bv.y}, D = c2{A.x - Bv.x, A.y + Bv.y};
+          const c2 X = (0.5f * scale) * S + cmul(D, W[it]);
+          vr[j] = X.x;
+          vi[j] = X.y;
+        }
+        float* o = Xk + (long)m * mstride;
+        *reinterpret_cast<f32x4*>(o) = vr;
+        *reinterpret_cast<f32x4*>(o + C) = vi;
+      }
+    }
+    __syncthreads();   // the rows are rewritten by the next ring
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------- inverse
+template <int KPW>
+__global__ __launch_bounds__(NT, 3) void irfft360_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                         int C, int K, int mtr) {
+  __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
+  __shared__ c2 PW[NH];       // exp(+2 pi i j / N)
+  __shared__ float BS[ROWS];  // per-slot bias
+  const Lane L = lane_roles(Z);
+  const int c0 = blockIdx.x * ROWS, b = blockIdx.z;
+  const int k_begin = blockIdx.y * KPW, k_end = min(K, k_begin + KPW);
+
+  if (threadIdx.x < NH) {
+    const c2 w = reinterpret_cast<const c2*>(f.pw)[threadIdx.x];
+    PW[threadIdx.x] = c2{w.x, -w.y};
+  }
+  if (threadIdx.x < ROWS) {
+    const int s = threadIdx.x;
+    BS[s] = bias ? bias[c0 + 4 * (s & 3) + (s >> 2)] : 0.0f;
+  }
+  c2 T[11];
+  load_pass_a_twiddles(f, L, T);
+
+  // m-major loads: thread (c4, mg), m = mg + 64*it <= 180; rows of channels 4*c4 + j are slots c4 + 4*j
+  const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
+  const long mstride = (long)K * B * 2 * C;
+  f32x4 rr[MIT], ri[MIT];
+  auto gload = [&](int k) {
+    const float* Yk = Yf + ((long)k * B + b) * 2 * C + c0 + 4 * c4;
+#pragma unroll
+    for (int it = 0; it < MIT; ++it) {
+      const int m = mg + 64 * it;
+      f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
+      if (m < mtr) {
+        const float* o = Yk + (long)m * mstride;
+        vr = *reinterpret_cast<const f32x4*>(o);
+        vi = *reinterpret_cast<const f32x4*>(o + C);
+      }
+      if (m == 0 || m == NH) vi = f32x4{0.f, 0.f, 0.f, 0.f};   // irfft ignores the imaginary parts of DC / Nyquist
+      rr[it] = vr;
+      ri[it] = vi;
+    }
+  };
+
+  // row output of the wave's own slots
+  float* yb = y + ((long)b * C + c0) * K * (long)NLON;
+  unsigned goff[RIT];
+  int loff[RIT], sl[RIT];
+#pragma unroll
+  for (int it = 0; it < RIT; ++it) {
+    const int idx = L.lane + 64 * it;
+    const int rloc = min(idx / Q4, 3), q = idx - rloc * Q4;
+    sl[it] = 4 * L.wave + rloc;
+    goff[it] = (unsigned)((4 * rloc + L.wave) * K) * NLON + 4 * q;
+    loff[it] = sl[it] * P + 2 * q;
+  }
+  const bool last_ok = L.lane + 64 * (RIT - 1) < 4 * Q4;
+
+  gload(k_begin);
+  for (int k = k_begin; k < k_end; ++k) {
+    // ---- spectrum rows X[m], m = 0..180
+#pragma unroll
+    for (int it = 0; it < MIT; ++it) {
+      const int m = mg + 64 * it;
+      if (m <= NH) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Z[(c4 + 4 * j) * P + m] = c2{rr[it][j], ri[it][j]};
+      }
+    }
+    __syncthreads();
+    if (k + 1 < k_end) gload(k + 1);
+
+    // ---- merge step folded into the loads of pass A: z[j] = S + i D, S = X[j] + conj X[n-j], D = e^{+2 pi i j/N} (X[j] - conj X[n-j])
+    if (L.t < 15) {
+      c2 v[12];
+      const c2* lo = L.row + L.t;          // X[a + 15 b]
+      const c2* hi = L.row + (15 - L.t);   // X[180 - a - 15 b] = hi[15 * (11 - b)]
+      const c2* pw = PW + L.t;
+#pragma unroll
+      for (int bb = 0; bb < 12; ++bb) {
+        const c2 A = lo[15 * bb], Bv = hi[15 * (11 - bb)], w = pw[15 * bb];
+        const c2 S = c2{A.x + Bv.x, A.y - Bv.y}, Dm = c2{A.x - Bv.x, A.y + Bv.y};
+        const c2 D = cmul(Dm, w);
+        v[bb] = c2{S.x - D.y, S.y + D.x};
+      }
+      __builtin_amdgcn_wave_barrier();   // all merge reads of the wave precede the in-place writes
+      pass_a_tail<+1>(L, v, T);
+    }
+    pass_b<+1>(L);
+
+    // ---- rows out: y[2j] = Re z[j], y[2j+1] = Im z[j]
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      if (it < RIT - 1 || last_ok) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Z + loff[it]) + BS[sl[it]];
+        *reinterpret_cast<f32x4*>(yb + goff[it] + (long)k * NLON) = v;
+      }
+    }
+    __syncthreads();   // the rows are rewritten by the next ring
+  }
+}
+
+}  // namespace
+
+// nlon = 360 fast path; returns SDY_ERR_UNSUPPORTED when the shape does not fit (the caller falls back to fft.hip)
+int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
+                          int B, int C, int K, int mtr, hipStream_t stream) {
+  if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
+  constexpr int KPW = 4;
+  dim3 grid(C / ROWS, (K + KPW - 1) / KPW, B);
+  hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  return sdy_launch_status();
+}
+
+int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
+                          int mtr, hipStream_t stream) {
+  if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
+  constexpr int KPW = 4;
+  dim3 grid(C / ROWS, (K + KPW - 1) / KPW, B);
+  hipLaunchKernelGGL((irfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, Yf, bias, y, B, C, K, mtr);
+  return sdy_launch_status();
+}
