@@ -35,8 +35,17 @@ constexpr int ROWS = 16;     // channels per workgroup
 constexpr int NT = 256;
 constexpr int P = 200;       // row pitch in complex words (>= 181, % 32 == 8)
 constexpr int Q4 = NLON / 4; // 16-byte pieces per row
-constexpr int RIT = (4 * Q4 + 63) / 64;   // row-I/O iterations of a wave over its 4 rows (6)
 constexpr int MIT = 3;                    // m-major iterations: m = mg + 64*it covers 0..191
+#ifndef SDY_FFT_MINB_F
+#define SDY_FFT_MINB_F 4
+#endif
+#ifndef SDY_FFT_MINB_I
+#define SDY_FFT_MINB_I 4
+#endif
+#ifndef SDY_FFT_KPW
+#define SDY_FFT_KPW 4
+#endif
+constexpr int MINB_F = SDY_FFT_MINB_F, MINB_I = SDY_FFT_MINB_I;   // workgroups per CU the register budgets are set for
 
 template <int SG>
 __device__ __forceinline__ c2 mul_i(c2 a) {   // (SG * i) * a
@@ -115,23 +124,30 @@ __device__ __forceinline__ void pfa(c2* v) {
 
 // lane roles shared by both kernels
 struct Lane {
-  int wave, lane, t;       // t = lane & 15: the a / k1 index of the two passes
-  int slot;                // row slot of the two passes
-  c2* row;                 // its LDS row
+  int wave, lane, t;       // wave is wave-uniform (SGPR); t = lane & 15: the a / k1 index of the two passes
+  c2* row;                 // LDS row of the two passes
 };
 __device__ __forceinline__ Lane lane_roles(c2* Z) {
   Lane L;
-  L.wave = threadIdx.x >> 6;
+  L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   L.lane = threadIdx.x & 63;
   L.t = L.lane & 15;
   const int rl = L.lane >> 4;
-  L.slot = 4 * L.wave + (rl & 1) * 2 + (rl >> 1);
-  L.row = Z + L.slot * P;
+  L.row = Z + (4 * L.wave + (rl & 1) * 2 + (rl >> 1)) * P;
   return L;
 }
 
+// pass-A twiddles w180^(a k1) as an LDS table [k1][16]: one base register per lane, compile-time offsets per k1
+constexpr int TWN = 12 * 16;
+__device__ __forceinline__ void fill_twiddles(const SdyFftDesc& f, c2* TW) {
+  if (threadIdx.x < TWN) {
+    const int k1 = threadIdx.x >> 4, a = threadIdx.x & 15;
+    TW[threadIdx.x] = reinterpret_cast<const c2*>(f.tw)[a < 15 ? a * k1 : 0];   // a*k1 <= 154 < 180
+  }
+}
+
 // passes A and B on the wave's own rows (in-order LDS of one wave: no workgroup barrier between them)
-template <int SG>
+template <int SG, bool NYQ_COPY>
 __device__ __forceinline__ void pass_b(const Lane& L) {
   __builtin_amdgcn_wave_barrier();
   if (L.t < 12) {
@@ -144,97 +160,110 @@ __device__ __forceinline__ void pass_b(const Lane& L) {
     c2* dst = L.row + L.t;
 #pragma unroll
     for (int k2 = 0; k2 < 15; ++k2) dst[12 * k2] = u[pfa_slot<3, 5>(k2)];
+    if (NYQ_COPY && L.t == 0) dst[NH] = u[pfa_slot<3, 5>(0)];   // Z[180] := Z[0] (periodic), read by the split step
   }
   __builtin_amdgcn_wave_barrier();
 }
 template <int SG>
-__device__ __forceinline__ void pass_a_tail(const Lane& L, c2* v, const c2* T) {   // v[b] = x[a + 15 b] already loaded
+__device__ __forceinline__ void pass_a_tail(const Lane& L, c2* v, const c2* TW) {   // v[b] = x[a + 15 b] already loaded
   pfa<3, 4, SG>(v);
   c2* dst = L.row + L.t;
+  const c2* tw = TW + L.t;
   dst[0] = v[pfa_slot<3, 4>(0)];
 #pragma unroll
   for (int k1 = 1; k1 < 12; ++k1) {
     const c2 y = v[pfa_slot<3, 4>(k1)];
-    dst[15 * k1] = SG < 0 ? cmul(y, T[k1 - 1]) : cmul_conj(y, T[k1 - 1]);
+    dst[15 * k1] = SG < 0 ? cmul(y, tw[16 * k1]) : cmul_conj(y, tw[16 * k1]);
   }
 }
-__device__ __forceinline__ void load_pass_a_twiddles(const SdyFftDesc& f, const Lane& L, c2* T) {
-  const int a = L.t < 15 ? L.t : 0;
-  const c2* tw = reinterpret_cast<const c2*>(f.tw);   // exp(-2 pi i j / 180)
-#pragma unroll
-  for (int k1 = 1; k1 < 12; ++k1) T[k1 - 1] = tw[a * k1];   // a*k1 <= 154 < 180
+
+// Row I/O of a wave's own 4 rows (slot 4w + r holds channel 4r + w): 90 16-byte pieces per row = all 64 lanes + lanes 0..25,
+// so every address is "row base (uniform) + 16 * lane (+ 1024)" and no per-piece index arithmetic is left in the ring loop.
+constexpr int TAIL = Q4 - 64;   // 26
+
+// Workgroup -> (channel block, ring group, image).  The hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs, each with its own L2.  The 16 channel blocks of one (ring group, image) write / read the two 64-byte halves of the
+// same 128-byte lines on the m-major side, so they are mapped to consecutive slots of ONE XCD: its L2 merges the halves
+// instead of every half-line going to HBM on its own.
+struct WgId {
+  int x, y, z;
+};
+__device__ __forceinline__ WgId wg_id(int nx, int ny) {
+  const unsigned total = gridDim.x, L = blockIdx.x;
+  const unsigned xcd = L % 8u, slot = L / 8u;
+  const unsigned id = xcd * (total / 8u) + min(xcd, total % 8u) + slot;
+  WgId w;
+  w.x = id % nx;
+  w.y = (id / nx) % ny;
+  w.z = id / (nx * ny);
+  return w;
 }
 
 // ----------------------------------------------------------------------------------------------------------- forward
 template <int KPW>
-__global__ __launch_bounds__(NT, 3) void rfft360_kernel(const SdyFftDesc f, const float* __restrict__ x,
-                                                        const float* __restrict__ pa, const float* __restrict__ pd,
-                                                        float* __restrict__ xn_out, float* __restrict__ Xf, int B, int C,
-                                                        int K, int mtr) {
+__global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f, const float* __restrict__ x,
+                                                           const float* __restrict__ pa, const float* __restrict__ pd,
+                                                           float* __restrict__ xn_out, float* __restrict__ Xf, int B,
+                                                           int C, int K, int mtr) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
+  __shared__ c2 TW[TWN];
   __shared__ c2 AD[ROWS];   // per-slot affine (a, d)
   const Lane L = lane_roles(Z);
-  const int c0 = blockIdx.x * ROWS, b = blockIdx.z;
-  const int k_begin = blockIdx.y * KPW, k_end = min(K, k_begin + KPW);
+  const WgId id = wg_id(C / ROWS, (K + KPW - 1) / KPW);
+  const int c0 = id.x * ROWS, b = id.z;
+  const int k_begin = id.y * KPW, k_end = min(K, k_begin + KPW);
 
+  fill_twiddles(f, TW);
   if (threadIdx.x < ROWS) {
     const int s = threadIdx.x, ch = c0 + 4 * (s & 3) + (s >> 2);
     AD[s] = pa ? c2{pa[b * C + ch], pd[b * C + ch]} : c2{1.0f, 0.0f};
   }
-  c2 T[11];
-  load_pass_a_twiddles(f, L, T);
 
-  // row I/O of the wave's own 4 slots: piece idx = lane + 64*it of 4*90, slot 4w + idx/90 holds channel 4*(idx/90) + w
-  const long ring = (long)NLON;
-  const float* xb = x + ((long)b * C + c0) * K * ring;
-  float* xnb = xn_out ? xn_out + ((long)b * C + c0) * K * ring : nullptr;
-  unsigned goff[RIT];   // float offset inside the (b, c0) block, ring 0
-  int loff[RIT];        // complex-word offset inside Z
-  int sl[RIT];
-#pragma unroll
-  for (int it = 0; it < RIT; ++it) {
-    const int idx = L.lane + 64 * it;
-    const int rloc = min(idx / Q4, 3), q = idx - rloc * Q4;
-    sl[it] = 4 * L.wave + rloc;
-    goff[it] = (unsigned)((4 * rloc + L.wave) * K) * NLON + 4 * q;
-    loff[it] = sl[it] * P + 2 * q;
-  }
-  const bool last_ok = L.lane + 64 * (RIT - 1) < 4 * Q4;
+  const float* xw = x + (((long)b * C + c0 + L.wave) * K) * NLON + 4 * L.lane;      // row r of the wave: + 4 r K N
+  float* xnw = xn_out ? xn_out + (((long)b * C + c0 + L.wave) * K) * NLON + 4 * L.lane : nullptr;
+  const long rstride = 4L * K * NLON;
+  c2* zw = Z + 4 * L.wave * P + 2 * L.lane;
+  const bool tail = L.lane < TAIL;
 
   // m-major pass: thread (c4, mg) stores channels 4*c4..4*c4+3 of m = mg + 64*it
   const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
   const float scale = 6.28318530717958647692f / (float)NLON;
   c2 W[MIT];        // -i * exp(-2 pi i m / N) * scale / 2
-  int am[MIT], an[MIT];
 #pragma unroll
   for (int it = 0; it < MIT; ++it) {
-    const int m = min(mg + 64 * it, NH);
-    const c2 w = reinterpret_cast<const c2*>(f.pw)[m];
+    const c2 w = reinterpret_cast<const c2*>(f.pw)[min(mg + 64 * it, NH)];
     W[it] = c2{w.y, -w.x} * (0.5f * scale);
-    am[it] = c4 * P + (m == NH ? 0 : m);
-    an[it] = c4 * P + ((m == 0 || m == NH) ? 0 : NH - m);
   }
+  const c2* za = Z + c4 * P + mg;                  // Z[m]:     za[64 it]           (Z[180] is the copy of Z[0])
+  const c2* zn01 = Z + c4 * P + (NH - 64 - mg);    // Z[n - m]: zn01[64 (1 - it)]   it = 0, 1
+  const c2* zn2 = Z + c4 * P + max(NH - 128 - mg, 0);
   const long mstride = (long)K * B * 2 * C;
 
-  f32x4 regs[RIT];
+  f32x4 regs[8];
   auto gload = [&](int k) {
 #pragma unroll
-    for (int it = 0; it < RIT; ++it)
-      if (it < RIT - 1 || last_ok) regs[it] = *reinterpret_cast<const f32x4*>(xb + goff[it] + (long)k * NLON);
+    for (int r = 0; r < 4; ++r) {
+      const float* src = xw + r * rstride + (long)k * NLON;
+      regs[2 * r] = *reinterpret_cast<const f32x4*>(src);
+      if (tail) regs[2 * r + 1] = *reinterpret_cast<const f32x4*>(src + 256);
+    }
   };
   gload(k_begin);
-  __syncthreads();   // AD
+  __syncthreads();   // AD, TW
 
   for (int k = k_begin; k < k_end; ++k) {
     // ---- stage the wave's rows: affine, optional store of the normalised field, LDS image z[j] = x[2j] + i x[2j+1]
 #pragma unroll
-    for (int it = 0; it < RIT; ++it) {
-      if (it < RIT - 1 || last_ok) {
-        const c2 ad = AD[sl[it]];
-        f32x4 v = regs[it] * ad.x + ad.y;
-        if (xnb) *reinterpret_cast<f32x4*>(xnb + goff[it] + (long)k * NLON) = v;
-        *reinterpret_cast<f32x4*>(Z + loff[it]) = v;
+    for (int r = 0; r < 4; ++r) {
+      const c2 ad = AD[4 * L.wave + r];
+      const f32x4 v0 = regs[2 * r] * ad.x + ad.y, v1 = regs[2 * r + 1] * ad.x + ad.y;
+      if (xnw) {
+        float* dst = xnw + r * rstride + (long)k * NLON;
+        *reinterpret_cast<f32x4*>(dst) = v0;
+        if (tail) *reinterpret_cast<f32x4*>(dst + 256) = v1;
       }
+      *reinterpret_cast<f32x4*>(zw + r * P) = v0;
+      if (tail) *reinterpret_cast<f32x4*>(zw + r * P + 128) = v1;
     }
     if (k + 1 < k_end) gload(k + 1);   // in flight under the two passes
     __builtin_amdgcn_wave_barrier();
@@ -245,9 +274,9 @@ __global__ __launch_bounds__(NT, 3) void rfft360_kernel(const SdyFftDesc f, cons
       const c2* src = L.row + L.t;
 #pragma unroll
       for (int bb = 0; bb < 12; ++bb) v[bb] = src[15 * bb];
-      pass_a_tail<-1>(L, v, T);
+      pass_a_tail<-1>(L, v, TW);
     }
-    pass_b<-1>(L);
+    pass_b<-1, true>(L);
     __syncthreads();
 
     // ---- split step + m-major stores: X[m] = h (A + conj B) + W (A - conj B), A = Z[m], B = Z[n - m]
@@ -259,7 +288,8 @@ __global__ __launch_bounds__(NT, 3) void rfft360_kernel(const SdyFftDesc f, cons
         f32x4 vr, vi;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const c2 A = Z[am[it] + 4 * j * P], Bv = Z[an[it] + 4 * j * P];
+          const c2 A = za[64 * it + 4 * j * P];
+          const c2 Bv = it < 2 ? zn01[64 * (1 - it) + 4 * j * P] : zn2[4 * j * P];
           const c2 S = c2{A.x + Bv.x, A.y - Bv.y}, D = c2{A.x - Bv.x, A.y + Bv.y};
           const c2 X = (0.5f * scale) * S + cmul(D, W[it]);
           vr[j] = X.x;
@@ -276,16 +306,19 @@ __global__ __launch_bounds__(NT, 3) void rfft360_kernel(const SdyFftDesc f, cons
 
 // ----------------------------------------------------------------------------------------------------------- inverse
 template <int KPW>
-__global__ __launch_bounds__(NT, 3) void irfft360_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
-                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                         int C, int K, int mtr) {
+__global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                            int C, int K, int mtr) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
+  __shared__ c2 TW[TWN];
   __shared__ c2 PW[NH];       // exp(+2 pi i j / N)
   __shared__ float BS[ROWS];  // per-slot bias
   const Lane L = lane_roles(Z);
-  const int c0 = blockIdx.x * ROWS, b = blockIdx.z;
-  const int k_begin = blockIdx.y * KPW, k_end = min(K, k_begin + KPW);
+  const WgId id = wg_id(C / ROWS, (K + KPW - 1) / KPW);
+  const int c0 = id.x * ROWS, b = id.z;
+  const int k_begin = id.y * KPW, k_end = min(K, k_begin + KPW);
 
+  fill_twiddles(f, TW);
   if (threadIdx.x < NH) {
     const c2 w = reinterpret_cast<const c2*>(f.pw)[threadIdx.x];
     PW[threadIdx.x] = c2{w.x, -w.y};
@@ -294,8 +327,6 @@ __global__ __launch_bounds__(NT, 3) void irfft360_kernel(const SdyFftDesc f, con
     const int s = threadIdx.x;
     BS[s] = bias ? bias[c0 + 4 * (s & 3) + (s >> 2)] : 0.0f;
   }
-  c2 T[11];
-  load_pass_a_twiddles(f, L, T);
 
   // m-major loads: thread (c4, mg), m = mg + 64*it <= 180; rows of channels 4*c4 + j are slots c4 + 4*j
   const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
@@ -318,29 +349,20 @@ __global__ __launch_bounds__(NT, 3) void irfft360_kernel(const SdyFftDesc f, con
     }
   };
 
-  // row output of the wave's own slots
-  float* yb = y + ((long)b * C + c0) * K * (long)NLON;
-  unsigned goff[RIT];
-  int loff[RIT], sl[RIT];
-#pragma unroll
-  for (int it = 0; it < RIT; ++it) {
-    const int idx = L.lane + 64 * it;
-    const int rloc = min(idx / Q4, 3), q = idx - rloc * Q4;
-    sl[it] = 4 * L.wave + rloc;
-    goff[it] = (unsigned)((4 * rloc + L.wave) * K) * NLON + 4 * q;
-    loff[it] = sl[it] * P + 2 * q;
-  }
-  const bool last_ok = L.lane + 64 * (RIT - 1) < 4 * Q4;
+  float* yw = y + (((long)b * C + c0 + L.wave) * K) * NLON + 4 * L.lane;
+  const long rstride = 4L * K * NLON;
+  const c2* zw = Z + 4 * L.wave * P + 2 * L.lane;
+  const bool tail = L.lane < TAIL;
+  c2* zs = Z + c4 * P + mg;
 
   gload(k_begin);
   for (int k = k_begin; k < k_end; ++k) {
     // ---- spectrum rows X[m], m = 0..180
 #pragma unroll
     for (int it = 0; it < MIT; ++it) {
-      const int m = mg + 64 * it;
-      if (m <= NH) {
+      if (mg + 64 * it <= NH) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Z[(c4 + 4 * j) * P + m] = c2{rr[it][j], ri[it][j]};
+        for (int j = 0; j < 4; ++j) zs[4 * j * P + 64 * it] = c2{rr[it][j], ri[it][j]};
       }
     }
     __syncthreads();
@@ -360,17 +382,17 @@ __global__ __launch_bounds__(NT, 3) void irfft360_kernel(const SdyFftDesc f, con
         v[bb] = c2{S.x - D.y, S.y + D.x};
       }
       __builtin_amdgcn_wave_barrier();   // all merge reads of the wave precede the in-place writes
-      pass_a_tail<+1>(L, v, T);
+      pass_a_tail<+1>(L, v, TW);
     }
-    pass_b<+1>(L);
+    pass_b<+1, false>(L);
 
     // ---- rows out: y[2j] = Re z[j], y[2j+1] = Im z[j]
 #pragma unroll
-    for (int it = 0; it < RIT; ++it) {
-      if (it < RIT - 1 || last_ok) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Z + loff[it]) + BS[sl[it]];
-        *reinterpret_cast<f32x4*>(yb + goff[it] + (long)k * NLON) = v;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float bs = BS[4 * L.wave + r];
+      float* dst = yw + r * rstride + (long)k * NLON;
+      *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(zw + r * P) + bs;
+      if (tail) *reinterpret_cast<f32x4*>(dst + 256) = *reinterpret_cast<const f32x4*>(zw + r * P + 128) + bs;
     }
     __syncthreads();   // the rows are rewritten by the next ring
   }
@@ -382,8 +404,8 @@ __global__ __launch_bounds__(NT, 3) void irfft360_kernel(const SdyFftDesc f, con
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                           int B, int C, int K, int mtr, hipStream_t stream) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
-  constexpr int KPW = 4;
-  dim3 grid(C / ROWS, (K + KPW - 1) / KPW, B);
+  constexpr int KPW = SDY_FFT_KPW;
+  dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
   hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
   return sdy_launch_status();
 }
@@ -391,8 +413,8 @@ int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, c
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
                           int mtr, hipStream_t stream) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
-  constexpr int KPW = 4;
-  dim3 grid(C / ROWS, (K + KPW - 1) / KPW, B);
+  constexpr int KPW = SDY_FFT_KPW;
+  dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
   hipLaunchKernelGGL((irfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, Yf, bias, y, B, C, K, mtr);
   return sdy_launch_status();
 }
