@@ -221,13 +221,13 @@ extern "C" int sdy_rfft_lon(const sdy_sht_plan* p, const float* x, const float* 
                             float* Xf, int B, int C, void* stream) {
   if (!p || !x || !Xf || B <= 0 || C <= 0) return SDY_ERR_ARG;
   if ((a == nullptr) != (d == nullptr)) return SDY_ERR_ARG;
-  return sdy_fft_launch_fwd(p->fft, x, a, d, xn_out, Xf, B, C, p->nlat, p->mtr, (hipStream_t)stream);
+  return sdy_fft_launch_fwd(p->fft, x, a, d, xn_out, Xf, B, C, p->nlat, p->mtr, 0, (hipStream_t)stream);
 }
 
 extern "C" int sdy_irfft_lon(const sdy_sht_plan* p, const float* Yf, const float* bias, float* y, int B, int C,
                              void* stream) {
   if (!p || !Yf || !y || B <= 0 || C <= 0) return SDY_ERR_ARG;
-  return sdy_fft_launch_inv(p->fft, Yf, bias, y, B, C, p->nlat, p->mtr, (hipStream_t)stream);
+  return sdy_fft_launch_inv(p->fft, Yf, bias, y, B, C, p->nlat, p->mtr, 0, (hipStream_t)stream);
 }
 
 extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, void* stream) {
@@ -334,17 +334,23 @@ extern "C" size_t sdy_dhconv_h3_pack_bytes(int Ci, int Co, int L) {
 
 // (Ci, Co, L, 2) -> per l the TRANSPOSED expanded real matrix W'^T[o'][i'], W' = [[wr, wi], [-wi, wr]] with rows
 // i' = (ri_in, i) and columns o' = (ri_out, o), split into fp16 hi | lo
-extern "C" int sdy_dhconv_h3_pack_weight(const float* w, int Ci, int Co, int L, void* packed_dev, float* scale) {
+// ilv = 1: rows / columns in the [c / 16][ri][16] order of the fused forward's spectral buffers (fft.h)
+static int dhconv_h3_pack(const float* w, int Ci, int Co, int L, void* packed_dev, float* scale, int ilv) {
   if (!w || !packed_dev || !scale || Ci <= 0 || Co <= 0 || L <= 0) return SDY_ERR_ARG;
+  if (ilv && ((Ci & 15) || (Co & 15))) return SDY_ERR_UNSUPPORTED;
   std::vector<_Float16> buf;
   *scale = h3_pack_host(buf, L, 2 * Co, 2 * Ci, dh_npad(Co), dh_kpad(Ci), [&](int l, int op, int ip) {
-    const int ro = op >= Co, o = op - ro * Co, ri = ip >= Ci, i = ip - ri * Ci;
+    const int ro = ilv ? (op >> 4) & 1 : op >= Co, o = ilv ? (op >> 5) * 16 + (op & 15) : op - ro * Co;
+    const int ri = ilv ? (ip >> 4) & 1 : ip >= Ci, i = ilv ? (ip >> 5) * 16 + (ip & 15) : ip - ri * Ci;
     const float* e = w + (((size_t)i * Co + o) * L + l) * 2;
     if (ri == ro) return e[0];
     return ri ? -e[1] : e[1];
   });
   SDY_HIP_TRY(hipMemcpy(packed_dev, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   return SDY_OK;
+}
+extern "C" int sdy_dhconv_h3_pack_weight(const float* w, int Ci, int Co, int L, void* packed_dev, float* scale) {
+  return dhconv_h3_pack(w, Ci, Co, L, packed_dev, scale, 0);
 }
 
 extern "C" int sdy_dhconv_h3(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B,
@@ -470,6 +476,13 @@ struct BlockW {
 };
 
 }  // namespace
+
+// Channel order of the forward's spectral buffers (fft.h): the 128-byte-line order whenever the dhconv weights can be
+// packed for it (split-fp16 GEMM path, E % 16 == 0); SDY_NO_SPEC_ILV=1 keeps the ABI order (A/B measurements).
+static int spec_ilv(const sdy_sfno_config& c) {
+  static const bool off = std::getenv("SDY_NO_SPEC_ILV") != nullptr;
+  return (c.gemm_mode == 1 && c.embed_dim % 16 == 0 && !off) ? 1 : 0;
+}
 
 struct sdy_sfno {
   sdy_sfno_config cfg;
@@ -664,7 +677,7 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
         if (w.fw.h3) (void)hipFree(w.fw.h3);
         w.fw.h3 = nullptr;
         SDY_HIP_TRY(hipMalloc(&w.fw.h3, sdy_dhconv_h3_pack_bytes(E, E, c.lmax)));
-        SDY_TRY(sdy_dhconv_h3_pack_weight(host, E, E, c.lmax, w.fw.h3, &w.fw.h3_scale));
+        SDY_TRY(dhconv_h3_pack(host, E, E, c.lmax, w.fw.h3, &w.fw.h3_scale, spec_ilv(c)));
       } else {
         SDY_TRY(dev_alloc(w.fw, numel));
         SDY_TRY(sdy_dhconv_pack_weight(host, E, E, c.lmax, w.fw.p, nullptr));
@@ -849,6 +862,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
 
   float* cur = xb;
   float* nxt = xa;
+  const int ilv = spec_ilv(c);   // channel order of Xf / Cs / Cs2 inside this forward
   for (int i = 0; i < L; ++i) {
     const BlockW& bw = n->blk[i];
     const sdy_sht_plan* pin = (i == 0) ? n->plan_data : n->plan_lg;
@@ -870,18 +884,18 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     have_st0 = false;
     // SpectralConvS2.forward (s2convolutions.py:158-193)
     SDY_TRY(sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, B, E, pin->nlat,
-                               pin->mtr, stream));
+                               pin->mtr, ilv, stream));
     SDY_TRY(sdy_legendre_fwd(pin, Xf, Cs, B, E, stream));
     if (scale_residual) {  // residual = inverse_transform(forward_transform(x))
       SDY_TRY(sdy_legendre_inv(pout, Cs, Xf, B, E, stream));
-      SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, stream));
+      SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, ilv, stream));
     }
     if (c.gemm_mode == 1)
       SDY_TRY(sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     else
       SDY_TRY(sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     SDY_TRY(sdy_legendre_inv(pout, Cs2, Xf, B, E, stream));
-    SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, stream));
+    SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, ilv, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
     conv_reset();
     cv.x = lazy_norm ? cur : xn; cv.x_bstride = lazy_norm ? ((cur == cat) ? cat_bs : (long)E * HW) : (long)E * HW;

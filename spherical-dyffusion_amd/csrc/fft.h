@@ -12,12 +12,17 @@ struct SdyFftDesc {
 };
 
 int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                       int B, int C, int K, int mtr, hipStream_t stream);
+                       int B, int C, int K, int mtr, int ilv, hipStream_t stream);
 int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
-                       hipStream_t stream);
+                       int ilv, hipStream_t stream);
 
+// ilv selects the channel order of the m-major side (Xf / Yf, 2C floats per (m, k, b)):
+//   0: [ri][c]            -- the layout of the C ABI (include/sdy_amd.h)
+//   1: [c / 16][ri][16]   -- a workgroup's 16 channels x (re, im) form ONE 128-byte line instead of two 64-byte half
+//                            lines 4*C bytes apart (C % 16 == 0).  The Legendre stages are agnostic (flat columns); the
+//                            dhconv weights are packed for the same order (capi.hip).  Used inside the fused forward.
 // nlon = 360 specialisation (fft360.hip); SDY_ERR_UNSUPPORTED when the shape does not fit
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                          int B, int C, int K, int mtr, hipStream_t stream);
+                          int B, int C, int K, int mtr, int ilv, hipStream_t stream);
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
-                          int mtr, hipStream_t stream);
+                          int mtr, int ilv, hipStream_t stream);

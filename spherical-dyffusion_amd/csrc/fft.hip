@@ -207,7 +207,7 @@ template <int NH, int KPW>
 __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const float* __restrict__ x,
                                                        const float* __restrict__ pa, const float* __restrict__ pd,
                                                        float* __restrict__ xn_out, float* __restrict__ Xf, int B,
-                                                       int C, int K, int mtr) {
+                                                       int C, int K, int mtr, int ilv) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int n = NH ? NH : f.n, N = 2 * n, S = NH ? ((NH + 1) | 1) : f.S;
   LdsView L = carve(sm, S, n);
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const 
     const int c = c0 + 4 * c4;
     if (c < C) {
       for (int m = mg; m < mtr; m += NT / 4) {
-        const long o = (((long)m * K + k) * B + b) * (2L * C) + c;
+        const long o = (((long)m * K + k) * B + b) * (2L * C) + (ilv ? c0 + c : c);   // ilv: fft.h
         f32x4 vr, vi;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const 
           vi[j] = zi[(4 * c4 + j) * S + m];
         }
         *reinterpret_cast<f32x4*>(Xf + o) = vr;
-        *reinterpret_cast<f32x4*>(Xf + o + C) = vi;
+        *reinterpret_cast<f32x4*>(Xf + o + (ilv ? CB : C)) = vi;
       }
     }
     __syncthreads();   // the LDS image is rewritten by the next ring
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const 
 template <int NH, int KPW>
 __global__ __launch_bounds__(NT) void irfft_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
                                                     const float* __restrict__ bias, float* __restrict__ y, int B, int C,
-                                                    int K, int mtr) {
+                                                    int K, int mtr, int ilv) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int n = NH ? NH : f.n, N = 2 * n, S = NH ? ((NH + 1) | 1) : f.S;
   LdsView L = carve(sm, S, n);
@@ -332,9 +332,9 @@ __global__ __launch_bounds__(NT) void irfft_kernel(const SdyFftDesc f, const flo
       const int m = mg + it * (NT / 4);
       f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
       if (cq < C && m < mtr) {
-        const long o = (((long)m * K + k) * B + b) * (2L * C) + cq;
+        const long o = (((long)m * K + k) * B + b) * (2L * C) + (ilv ? c0 + cq : cq);
         vr = *reinterpret_cast<const f32x4*>(Yf + o);
-        vi = *reinterpret_cast<const f32x4*>(Yf + o + C);
+        vi = *reinterpret_cast<const f32x4*>(Yf + o + (ilv ? CB : C));
       }
       rr[it] = vr;
       ri[it] = vi;
@@ -360,9 +360,9 @@ __global__ __launch_bounds__(NT) void irfft_kernel(const SdyFftDesc f, const flo
       for (int m = mg; m <= n; m += NT / 4) {
         f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
         if (cq < C && m < mtr) {
-          const long o = (((long)m * K + k) * B + b) * (2L * C) + cq;
+          const long o = (((long)m * K + k) * B + b) * (2L * C) + (ilv ? c0 + cq : cq);
           vr = *reinterpret_cast<const f32x4*>(Yf + o);
-          vi = *reinterpret_cast<const f32x4*>(Yf + o + C);
+          vi = *reinterpret_cast<const f32x4*>(Yf + o + (ilv ? CB : C));
         }
         stage_m(m, vr, vi);
       }
@@ -430,9 +430,10 @@ bool use_generic_only() {
 }  // namespace
 
 int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                       int B, int C, int K, int mtr, hipStream_t stream) {
+                       int B, int C, int K, int mtr, int ilv, hipStream_t stream) {
+  if (ilv && C % CB != 0) return SDY_ERR_UNSUPPORTED;
   if (f.n == 180 && !use_generic_only()) {
-    const int rc = sdy_fft360_launch_fwd(f, x, a, d, xn_out, Xf, B, C, K, mtr, stream);
+    const int rc = sdy_fft360_launch_fwd(f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, stream);
     if (rc != SDY_ERR_UNSUPPORTED) return rc;
   }
   const size_t smem = fft_smem_bytes(f);
@@ -440,20 +441,21 @@ int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, cons
   constexpr int KPW = 4;   // latitude rings per workgroup on the pipelined (compile-time size) paths
   dim3 grid((C + CB - 1) / CB, (K + KPW - 1) / KPW, B);
   if (f.n == 180) {
-    hipLaunchKernelGGL((rfft_fwd_kernel<180, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+    hipLaunchKernelGGL((rfft_fwd_kernel<180, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv);
   } else if (f.n == 32) {
-    hipLaunchKernelGGL((rfft_fwd_kernel<32, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+    hipLaunchKernelGGL((rfft_fwd_kernel<32, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv);
   } else {
     grid.y = K;
-    hipLaunchKernelGGL((rfft_fwd_kernel<0, 1>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+    hipLaunchKernelGGL((rfft_fwd_kernel<0, 1>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv);
   }
   return sdy_launch_status();
 }
 
 int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
-                       hipStream_t stream) {
+                       int ilv, hipStream_t stream) {
+  if (ilv && C % CB != 0) return SDY_ERR_UNSUPPORTED;
   if (f.n == 180 && !use_generic_only()) {
-    const int rc = sdy_fft360_launch_inv(f, Yf, bias, y, B, C, K, mtr, stream);
+    const int rc = sdy_fft360_launch_inv(f, Yf, bias, y, B, C, K, mtr, ilv, stream);
     if (rc != SDY_ERR_UNSUPPORTED) return rc;
   }
   const size_t smem = fft_smem_bytes(f);
@@ -461,12 +463,12 @@ int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, 
   constexpr int KPW = 4;
   dim3 grid((C + CB - 1) / CB, (K + KPW - 1) / KPW, B);
   if (f.n == 180) {
-    hipLaunchKernelGGL((irfft_kernel<180, KPW>), grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+    hipLaunchKernelGGL((irfft_kernel<180, KPW>), grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr, ilv);
   } else if (f.n == 32) {
-    hipLaunchKernelGGL((irfft_kernel<32, KPW>), grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+    hipLaunchKernelGGL((irfft_kernel<32, KPW>), grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr, ilv);
   } else {
     grid.y = K;
-    hipLaunchKernelGGL((irfft_kernel<0, 1>), grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr);
+    hipLaunchKernelGGL((irfft_kernel<0, 1>), grid, dim3(NT), smem, stream, f, Yf, bias, y, B, C, K, mtr, ilv);
   }
   return sdy_launch_status();
 }

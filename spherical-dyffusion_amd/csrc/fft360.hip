@@ -204,7 +204,7 @@ template <int KPW>
 __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f, const float* __restrict__ x,
                                                            const float* __restrict__ pa, const float* __restrict__ pd,
                                                            float* __restrict__ xn_out, float* __restrict__ Xf, int B,
-                                                           int C, int K, int mtr) {
+                                                           int C, int K, int mtr, int ilv) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
   __shared__ c2 TW[TWN];
   __shared__ c2 AD[ROWS];   // per-slot affine (a, d)
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
   const c2* zn01 = Z + c4 * P + (NH - 64 - mg);    // Z[n - m]: zn01[64 (1 - it)]   it = 0, 1
   const c2* zn2 = Z + c4 * P + max(NH - 128 - mg, 0);
   const long mstride = (long)K * B * 2 * C;
+  const int re_off = (ilv ? 2 * c0 : c0) + 4 * c4, im_off = ilv ? 16 : C;   // see fft.h
 
   f32x4 regs[8];
   auto gload = [&](int k) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
     __syncthreads();
 
     // ---- split step + m-major stores: X[m] = h (A + conj B) + W (A - conj B), A = Z[m], B = Z[n - m]
-    float* Xk = Xf + ((long)k * B + b) * 2 * C + c0 + 4 * c4;
+    float* Xk = Xf + ((long)k * B + b) * 2 * C + re_off;
 #pragma unroll
     for (int it = 0; it < MIT; ++it) {
       const int m = mg + 64 * it;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
         }
         float* o = Xk + (long)m * mstride;
         *reinterpret_cast<f32x4*>(o) = vr;
-        *reinterpret_cast<f32x4*>(o + C) = vi;
+        *reinterpret_cast<f32x4*>(o + im_off) = vi;
       }
     }
     __syncthreads();   // the rows are rewritten by the next ring
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
 template <int KPW>
 __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
                                                             const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                            int C, int K, int mtr) {
+                                                            int C, int K, int mtr, int ilv) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
   __shared__ c2 TW[TWN];
   __shared__ c2 PW[NH];       // exp(+2 pi i j / N)
@@ -331,9 +332,10 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
   // m-major loads: thread (c4, mg), m = mg + 64*it <= 180; rows of channels 4*c4 + j are slots c4 + 4*j
   const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
   const long mstride = (long)K * B * 2 * C;
+  const int re_off = (ilv ? 2 * c0 : c0) + 4 * c4, im_off = ilv ? 16 : C;   // see fft.h
   f32x4 rr[MIT], ri[MIT];
   auto gload = [&](int k) {
-    const float* Yk = Yf + ((long)k * B + b) * 2 * C + c0 + 4 * c4;
+    const float* Yk = Yf + ((long)k * B + b) * 2 * C + re_off;
 #pragma unroll
     for (int it = 0; it < MIT; ++it) {
       const int m = mg + 64 * it;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
       if (m < mtr) {
         const float* o = Yk + (long)m * mstride;
         vr = *reinterpret_cast<const f32x4*>(o);
-        vi = *reinterpret_cast<const f32x4*>(o + C);
+        vi = *reinterpret_cast<const f32x4*>(o + im_off);
       }
       if (m == 0 || m == NH) vi = f32x4{0.f, 0.f, 0.f, 0.f};   // irfft ignores the imaginary parts of DC / Nyquist
       rr[it] = vr;
@@ -402,19 +404,19 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
 
 // nlon = 360 fast path; returns SDY_ERR_UNSUPPORTED when the shape does not fit (the caller falls back to fft.hip)
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                          int B, int C, int K, int mtr, hipStream_t stream) {
+                          int B, int C, int K, int mtr, int ilv, hipStream_t stream) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = SDY_FFT_KPW;
   dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
-  hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr);
+  hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv);
   return sdy_launch_status();
 }
 
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
-                          int mtr, hipStream_t stream) {
+                          int mtr, int ilv, hipStream_t stream) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = SDY_FFT_KPW;
   dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
-  hipLaunchKernelGGL((irfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, Yf, bias, y, B, C, K, mtr);
+  hipLaunchKernelGGL((irfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, Yf, bias, y, B, C, K, mtr, ilv);
   return sdy_launch_status();
 }

@@ -7,5 +7,5 @@ for D in "$@"; do
   make CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $D" fft360.o > /dev/null 2>&1
   make > /dev/null 2>&1
   echo "== $D"
-  (cd $R && python tools/stage_bench.py 25 2>&1 | grep -E "fft"; python tools/stage_bench.py 25 2>&1 | grep -E "fft")
+  (cd $R && python tools/stage_bench.py 25 2>&1 | grep -E "fft")
 done
