@@ -110,6 +110,16 @@ int sdy_dhconv_h3_pack_weight(const float* w_host, int Ci, int Co, int L, void* 
 int sdy_dhconv_h3(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B, int Ci,
                   int Co, void* stream);
 
+/* Same contraction for Ci = Co = 256 as a persistent fragment-stream kernel (dh_h3.hip): a workgroup owns 64 rows and
+ * all 512 output columns, so every coefficient row is read once; the packed weight (1 MB per degree, MFMA fragment
+ * order) streams L2 -> registers and each degree is served by one XCD.  Same reference lines as sdy_dhconv
+ * (src/models/sfno/contractions.py:159-169).  `scale` is what the pack returned. */
+int sdy_dhconv_frag_supported(int Ci, int Co);
+size_t sdy_dhconv_frag_pack_bytes(int L);
+int sdy_dhconv_frag_pack(const float* w_host, int L, void* packed_dev, float* scale);
+int sdy_dhconv_frag(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B,
+                    void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * nn.InstanceNorm2d(C, eps, affine=True, track_running_stats=False) statistics folded with the block's time
  * scale/shift (src/models/sfno/sfnonet.py:280-299,641-648) into per-(b,c) coefficients:

@@ -134,6 +134,10 @@ SIGNATURES = {
     "sdy_dhconv_h3_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "sdy_dhconv_h3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p]),
+    "sdy_dhconv_frag_supported": (C.c_int, [C.c_int, C.c_int]),
+    "sdy_dhconv_frag_pack_bytes": (C.c_size_t, [C.c_int]),
+    "sdy_dhconv_frag_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "sdy_dhconv_frag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sdy_instnorm_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_conv1x1": (C.c_int, [C.POINTER(SdyConvArgs), C.c_void_p]),

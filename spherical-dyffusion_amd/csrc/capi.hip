@@ -673,7 +673,11 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
     }
     if (rest == "filter.filter.weight") {
       EXPECT_NUMEL((size_t)E * E * c.lmax * 2);
-      if (h3) {
+      static const bool no_dh_frag = std::getenv("SDY_NO_DH_FRAG") != nullptr;
+      if (h3 && sdy_dhconv_frag_supported(E, E) && !no_dh_frag) {   // persistent fragment-stream kernel (dh_h3.hip)
+        if (!w.fw.frag) SDY_HIP_TRY(hipMalloc(&w.fw.frag, sdy_dhconv_frag_pack_bytes(c.lmax)));
+        SDY_TRY(sdy_dh_h3_pack(host, c.lmax, w.fw.frag, &w.fw.frag_scale, spec_ilv(c)));
+      } else if (h3) {
         if (w.fw.h3) (void)hipFree(w.fw.h3);
         w.fw.h3 = nullptr;
         SDY_HIP_TRY(hipMalloc(&w.fw.h3, sdy_dhconv_h3_pack_bytes(E, E, c.lmax)));
@@ -890,7 +894,9 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       SDY_TRY(sdy_legendre_inv(pout, Cs, Xf, B, E, stream));
       SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, ilv, stream));
     }
-    if (c.gemm_mode == 1)
+    if (bw.fw.frag)
+      SDY_TRY(sdy_dhconv_frag(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, B, stream));
+    else if (c.gemm_mode == 1)
       SDY_TRY(sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     else
       SDY_TRY(sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));

@@ -110,6 +110,8 @@ int sdy_gemm_h3_ws_launch(const GemmParams& p, const void* packed, int rows_pad,
 
 // ---- persistent 256 -> 256 convolution (conv_h3.hip)
 int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream);
+// dh_h3.hip: fragment-stream pack of the dhconv weight; ilv = channel order of the 2C axis (fft.h)
+int sdy_dh_h3_pack(const float* w_host, int L, void* packed_dev, float* scale, int ilv);
 
 // ---- skinny Legendre GEMM with the table streamed as MFMA fragments (leg_h3.hip), rows and K <= 192
 typedef float (*sdy_leg_value_fn)(void* ctx, int z, int row, int k);

@@ -45,7 +45,14 @@ def contract_dhconv(x: torch.Tensor, weight: torch.Tensor, separable: bool = Fal
     w_host = weight.detach().to(torch.float32).cpu().contiguous()
     from ._lib import default_gemm_mode
     with torch.cuda.device(x.device):
-        if (gemm_mode or default_gemm_mode()) == "h3":
+        mode = gemm_mode or default_gemm_mode()
+        if mode == "h3" and lib.sdy_dhconv_frag_supported(Ci, Co):
+            wp = torch.empty(lib.sdy_dhconv_frag_pack_bytes(L), dtype=torch.uint8, device=x.device)
+            sc = C.c_float()
+            check(lib.sdy_dhconv_frag_pack(ptr(w_host), L, ptr(wp), C.byref(sc)), "sdy_dhconv_frag_pack")
+            check(lib.sdy_dhconv_frag(ptr(cs_in), ptr(wp), sc.value, ptr(cs_out), L, mtr, B, current_stream()),
+                  "sdy_dhconv_frag")
+        elif mode == "h3":
             wp = torch.empty(lib.sdy_dhconv_h3_pack_bytes(Ci, Co, L), dtype=torch.uint8, device=x.device)
             sc = C.c_float()
             check(lib.sdy_dhconv_h3_pack_weight(ptr(w_host), Ci, Co, L, ptr(wp), C.byref(sc)), "sdy_dhconv_h3_pack_weight")

@@ -80,7 +80,7 @@ def test_sht_roundtrip_bandlimited(sdy):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("B,E,L,M", [(2, 8, 32, 33), (1, 256, 180, 181), (3, 16, 20, 11)])
+@pytest.mark.parametrize("B,E,L,M", [(2, 8, 32, 33), (1, 256, 180, 181), (3, 16, 20, 11), (3, 256, 20, 11), (5, 256, 9, 10)])
 def test_dhconv(sdy, B, E, L, M, mode):
     g = _gen(4)
     x = torch.randn(B, E, L, M, dtype=torch.complex64, generator=g)

@@ -43,5 +43,10 @@ bench("rfft (affine, store xn)", lambda: check(lib.sdy_rfft_lon(plan.handle, ptr
 bench("rfft (no xn store)", lambda: check(lib.sdy_rfft_lon(plan.handle, ptr(x), ptr(a), ptr(d), None, ptr(Xf), B, E, st())), 2 * T)
 bench("legendre_fwd", lambda: check(lib.sdy_legendre_fwd(plan.handle, ptr(Xf), ptr(Cs), B, E, st())), 1.5 * T, 3.0e9 * B)
 bench("dhconv", lambda: check(lib.sdy_dhconv(ptr(Cs), ptr(wp), ptr(Cs2), L, mtr, B, E, E, st())), T + 94.4e6, 8.54e9 * B)
+wf = torch.empty(lib.sdy_dhconv_frag_pack_bytes(L), dtype=torch.uint8, device=dev)
+import ctypes as _C
+_sc = _C.c_float()
+check(lib.sdy_dhconv_frag_pack(ptr(w.contiguous()), L, ptr(wf), _C.byref(_sc)))
+bench("dhconv (fragment stream)", lambda: check(lib.sdy_dhconv_frag(ptr(Cs), ptr(wf), _sc.value, ptr(Cs2), L, mtr, B, st())), T + 94.4e6 * 2, 8.54e9 * B)
 bench("legendre_inv", lambda: check(lib.sdy_legendre_inv(plan.handle, ptr(Cs2), ptr(Xf), B, E, st())), 1.5 * T, 3.0e9 * B)
 bench("irfft (+bias)", lambda: check(lib.sdy_irfft_lon(plan.handle, ptr(Xf), ptr(bias), ptr(y), B, E, st())), 2 * T)
