@@ -12,7 +12,8 @@
 //   * the 64 x 512 activation tile is fetched once, split hi/lo and parked in LDS ([row][k], XOR-swizzled, 128 KB);
 //   * wave w computes columns 64w .. 64w+63: the weight never touches LDS, it is packed per (l, wave) as a linear stream of
 //     MFMA B-fragment pairs (hi, lo) in consumption order and flows L2 -> registers through an 8-group ring;
-//   * the accumulators (rows x columns, column = lane) are stored straight from registers as 128-byte row segments.
+//   * the accumulators (rows x columns, column = lane) are transposed per wave through a private 2 KB LDS area and stored
+//     as 16 bytes per lane, 256-byte row segments.
 // Work distribution: each degree l belongs to ONE XCD (boustrophedon over l, so the (l+1)-proportional work balances), and
 // the 32 workgroups of an XCD walk its tile list interleaved -- at any time they sit on the same one or two degrees, whose
 // 1 MB weight streams stay in that XCD's 4 MB L2 and are fetched from HBM once.
@@ -45,6 +46,7 @@ struct DhParams {
   const f16x8* w;                  // [l][8 waves][DGPW groups][hi | lo][64 lanes]
   int L, mtr, B;
   float out_scale;
+  unsigned long long* stamps;      // timing experiments only (SDY_DH_STAMPS)
 };
 
 __device__ __forceinline__ int dh_swz(int r) { return (r & 15) ^ (((r >> 4) & 1) * 3); }
@@ -97,9 +99,11 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
 
   // activation rows of a tile: clamped to row 0 of the degree beyond the ragged edge (zeroed when staged)
   f32x4 xr[8][2];
-  auto x_ptr = [&](const TileIt& it, int i) {
-    const int row = it.t * DTN + r0 + 8 * i;
-    return p.X + (long)it.l * p.sX + (long)(row < dh_rows(p, it.l) ? row : 0) * DK + 8 * oc;
+  auto x_ptr = [&](const TileIt& it, int i) {   // uniform degree base + a 32-bit lane offset
+    int rr = r0;
+    asm volatile("" : "+v"(rr));   // computed where it is used: 16 hoisted addresses would not fit the register budget
+    const int row = it.t * DTN + rr + 8 * i;
+    return p.X + (long)it.l * p.sX + (unsigned)((row < dh_rows(p, it.l) ? row : 0) * DK + 8 * oc);
   };
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -108,10 +112,17 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
     xr[i][1] = *reinterpret_cast<const f32x4*>(g + 4);
   }
 
+  int tile_it = -1;
   while (true) {
+    ++tile_it;
     // laundered per tile: keeps the unrolled loops' LDS addresses from being hoisted into (spilled) loop invariants
     asm volatile("" : "+v"(l31), "+v"(h), "+v"(oc), "+v"(r0));
     const int M = dh_rows(p, cur.l);
+    auto stamp = [&](int i) {
+      if (p.stamps && blockIdx.x == 11 && lane == 0 && tile_it >= 2 && tile_it < 6)
+        p.stamps[((tile_it - 2) * 8 + wave) * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     const int row0 = cur.t * DTN;
     TileIt nxt = cur;
     dh_advance(p, nxt, xcd, nslots);
@@ -135,12 +146,11 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
       *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
       *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
     }
+    stamp(1);
     __syncthreads();
+    stamp(2);
 
     // ---- MFMA phase: all 64 rows x columns 64 wave .. +64, K = 512
-    const float* xn[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) xn[i] = x_ptr(pre, i);
     const wptr_t wnext = w_base(pre.l);
     f32x16 acc[2][2];   // [row tile j][column tile ni]
 #pragma unroll
@@ -149,6 +159,21 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][ni][r] = 0.0f;
+    // Order inside a k-step: the four (x lo) x (w hi) products first -- then the x-lo fragments of the NEXT k-step are
+    // requested into the same registers -- then the eight products that read the x-hi fragments, whose successors are
+    // requested last and arrive under the next k-step's first four MFMAs.  (A wave that loads its fragments at the top of
+    // every k-step and waits keeps the matrix pipe about 60 % busy; double-buffered fragment registers do not fit.)
+    f16x8 ah[2], al[2];
+    auto load_lo = [&](int ks) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) al[j] = *reinterpret_cast<const f16x8*>(Xs_lo + dh_off(32 * j + l31, 2 * ks + h));
+    };
+    auto load_hi = [&](int ks) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ah[j] = *reinterpret_cast<const f16x8*>(Xs_hi + dh_off(32 * j + l31, 2 * ks + h));
+    };
+    load_lo(0);
+    load_hi(0);
 #pragma unroll
     for (int kb = 0; kb < DKS / 4; ++kb) {
       if (kb == DKS / 4 - 1) {   // the refills of the last block fetch block 0 of the next tile's stream
@@ -157,56 +182,97 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ks = 4 * kb + i;
-        f16x8 ah[2], al[2];
+        const int ks = 4 * kb + i, s0 = 2 * i, s1 = 2 * i + 1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int off = dh_off(32 * j + l31, 2 * ks + h);
-          ah[j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
-          al[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], r_hi[s0 + ni], acc[j][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef DH_NOLDS
+        if (ks + 1 < DKS) load_lo(ks + 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], r_lo[s0 + ni], acc[j][ni], 0, 0, 0);
+#ifndef DH_NOW
+        r_lo[s0] = wp[s0 * DGROUP + 64];
+        r_lo[s1] = wp[s1 * DGROUP + 64];
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], r_hi[s0 + ni], acc[j][ni], 0, 0, 0);
+#ifndef DH_NOW
+        r_hi[s0] = wp[s0 * DGROUP];
+        r_hi[s1] = wp[s1 * DGROUP];
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef DH_NOLDS
+        if (ks + 1 < DKS) load_hi(ks + 1);
+#endif
+#ifndef DH_NOPREFETCH
+        if ((i & 1) == 0) {   // one 16-byte piece of the next tile per two k-steps, never a burst
+          const int g = 2 * kb + (i >> 1);   // 0..15
+          xr[g >> 1][g & 1] = *reinterpret_cast<const f32x4*>(x_ptr(pre, g >> 1) + 4 * (g & 1));
         }
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int s = 2 * i + ni;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], r_hi[s], acc[j][ni], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], r_lo[s], acc[j][ni], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], r_hi[s], acc[j][ni], 0, 0, 0);
-          r_hi[s] = wp[s * DGROUP];
-          r_lo[s] = wp[s * DGROUP + 64];
-          if ((s & 3) == 0) {   // one 16-byte piece of the next tile per four weight groups, never a burst
-            const int g = (8 * kb + s) >> 2;   // 0..15
-            xr[g >> 1][g & 1] = *reinterpret_cast<const f32x4*>(xn[g >> 1] + 4 * (g & 1));
-          }
-          __builtin_amdgcn_sched_barrier(0);   // keep the loads here (the scheduler otherwise sinks them next to their use)
-        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
       }
+#ifndef DH_WSAME
       wp += DRING * DGROUP;
+#endif
     }
 
-    // ---- epilogue: row (r & 3) + 8 (r >> 2) + 4 h of each row tile, column = lane: 128-byte row segments
+    stamp(3);
+    // ---- epilogue: the accumulators hold column = lane, i.e. a direct store is 4 bytes per lane (measured: the 64 dword
+    // stores per lane took 40 % of the tile).  Each wave transposes 8-row chunks of its 64 x 64 block through a private
+    // 2 KB LDS staging area (in-order LDS of one wave: no barrier) and stores 16 bytes per lane, 256-byte row segments.
     {
-      float* og = p.out + (long)cur.l * p.sC + (long)row0 * DN + 64 * wave + l31;
+      float* stg = reinterpret_cast<float*>(smem + 2 * DTN * DK * sizeof(_Float16)) + wave * (8 * 64);
+      const int srow = lane >> 4, sc4 = lane & 15;
+      float* og = p.out + (long)cur.l * p.sC + (long)row0 * DN + 64 * wave + 4 * sc4;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (row0 + row < M) {
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) og[(long)row * DN + 32 * ni] = acc[j][ni][r] * p.out_scale;
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stg[(q + 4 * h) * 64 + 32 * ni + l31] = acc[j][ni][4 * g + q] * p.out_scale;
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int row = 32 * j + 8 * g + srow + 4 * hh;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (srow + 4 * hh) * 64 + 4 * sc4);
+            if (row0 + row < M) *reinterpret_cast<f32x4*>(og + (long)row * DN) = v;
           }
+          __builtin_amdgcn_wave_barrier();
         }
     }
+    stamp(4);
     if (!more) break;
     cur = nxt;
     __syncthreads();   // every wave is done reading the LDS tile
+    stamp(5);
   }
 }
 
 }  // namespace
+
+static unsigned long long* g_dstamps = nullptr;
+extern "C" int sdy_dhconv_frag_debug_stamps(unsigned long long* host256) {
+  unsigned long long* host64 = host256;
+  if (!g_dstamps || !host64) return SDY_ERR_STATE;
+  SDY_HIP_TRY(hipDeviceSynchronize());
+  SDY_HIP_TRY(hipMemcpy(host64, g_dstamps, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return SDY_OK;
+}
 
 extern "C" int sdy_dhconv_frag_supported(int Ci, int Co) { return (Ci == DE && Co == DE) ? 1 : 0; }
 
@@ -263,8 +329,13 @@ extern "C" int sdy_dhconv_frag(const float* Cs_in, const void* packed, float sca
   p.w = reinterpret_cast<const f16x8*>(packed);
   p.L = L; p.mtr = mtr; p.B = B;
   p.out_scale = 1.0f / (scale * DSX);
+  p.stamps = nullptr;
+  if (std::getenv("SDY_DH_STAMPS")) {
+    if (!g_dstamps) SDY_HIP_TRY(hipMalloc(&g_dstamps, 256 * sizeof(unsigned long long)));
+    p.stamps = g_dstamps;
+  }
   static int n_cu = 0;
-  const int smem = 2 * DTN * DK * (int)sizeof(_Float16);
+  const int smem = 2 * DTN * DK * (int)sizeof(_Float16) + DWAVES * 8 * 64 * (int)sizeof(float);   // x tile + staging
   if (!n_cu) {
     int dev = 0;
     SDY_HIP_TRY(hipGetDevice(&dev));

@@ -17,7 +17,7 @@ for r in rows:
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     cnt[(k, r["Counter_Name"])] += 1
 for k, d in agg.items():
-    if "gemm" not in k and "fft" not in k and "mlp" not in k: continue
+    if not any(t in k for t in ("gemm", "fft", "mlp", "dh_h3", "leg_h3", "conv_h3")): continue
     print(k)
     for c, v in d.items(): print(f"    {c:28s} {v / cnt[(k, c)]:16.1f} (avg per dispatch, {cnt[(k,c)]} dispatches)")
 PY
