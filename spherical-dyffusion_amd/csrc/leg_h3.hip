@@ -35,7 +35,6 @@ struct LegParams {
   float* C; long ldc, sC;        // result: row r at C + z * sC + r * ldc
   int M_store, K, N;
   int tri;                       // SDY_TRI_LEG_FWD / SDY_TRI_LEG_INV
-  int nz;                        // orders m (batch count)
   float out_scale;
 };
 
@@ -52,13 +51,8 @@ __global__ __launch_bounds__(192, 3) void leg_h3_kernel(const LegParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  // Workgroup -> (column tile, order m).  Consecutive workgroup ids are dealt round-robin to the 8 XCDs; all column tiles
-  // of one m share its 144 KB table, so m is pinned to XCD m % 8: the table is fetched into ONE L2 instead of eight.
-  const int nx = (p.N + LTN - 1) / LTN;
-  const int slot = (int)blockIdx.x >> 3;
-  const int z = (slot / nx) * 8 + ((int)blockIdx.x & 7);
-  if (z >= p.nz) return;
-  const int n0 = (slot % nx) * LTN;
+  const int z = blockIdx.y;
+  const int n0 = blockIdx.x * LTN;
   const bool full = n0 + LTN <= p.N;
 
   const bool fwd = p.tri == SDY_TRI_LEG_FWD;
@@ -237,8 +231,7 @@ int sdy_leg_h3_launch(const void* table, float scale, int nz, const float* X, lo
   p.C = C; p.ldc = ldc; p.sC = sC;
   p.M_store = M_store; p.K = K; p.N = N; p.tri = tri;
   p.out_scale = 1.0f / (scale * LSX);
-  p.nz = nz;
-  dim3 grid(((N + LTN - 1) / LTN) * ((nz + 7) / 8) * 8);
+  dim3 grid((N + LTN - 1) / LTN, nz);
   hipLaunchKernelGGL(leg_h3_kernel, grid, dim3(192), 0, stream, p);
   return sdy_launch_status();
 }
