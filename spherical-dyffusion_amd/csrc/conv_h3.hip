@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
 
   // Software pipeline over tiles (one workgroup per CU, full register budget).  Loads are issued ONE per step, never as
   // a burst: a wave that issues more than the CU can keep in flight stalls at issue until HBM has delivered (a burst of
-  // 32 KB per wave measured 9-20k idle cycles).  Tile t+1's pixels (xr) ride on tile t's MFMA groups, tile t+1's addend
-  // rows (addn) on tile t's store loop; both are consumed a full phase later.
+  // 32 KB per wave measured 9-20k idle cycles).  Tile t+1's pixels (xr) and addend rows (addn) both ride on tile t's
+  // store loop; the MFMA phase only streams the L2-resident weight ring.
   f32x4 xr[2][8], addv[16], addn[16];
   auto x_ptr = [&](int t) {
     const int zz = t / tpi, nn = (t - zz * tpi) * CTN;
@@ -201,10 +201,6 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
           for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], acc[mi][j], 0, 0, 0);
           r_hi[s] = wp[s * CGROUP];
           r_lo[s] = wp[s * CGROUP + 64];
-          if ((s & 1) == 0) {   // one pixel load of the next tile per two weight groups
-            const int g = (8 * kb + s) >> 1;   // 0..15
-            xr[g >> 3][g & 7] = *reinterpret_cast<const f32x4*>(xnext + (long)(8 * (o0 + 16 * (g >> 3)) + (g & 7)) * p.HW);
-          }
           __builtin_amdgcn_sched_barrier(0);   // keep the loads here (the scheduler otherwise sinks them next to their use)
         }
       }
@@ -241,6 +237,9 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
         if (c_ok) *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
         // next tile's addend row, one per step (every lane: a lane beyond a ragged tile's edge still owns pixels of the next)
         addn[i] = *reinterpret_cast<const f32x4*>(anext + (long)(16 * i) * p.HW);
+        // next tile's pixels, one piece per step as well: with them out of the MFMA phase the weight ring no longer queues
+        // behind HBM loads there (vmcnt retires in order): MFMA phase 12.0k -> 7.6k cycles, kernel -3 %
+        xr[i >> 3][i & 7] = *reinterpret_cast<const f32x4*>(xnext + (long)(8 * (o0 + 16 * (i >> 3)) + (i & 7)) * p.HW);
         if (c_ok) {
           psum[i] += (double)((v.x + v.y) + (v.z + v.w));
           psq[i] += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
