@@ -21,10 +21,13 @@
  * Dropout stream (the reference uses torch's global generator: src/models/sfno/layers.py:76-78,
  * src/models/modules/drop_path.py:19 -- not reproducible across devices, so the product defines its own):
  *   Philox4x32-10, key = (seed_lo, seed_hi), counter = (c0, c1, stream, call)
- *     element dropout : c0 = pixel (h*nlon + w), c1 = b_global*(C/4) + (ch>>2), word = ch & 3,
- *                       stream = 2*layer + kind (kind 0 = MLP hidden, 1 = MLP output)
- *     drop path       : c0 = b_global, c1 = 0xFFFFFFFF, stream = 0x1000 + layer, word 0
- *   keep <=> word >= floor(p * 2^32);  kept values are scaled by 1/(1-p).
+ *     element dropout : n = pixel (h*nlon + w); c0 = n with bit 5 cleared, c1 = b_global*(C/4) + (ch>>2), word = ch & 3,
+ *                       half-word = bit 5 of n (0: low 16 bits, 1: high 16 bits),
+ *                       stream = 2*layer + kind (kind 0 = MLP hidden, 1 = MLP output);
+ *                       keep <=> half-word >= floor(p * 2^16)   (one call serves 4 channels x the pixel pair n, n + 32)
+ *     drop path       : c0 = b_global, c1 = 0xFFFFFFFF, stream = 0x1000 + layer, word 0;
+ *                       keep <=> word >= floor(p * 2^32)
+ *   kept values are scaled by 1/(1-p).
  */
 #ifndef SDY_AMD_H
 #define SDY_AMD_H

@@ -57,18 +57,30 @@ def drop_threshold(p: float) -> int:
     return min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF)
 
 
+def drop_threshold16(p: float) -> int:
+    """16-bit threshold of the element dropout: keep <=> half-word >= threshold (p at fp32 precision)."""
+    p32 = float(np.float32(p))
+    return min(max(int(p32 * 65536.0), 1 if p32 > 0.0 else 0), 0xFFFF)   # p > 0 never rounds to "no dropout"
+
+
 def element_keep_mask(seed: int, call: int, layer: int, kind: int, p: float,
                       B: int, C: int, H: int, W: int, batch_offset: int = 0) -> np.ndarray:
-    """Keep mask (B, C, H, W) of 0/1 float32 for MLP dropout (kind 0 = hidden, 1 = output)."""
+    """Keep mask (B, C, H, W) of 0/1 float32 for MLP dropout (kind 0 = hidden, 1 = output).
+
+    One Philox call covers 4 channels x the pixel pair (n & ~32, n | 32): word = ch & 3, low half-word for the pixel
+    with bit 5 clear, high half-word for its partner (include/sdy_amd.h)."""
     assert C % 4 == 0
-    thr = np.uint32(drop_threshold(p))
-    pix = np.arange(H * W, dtype=np.uint32)[None, None, :]
+    thr = np.uint32(drop_threshold16(p))
+    npix = np.arange(H * W, dtype=np.uint32)
+    pix = (npix & np.uint32(0xFFFFFFDF))[None, None, :]
+    half = ((npix >> np.uint32(5)) & np.uint32(1))[None, None, None, :]
     b = (np.arange(B, dtype=np.uint64) + np.uint64(batch_offset))[:, None, None]
     g = np.arange(C // 4, dtype=np.uint64)[None, :, None]
     c1 = ((b * np.uint64(C // 4) + g) & MASK32).astype(np.uint32)
     words = philox4x32_10(pix, c1, np.uint32(2 * layer + kind), np.uint32(call & 0xFFFFFFFF),
                           seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     w = np.stack(words, axis=2)  # (B, C/4, 4, HW)
+    w = np.where(half == 1, w >> np.uint32(16), w & np.uint32(0xFFFF))
     keep = (w >= thr).astype(np.float32)
     return keep.reshape(B, C, H, W)
 

@@ -415,7 +415,7 @@ extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
   g.add = a->add_mode ? a->add : nullptr; g.sAdd = a->add_bstride; g.ldadd = a->HW; g.add_mode = a->add_mode;
   g.act = a->act;
   if (a->drop_p > 0.0f) {
-    g.drop_thr = sdy_drop_threshold(a->drop_p);
+    g.drop_thr = sdy_drop_threshold16(a->drop_p);
     if (g.drop_thr == 0u) g.drop_thr = 1u;
     g.drop_scale = 1.0f / (1.0f - a->drop_p);
     g.keep_mask = a->keep_mask;

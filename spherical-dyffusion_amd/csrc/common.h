@@ -63,6 +63,19 @@ __host__ __device__ __forceinline__ philox4 philox4x32_10(uint32_t c0, uint32_t 
   }
   return philox4{c0, c1, c2, c3};
 }
+// Element dropout takes 16 bits per decision: one Philox call (4 words) covers 4 channels x the pixel pair (n, n + 32),
+// low half-word for the pixel with bit 5 clear, high half-word for its partner (include/sdy_amd.h).  The pair is what one
+// lane of a 64-pixel MFMA tile holds, so every call is computed once and used 8 times; the 64-bit multiplies of Philox
+// run at quarter rate and were 27 % of the fused MLP with dropout.
+static inline uint32_t sdy_drop_threshold16(float p) {
+  double t = (double)p * 65536.0;
+  if (t >= 65535.0) return 0xFFFFu;
+  if (t <= 0.0) return 0u;
+  return (uint32_t)t;
+}
+__host__ __device__ __forceinline__ bool sdy_keep16(uint32_t word, int half, uint32_t thr16) {
+  return ((half ? (word >> 16) : (word & 0xFFFFu)) >= thr16);
+}
 static inline uint32_t sdy_drop_threshold(float p) {
   double t = (double)p * 4294967296.0;
   if (t >= 4294967295.0) return 0xFFFFFFFFu;

@@ -51,7 +51,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[WM][WN], const 
         const int row_base = row0 + 8 * rg;
         uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (do_drop && !maskg && (FULL || (col_ok && row_base < M_store))) {
-          const philox4 w = philox4x32_10((uint32_t)gn, c1_base + (uint32_t)(row_base >> 2), p.stream_id, p.call,
+          const philox4 w = philox4x32_10((uint32_t)gn & ~32u, c1_base + (uint32_t)(row_base >> 2), p.stream_id, p.call,
                                           p.seed_lo, p.seed_hi);
           words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
         }
@@ -63,7 +63,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[WM][WN], const 
           if (p.add_mode == 1) v += add_r[r];
           if (p.act == 1) v = gelu_erf(v);
           if (do_drop) {
-            const bool keep = maskg ? (keep_r[r] != 0.0f) : (words[r4] >= p.drop_thr);
+            const bool keep = maskg ? (keep_r[r] != 0.0f) : sdy_keep16(words[r4], (gn >> 5) & 1, p.drop_thr);
             v = keep ? v * p.drop_scale : 0.0f;
           }
           v *= bscale;

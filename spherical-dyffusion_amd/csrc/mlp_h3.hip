@@ -264,12 +264,13 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     float v[4], t[4], e[4], q[4];
     uint32_t c0, c1, c2, c3, k0, k1;
   };
+  uint32_t pw[4];   // Philox words of the last j == 0 piece: its j == 1 partner (same rows, pixel + 32) takes the high halves
   auto chain_stage = [&](Piece& s, int st, int hc, int j, int g4) {
     const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
     const int px = 32 * j + l31;
-    if (do_drop && st < 10) {
+    if (do_drop && st < 10 && j == 0) {
       if (st == 0) {
-        s.c0 = (uint32_t)(n0 + px); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = p.call;
+        s.c0 = (uint32_t)(n0 + l31); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = p.call;
         s.k0 = p.seed_lo; s.k1 = p.seed_hi;
       }
       const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0, p1 = (uint64_t)0xCD9E8D57u * s.c2;   // one Philox4x32 round
@@ -322,9 +323,9 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         break;
       case 10: {
         if (do_drop) {
-          const uint32_t words[4] = {s.c0, s.c1, s.c2, s.c3};
+          if (j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s.v[r] = (words[r] >= p.drop_thr) ? s.v[r] * p.drop_scale : 0.0f;
+          for (int r = 0; r < 4; ++r) s.v[r] = sdy_keep16(pw[r], j, p.drop_thr) ? s.v[r] * p.drop_scale : 0.0f;
         }
         break;
       }
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     for (int st = 0; st < 12; ++st) chain_stage(s, st, hc, j, g4);
   };
   // fc2 of chunk hc2 (output rows 64 wave .. +64 += W2[:, chunk] . hidden chunk from LDS), optionally with the chain
-  // of chunk hc2 + 1 interleaved: k-step t carries piece t, one stage per MFMA, each (MFMA, stage) pair fenced
+  // of chunk hc2 + 1 interleaved: k-step t carries piece t = (tile j = t & 1, row group t >> 1), one stage per MFMA, each (MFMA, stage) pair fenced
   auto fc2 = [&](int hc2, auto with_chain) {
     constexpr bool CHAIN = decltype(with_chain)::value;
     const _Float16* Hh = Hs + (hc2 & 1) * (2 * TN * HC);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
           const f16x8 b = (k >= 2 && k < 4) ? bl[c][j] : bh[c][j];
           oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, oacc[mi][j], 0, 0, 0);
           if constexpr (CHAIN) {
-            chain_stage(ps, 6 * mi + k, hc2 + 1, t >> 2, t & 3);
+            chain_stage(ps, 6 * mi + k, hc2 + 1, t & 1, t >> 1);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   fc1();
   stamp(2);
 #pragma unroll
-  for (int pc = 0; pc < 8; ++pc) chain_piece(0, pc >> 2, pc & 3);
+  for (int pc = 0; pc < 8; ++pc) chain_piece(0, pc & 1, pc >> 1);
   stamp(3);
   __syncthreads();
   stamp(4);
@@ -454,20 +455,20 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) bv[g4] = *reinterpret_cast<const f32x4*>(p.b2 + row0 + 8 * g4);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int px = 32 * j + l31;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (do_drop) {   // one call per 4 rows x the pixel pair (l31, l31 + 32)
+          const philox4 w = philox4x32_10((uint32_t)(n0 + l31), c1_base2 + (uint32_t)((row0 + 8 * g4) >> 2), p.stream2,
+                                          p.call, p.seed_lo, p.seed_hi);
+          words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
+        }
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-          if (do_drop) {
-            const philox4 w = philox4x32_10((uint32_t)(n0 + px), c1_base2 + (uint32_t)((row0 + 8 * g4) >> 2), p.stream2,
-                                            p.call, p.seed_lo, p.seed_hi);
-            words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
-          }
+        for (int j = 0; j < 2; ++j) {
+          const int px = 32 * j + l31;
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
             float o = oacc[mi][j][4 * g4 + r4] * p.s2 + bv[g4][r4];
-            if (do_drop) o = (words[r4] >= p.drop_thr) ? o * p.drop_scale : 0.0f;
+            if (do_drop) o = sdy_keep16(words[r4], j, p.drop_thr) ? o * p.drop_scale : 0.0f;
             Os[(row0 + 8 * g4 + r4) * TN + px] = o * bscale;
           }
         }
@@ -616,7 +617,7 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   p.s1 = 1.0f / (a->w1_scale * SX);
   p.s2 = 1.0f / (a->w2_scale * SX);
   if (a->drop_p > 0.0f) {
-    p.drop_thr = sdy_drop_threshold(a->drop_p);
+    p.drop_thr = sdy_drop_threshold16(a->drop_p);
     if (p.drop_thr == 0u) p.drop_thr = 1u;
     p.drop_scale = 1.0f / (1.0f - a->drop_p);
   }
