@@ -1,0 +1,37 @@
+"""The kernel-selection switches (fallback paths kept for A/B measurements) must all compute the same network.
+
+Every variant runs the same seeded forward (E = 256, 180 x 360, dropout and drop path ON, so the Philox streams of the
+fused and the unfused kernels are compared too) in its own process and is held to the default path's output.
+Tolerance: 2e-5 relative L2 (both sides are fp32-class; the bound of the path is 1e-4)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANTS = ["SDY_NO_SPEC_ILV", "SDY_NO_DH_FRAG", "SDY_NO_FFT360", "SDY_NO_FUSED_MLP", "SDY_NO_CONV_FRAG",
+            "SDY_NO_LEG_FRAG", "SDY_NO_FUSED_STATS"]
+TOL = 2e-5
+
+
+def _run(tmp_path, tag, env_extra):
+    out = tmp_path / f"{tag}.pt"
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_forward.py"), str(out)], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"{tag}: {r.stderr[-2000:]}"
+    return torch.load(out)
+
+
+@pytest.mark.gpu
+def test_kernel_selection_switches_agree(tmp_path):
+    ref = _run(tmp_path, "default", {})
+    assert torch.isfinite(ref).all()
+    for v in VARIANTS:
+        got = _run(tmp_path, v, {v: "1"})
+        err = (torch.linalg.vector_norm(got.double() - ref.double()) / torch.linalg.vector_norm(ref.double())).item()
+        assert err < TOL, f"{v}=1 differs from the default path: rel L2 {err:.3e}"
