@@ -83,6 +83,10 @@ struct sdy_sht_plan {
   void* d_wq_frag = nullptr;
   void* d_pct_frag = nullptr;
   float s_wq_frag = 1.f, s_pct_frag = 1.f;
+  // the same with the equatorial symmetry folded in (leg_par.hip; even nlat)
+  void* d_wq_par = nullptr;
+  void* d_pct_par = nullptr;
+  float s_wq_par = 1.f, s_pct_par = 1.f;
 };
 
 static int env_gemm_mode() {
@@ -183,6 +187,22 @@ extern "C" int sdy_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, in
       return x->t[((size_t)m * x->lmax + l) * x->Kpad4 + k];
     }, &cx, p->d_pct_frag, &p->s_pct_frag);
     if (r != SDY_OK) { sdy_sht_plan_destroy(p); return r; }
+    if (sdy_leg_par_supported(nlat, lmax)) {
+      e = hipMalloc(&p->d_wq_par, sdy_leg_par_table_bytes(mtr));
+      if (e == hipSuccess) e = hipMalloc(&p->d_pct_par, sdy_leg_par_table_bytes(mtr));
+      if (e != hipSuccess) { sdy_sht_plan_destroy(p); return (int)e; }
+      cx.t = wqT.data();
+      r = sdy_leg_par_pack(mtr, nlat, lmax, 1, [](void* c, int m, int l, int k) {
+        const Ctx* x = static_cast<const Ctx*>(c);
+        return x->t[((size_t)m * x->nlat + k) * x->Lpad4 + l];
+      }, &cx, p->d_wq_par, &p->s_wq_par);
+      cx.t = pf.data();
+      if (r == SDY_OK) r = sdy_leg_par_pack(mtr, nlat, lmax, 0, [](void* c, int m, int k, int l) {
+        const Ctx* x = static_cast<const Ctx*>(c);
+        return x->t[((size_t)m * x->lmax + l) * x->Kpad4 + k];
+      }, &cx, p->d_pct_par, &p->s_pct_par);
+      if (r != SDY_OK) { sdy_sht_plan_destroy(p); return r; }
+    }
   }
   p->fft.tw = p->d_tw;
   p->fft.pw = p->d_pw;
@@ -198,6 +218,8 @@ extern "C" void sdy_sht_plan_destroy(sdy_sht_plan* p) {
   if (p->d_pw) (void)hipFree(p->d_pw);
   if (p->d_wq_h3) (void)hipFree(p->d_wq_h3);
   if (p->d_pct_h3) (void)hipFree(p->d_pct_h3);
+  if (p->d_wq_par) (void)hipFree(p->d_wq_par);
+  if (p->d_pct_par) (void)hipFree(p->d_pct_par);
   if (p->d_wq_frag) (void)hipFree(p->d_wq_frag);
   if (p->d_pct_frag) (void)hipFree(p->d_pct_frag);
   delete p;
@@ -241,6 +263,10 @@ extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* C
   g.M = p->Lpad4; g.M_store = p->lmax; g.N = N; g.K = p->nlat; g.nbatch = p->mtr;
   g.tri_mode = SDY_TRI_LEG_FWD; g.tile = SDY_TILE_64x128;
   static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
+  static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
+  if (p->d_wq_par && !no_frag && !no_par)
+    return sdy_leg_par_launch(p->d_wq_par, p->s_wq_par, p->mtr, Xf, N, (long)p->nlat * N, Cs, (long)p->mtr * N, N, p->lmax,
+                              p->nlat, N, 1, (hipStream_t)stream);
   if (p->d_wq_frag && !no_frag)
     return sdy_leg_h3_launch(p->d_wq_frag, p->s_wq_frag, p->mtr, Xf, N, (long)p->nlat * N, Cs, (long)p->mtr * N, N, p->lmax,
                              p->nlat, N, SDY_TRI_LEG_FWD, (hipStream_t)stream);
@@ -261,6 +287,10 @@ extern "C" int sdy_legendre_inv(const sdy_sht_plan* p, const float* Cs, float* Y
   g.M = p->Kpad4; g.M_store = p->nlat; g.N = N; g.K = p->lmax; g.nbatch = p->mtr;
   g.tri_mode = SDY_TRI_LEG_INV; g.tile = SDY_TILE_64x128;
   static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
+  static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
+  if (p->d_pct_par && !no_frag && !no_par)
+    return sdy_leg_par_launch(p->d_pct_par, p->s_pct_par, p->mtr, Cs, (long)p->mtr * N, N, Yf, N, (long)p->nlat * N, p->nlat,
+                              p->lmax, N, 0, (hipStream_t)stream);
   if (p->d_pct_frag && !no_frag)
     return sdy_leg_h3_launch(p->d_pct_frag, p->s_pct_frag, p->mtr, Cs, (long)p->mtr * N, N, Yf, N, (long)p->nlat * N, p->nlat,
                              p->lmax, N, SDY_TRI_LEG_INV, (hipStream_t)stream);

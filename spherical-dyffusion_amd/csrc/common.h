@@ -131,6 +131,12 @@ typedef float (*sdy_leg_value_fn)(void* ctx, int z, int row, int k);
 int sdy_leg_h3_supported(int rows, int K);
 size_t sdy_leg_h3_table_bytes(int nz);
 int sdy_leg_h3_pack(int nz, int rows, int K, sdy_leg_value_fn value, void* ctx, void* dev, float* scale);
+// leg_par.hip: the same transforms with the equatorial symmetry folded in (even nlat)
+int sdy_leg_par_supported(int nlat, int lmax);
+size_t sdy_leg_par_table_bytes(int nz);
+int sdy_leg_par_pack(int nz, int nlat, int lmax, int fwd, sdy_leg_value_fn value, void* ctx, void* dev, float* scale);
+int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, long ldx, long sX, float* C, long ldc,
+                       long sC, int rows_out, int K, int N, int fwd, hipStream_t stream);
 int sdy_leg_h3_launch(const void* table, float scale, int nz, const float* X, long ldx, long sX, float* C, long ldc, long sC,
                       int M_store, int K, int N, int tri, hipStream_t stream);
 
