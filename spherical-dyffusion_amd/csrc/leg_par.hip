@@ -81,6 +81,15 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
     const float* __restrict__ xg = p.X + (long)z * p.sX + (ok ? n0 + 4 * q : 0);
     f32x4 xr[2][8];
     bool v_ok[2][8];
+    // synthesis: an octet whose 16 degrees are all below m is zero -- no loads at all (half of the octets on average)
+    const bool oct_live = p.fwd || (16 * o + 15 >= z);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xr[0][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xr[1][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      v_ok[0][e] = v_ok[1][e] = false;
+    }
+    if (oct_live)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int r = 8 * o + e;
