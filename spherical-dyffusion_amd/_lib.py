@@ -153,6 +153,7 @@ SIGNATURES = {
     "sdy_conv256_h3_supported": (C.c_int, [C.c_int, C.c_int]),
     "sdy_conv256_h3_pack_bytes": (C.c_size_t, []),
     "sdy_conv256_h3_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "sdy_conv256_h3_pack_cin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "sdy_h3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sdy_h3_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "sdy_sfno_create": (C.c_int, [C.POINTER(SdySfnoConfig), C.POINTER(C.c_void_p)]),

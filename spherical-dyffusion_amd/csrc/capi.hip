@@ -564,9 +564,10 @@ static int dev_upload_conv(DevBuf& b, const float* host, int out, int in, int ld
     b.h3 = nullptr;
     SDY_HIP_TRY(hipMalloc(&b.h3, sdy_h3_pack_bytes(out, in)));
     SDY_TRY(sdy_h3_pack_weight(host, out, in, b.h3, &b.h3_scale));
-    if (sdy_conv256_h3_supported(in, out)) {
+    static const bool only256 = std::getenv("SDY_CONV_FRAG_256_ONLY") != nullptr;   // A/B: encoders on the tile GEMM
+    if (sdy_conv256_h3_supported(in, out) && !(only256 && in != 256)) {
       if (!b.frag) SDY_HIP_TRY(hipMalloc(&b.frag, sdy_conv256_h3_pack_bytes()));
-      SDY_TRY(sdy_conv256_h3_pack(host, b.frag, &b.frag_scale));
+      SDY_TRY(sdy_conv256_h3_pack_cin(host, in, b.frag, &b.frag_scale));
     }
   }
   return SDY_OK;

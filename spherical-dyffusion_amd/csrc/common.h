@@ -123,6 +123,7 @@ int sdy_gemm_h3_ws_launch(const GemmParams& p, const void* packed, int rows_pad,
 
 // ---- persistent 256 -> 256 convolution (conv_h3.hip)
 int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream);
+extern "C" int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* dev, float* scale);   // (256, Cin) weight, Cin <= 256
 // dh_h3.hip: fragment-stream pack of the dhconv weight; ilv = channel order of the 2C axis (fft.h)
 int sdy_dh_h3_pack(const float* w_host, int L, void* packed_dev, float* scale, int ilv);
 

@@ -1,4 +1,4 @@
-// 256 -> 256 channel 1x1 convolution (the block's inner skip, the encoder's second layer) as a persistent split-fp16
+// Cin (<= 256) -> 256 channel 1x1 convolution (the block's inner skip, both encoder layers) as a persistent split-fp16
 // kernel in the style of mlp_h3.hip:
 //   out[b] = act( W . (pa[b]*x[b] + pd[b]) + bias + add_pre[b] ) + add_post[b]        (+ InstanceNorm statistics of out)
 //   * one workgroup owns 64 pixels and all 256 output rows; the activation tile is fetched once, split hi/lo and
@@ -41,6 +41,7 @@ struct ConvParams {
   float* out; long out_bs;
   double* stats;
   int HW, B;
+  int Cin;                         // input channels (<= 256; the weight stream is zero-padded to KBLK * 64)
   float out_scale;
   unsigned long long* stamps;    // timing experiments only (SDY_CONV_STAMPS)
 };
@@ -48,6 +49,8 @@ struct ConvParams {
 __device__ __forceinline__ int cv_swz(int px) { return (px & 15) ^ (((px >> 4) & 1) * 3); }
 __device__ __forceinline__ int cv_off(int px, int c) { return px * CE + (((c & 16) | ((c ^ cv_swz(px)) & 15)) << 3); }
 
+// KBLK = ceil(Cin / 64): k-blocks of 4 k-steps actually streamed (4 for the block's 256 -> 256 convs, 2 / 3 for the encoders)
+template <int KBLK>
 __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CTN * CE * 2];   // 64 KB
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
   auto add_ptr = [&](int t) {
     const int zz = t / tpi, nn = (t - zz * tpi) * CTN;
     const int cc = nn + 4 * q0;
-    return (p.add ? p.add + (long)zz * p.add_bs : p.x + (long)zz * p.x_bs) + (long)o0 * p.HW + (cc < p.HW ? cc : 0);
+    return (p.add ? p.add + (long)zz * p.add_bs : p.out + (long)zz * p.out_bs) + (long)o0 * p.HW + (cc < p.HW ? cc : 0);
   };
   if (t_begin < t_end) {
     const float* xg = x_ptr(t_begin);
@@ -102,9 +105,16 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
 #pragma unroll
     for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)(8 * (o0 + 16 * oc) + e) * p.HW);
+      for (int e = 0; e < 8; ++e) {
+        const int ch = 8 * (o0 + 16 * oc) + e;
+        xr[oc][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ch < p.Cin) xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)ch * p.HW);   // channels past Cin: no load
+      }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) addv[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+    for (int i = 0; i < 16; ++i) {
+      addv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.add) addv[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+    }
   }
 
   for (int tile = t_begin; tile < t_end; ++tile) {
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
           f16x8 vh, vl;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float v = ok ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
+            const float v = (ok && c0 + e < p.Cin) ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
             const _Float16 hv = (_Float16)v;
             vh[e] = hv;
             vl[e] = (_Float16)(v - (float)hv);
@@ -175,8 +185,8 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.0f;
 #pragma unroll
-    for (int kb = 0; kb < CKS / 4; ++kb) {
-      if (kb == CKS / 4 - 1) {   // the refills of the last block fetch block 0 again: ring ready for the next tile
+    for (int kb = 0; kb < KBLK; ++kb) {
+      if (kb == KBLK - 1) {   // the refills of the last block fetch block 0 again: ring ready for the next tile
         wp = wbase;
         asm volatile("" : "+v"(wp));
       }
@@ -236,10 +246,13 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
         if (p.add_mode == 2) v += addv[i];
         if (c_ok) *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
         // next tile's addend row, one per step (every lane: a lane beyond a ragged tile's edge still owns pixels of the next)
-        addn[i] = *reinterpret_cast<const f32x4*>(anext + (long)(16 * i) * p.HW);
+        if (p.add) addn[i] = *reinterpret_cast<const f32x4*>(anext + (long)(16 * i) * p.HW);   // (workgroup-uniform)
         // next tile's pixels, one piece per step as well: with them out of the MFMA phase the weight ring no longer queues
         // behind HBM loads there (vmcnt retires in order): MFMA phase 12.0k -> 7.6k cycles, kernel -3 %
-        xr[i >> 3][i & 7] = *reinterpret_cast<const f32x4*>(xnext + (long)(8 * (o0 + 16 * (i >> 3)) + (i & 7)) * p.HW);
+        {
+          const int ch = 8 * (o0 + 16 * (i >> 3)) + (i & 7);
+          if (ch < p.Cin) xr[i >> 3][i & 7] = *reinterpret_cast<const f32x4*>(xnext + (long)ch * p.HW);
+        }
         if (c_ok) {
           psum[i] += (double)((v.x + v.y) + (v.z + v.w));
           psq[i] += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
@@ -288,15 +301,15 @@ extern "C" int sdy_conv256_h3_debug_stamps(unsigned long long* host64) {
   return SDY_OK;
 }
 
-extern "C" int sdy_conv256_h3_supported(int Cin, int Cout) { return (Cin == CE && Cout == CE) ? 1 : 0; }
+extern "C" int sdy_conv256_h3_supported(int Cin, int Cout) { return (Cin >= 1 && Cin <= CE && Cout == CE) ? 1 : 0; }
 
 extern "C" size_t sdy_conv256_h3_pack_bytes(void) { return (size_t)4 * CGPW * CGROUP * sizeof(f16x8); }
 
-// w_host: (256, 256) row-major (Cout, Cin)
-extern "C" int sdy_conv256_h3_pack(const float* w_host, void* dev, float* scale) {
-  if (!w_host || !dev || !scale) return SDY_ERR_ARG;
+// w_host: (256, Cin) row-major (Cout, Cin), Cin <= 256 (zero-padded to 256 in the stream)
+extern "C" int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* dev, float* scale) {
+  if (!w_host || !dev || !scale || Cin < 1 || Cin > CE) return SDY_ERR_ARG;
   float mx = 0.f;
-  for (int i = 0; i < CE * CE; ++i) mx = std::fmax(mx, std::fabs(w_host[i]));
+  for (int i = 0; i < CE * Cin; ++i) mx = std::fmax(mx, std::fabs(w_host[i]));
   float s = 1.0f;
   if (mx > 0.f && std::isfinite(mx)) {
     int e;
@@ -311,7 +324,8 @@ extern "C" int sdy_conv256_h3_pack(const float* w_host, void* dev, float* scale)
       for (int mi = 0; mi < 2; ++mi, d += gh)
         for (int ln = 0; ln < 64; ++ln)
           for (int e = 0; e < 8; ++e) {
-            const float v = w_host[(size_t)(64 * w + 32 * mi + (ln & 31)) * CE + 16 * ks + 8 * (ln >> 5) + e] * s;
+            const int kk = 16 * ks + 8 * (ln >> 5) + e;
+            const float v = kk < Cin ? w_host[(size_t)(64 * w + 32 * mi + (ln & 31)) * Cin + kk] * s : 0.0f;
             const _Float16 hv = (_Float16)v;
             d[ln * 8 + e] = hv;
             d[64 * 8 + ln * 8 + e] = (_Float16)(v - (float)hv);
@@ -320,11 +334,15 @@ extern "C" int sdy_conv256_h3_pack(const float* w_host, void* dev, float* scale)
   *scale = s;
   return SDY_OK;
 }
+extern "C" int sdy_conv256_h3_pack(const float* w_host, void* dev, float* scale) {
+  return sdy_conv256_h3_pack_cin(w_host, CE, dev, scale);
+}
 
 int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   if (!a || !a->x || !a->w_frag || !a->out || a->B <= 0 || a->HW <= 0) return SDY_ERR_ARG;
   if (!sdy_conv256_h3_supported(a->Cin, a->Cout)) return SDY_ERR_UNSUPPORTED;
   if (a->drop_p > 0.f || a->keep_mask || a->batch_scale) return SDY_ERR_UNSUPPORTED;
+  if (a->pa && a->Cin != CE) return SDY_ERR_UNSUPPORTED;   // the affine prologue reads 8-channel groups
   if ((a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3) || (a->add_mode && (a->add_bstride & 3))) return SDY_ERR_ALIGN;
   ConvParams p;
   p.x = a->x; p.x_bs = a->x_bstride; p.pa = a->pa; p.pd = a->pd;
@@ -334,7 +352,7 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   p.act = a->act;
   p.out = a->out; p.out_bs = a->out_bstride;
   p.stats = a->stats;
-  p.HW = a->HW; p.B = a->B;
+  p.HW = a->HW; p.B = a->B; p.Cin = a->Cin;
   p.out_scale = 1.0f / (a->w_frag_scale * CSX);
   p.stamps = nullptr;
   if (std::getenv("SDY_CONV_STAMPS")) {
@@ -350,6 +368,11 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   const long ntiles = (long)((a->HW + CTN - 1) / CTN) * a->B;
   const long want = n_cu;   // persistent: one workgroup per CU
   dim3 grid((unsigned)(ntiles < want ? ntiles : want));
-  hipLaunchKernelGGL(conv_h3_kernel, grid, dim3(256), 0, stream, p);
+  switch ((a->Cin + 63) / 64) {
+    case 1: hipLaunchKernelGGL(conv_h3_kernel<1>, grid, dim3(256), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL(conv_h3_kernel<2>, grid, dim3(256), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL(conv_h3_kernel<3>, grid, dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL(conv_h3_kernel<4>, grid, dim3(256), 0, stream, p); break;
+  }
   return sdy_launch_status();
 }

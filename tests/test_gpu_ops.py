@@ -329,3 +329,25 @@ def test_conv256_persistent_kernel_and_statistics(sdy, B, H, W):
     # same result as the tile GEMM
     out3 = sdy.ops.conv1x1(x.cuda(), w, None, add=pe.cuda(), add_mode=2, h3=True)
     assert rel_l2(out2, out3) < 5e-6
+
+
+@pytest.mark.parametrize("Cin", [65, 128, 130, 200, 4])
+def test_conv_cin_to_256_persistent_kernel(sdy, Cin):
+    """The persistent kernel with fewer than 256 input channels (the encoders' first layers: 65 and 128 channels in
+    the benchmark configuration): bias + GELU epilogue, no addend, ragged image edge (3 x 20 x 36 = 12 tiles of 64 + ragged)."""
+    g = _gen(47)
+    F = torch.nn.functional
+    B, H, W = 3, 20, 37 * 4
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.3 - 0.2
+    w = torch.randn(256, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = 0.1 * torch.randn(256, generator=g)
+    frag = sdy.ops.pack_conv256(w, "cuda")
+    out = sdy.ops.conv1x1(x.cuda(), w, b, gelu=True, frag_prepared=frag)
+    ref = F.gelu(F.conv2d(x.double(), w.double(), b.double()))
+    assert rel_l2(out, ref) < TOL_OP
+    st = torch.zeros(B, 256, 2, dtype=torch.float64, device="cuda")
+    out2 = sdy.ops.conv1x1(x.cuda(), w, None, frag_prepared=frag, stats=st)
+    ref2 = F.conv2d(x.double(), w.double())
+    assert rel_l2(out2, ref2) < TOL_OP
+    want = torch.stack([ref2.sum((2, 3)), (ref2 * ref2).sum((2, 3))], -1)
+    assert torch.allclose(st.cpu(), want, rtol=1e-4, atol=1e-5 * H * W)
