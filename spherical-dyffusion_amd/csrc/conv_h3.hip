@@ -26,15 +26,28 @@ namespace {
 constexpr int CE = 256;          // channels in = out
 constexpr int CTN = 64;          // pixels per tile
 constexpr int CKS = CE / 16;     // k-steps
-constexpr int CRING = 8;         // groups in flight (4 k-steps x 2 m-tiles)
-constexpr int CGPW = 2 * CKS;    // groups per wave
+// Waves per workgroup.  8 = two per SIMD: the arbiter then fills one wave's LDS / memory waits and its VALU-only phases
+// (fp16 split of the tile, GELU + statistics of the store loop) with the other wave's instructions; with 4 waves every
+// phase of the tile ran alone on its SIMD (dh_h3.hip has the measurements that led here).
+#ifndef SDY_CONV_NW
+#define SDY_CONV_NW 8
+#endif
+constexpr int CNW = SDY_CONV_NW;
+static_assert(CNW == 4 || CNW == 8, "4 or 8 waves");
+constexpr int CNT = 64 * CNW;    // threads
+constexpr int CMT = 8 / CNW;     // 32-row output tiles per wave
+constexpr int COC = 8 / CNW;     // channel octets per thread in the staging role (octets o0 + 4 CNW * oc)
+constexpr int CRPT = 64 / CNW;   // output rows per thread in the store loop (rows o0 + 4 CNW * i)
+constexpr int CRS = 4 * CNW;     // = range of o0 = tid / 16
+constexpr int CRING = 4 * CMT;   // groups in flight (4 k-steps x CMT m-tiles)
+constexpr int CGPW = CMT * CKS;  // groups per wave
 constexpr int CGROUP = 2 * 64;   // f16x8 elements per group
 constexpr float CSX = 16.0f;
 
 struct ConvParams {
   const float* x; long x_bs;
   const float* pa; const float* pd;
-  const f16x8* w;                  // [4 waves][CGPW groups][hi | lo][64 lanes]
+  const f16x8* w;                  // [CNW waves][CGPW groups][hi | lo][64 lanes]
   const float* bias;
   const float* add; long add_bs; int add_mode;   // 1: before the activation, 2: after it
   int act;
@@ -51,7 +64,7 @@ __device__ __forceinline__ int cv_off(int px, int c) { return px * CE + (((c & 1
 
 // KBLK = ceil(Cin / 64): k-blocks of 4 k-steps actually streamed (4 for the block's 256 -> 256 convs, 2 / 3 for the encoders)
 template <int KBLK>
-__global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CTN * CE * 2];   // 64 KB
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
   _Float16* Xs_lo = Xs_hi + CTN * CE;
@@ -78,18 +91,18 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
   }
   wp += CRING * CGROUP;
 
-  float brow[16];            // bias of the rows this thread stores (rows tid / 16 + 16 i): the same for every tile
+  float brow[CRPT];          // bias of the rows this thread stores (rows tid / 16 + CRS i): the same for every tile
 #pragma unroll
-  for (int i = 0; i < 16; ++i) brow[i] = p.bias ? p.bias[o0 + 16 * i] : 0.0f;
-  double psum[16], psq[16];   // fp64: sums of fp32 per-tile partials are then exact, i.e. independent of the tiling   // statistics partials of those rows
+  for (int i = 0; i < CRPT; ++i) brow[i] = p.bias ? p.bias[o0 + CRS * i] : 0.0f;
+  double psum[CRPT], psq[CRPT];   // statistics partials of those rows; fp64: sums of fp32 per-tile partials are then exact
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { psum[i] = 0.0; psq[i] = 0.0; }
+  for (int i = 0; i < CRPT; ++i) { psum[i] = 0.0; psq[i] = 0.0; }
 
   // Software pipeline over tiles (one workgroup per CU, full register budget).  Loads are issued ONE per step, never as
   // a burst: a wave that issues more than the CU can keep in flight stalls at issue until HBM has delivered (a burst of
-  // 32 KB per wave measured 9-20k idle cycles).  Tile t+1's pixels (xr) and addend rows (addn) both ride on tile t's
-  // store loop; the MFMA phase only streams the L2-resident weight ring.
-  f32x4 xr[2][8], addv[16], addn[16];
+  // 32 KB per wave measured 9-20k idle cycles).  Tile t+1's pixels (xr) and addend rows (addv, reloaded right after their
+  // use) both ride on tile t's store loop; the MFMA phase only streams the L2-resident weight ring.
+  f32x4 xr[COC][8], addv[CRPT];
   auto x_ptr = [&](int t) {
     const int zz = t / tpi, nn = (t - zz * tpi) * CTN;
     return p.x + (long)zz * p.x_bs + ((nn + 4 * q0 < p.HW) ? nn + 4 * q0 : 0);   // ragged slice: clamped, zeroed later
@@ -103,17 +116,17 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
     const float* xg = x_ptr(t_begin);
     const float* ag = add_ptr(t_begin);
 #pragma unroll
-    for (int oc = 0; oc < 2; ++oc)
+    for (int oc = 0; oc < COC; ++oc)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int ch = 8 * (o0 + 16 * oc) + e;
+        const int ch = 8 * (o0 + CRS * oc) + e;
         xr[oc][e] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ch < p.Cin) xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)ch * p.HW);   // channels past Cin: no load
       }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < CRPT; ++i) {
       addv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.add) addv[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+      if (p.add) addv[i] = *reinterpret_cast<const f32x4*>(ag + (long)(CRS * i) * p.HW);
     }
   }
 
@@ -130,12 +143,12 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
     const int n0 = (tile - z * tpi) * CTN;
     const bool full = n0 + CTN <= p.HW;
 
-    // ---- phase 0: x tile (already in registers) -> LDS (fp16 hi / lo, [px][k]); thread = (pixel quad q0, octets o0, o0 + 16)
+    // ---- phase 0: x tile (already in registers) -> LDS (fp16 hi / lo, [px][k]); thread = (pixel quad q0, octets o0 + CRS oc)
     {
       const bool ok = full || (n0 + 4 * q0 < p.HW);
 #pragma unroll
-      for (int oc = 0; oc < 2; ++oc) {
-        const int c0 = 8 * (o0 + 16 * oc);
+      for (int oc = 0; oc < COC; ++oc) {
+        const int c0 = 8 * (o0 + CRS * oc);
         float av[8], dv[8];
         if (p.pa) {
           const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * CE + c0);
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
             vh[e] = hv;
             vl[e] = (_Float16)(v - (float)hv);
           }
-          const int off = cv_off(4 * q0 + pp, o0 + 16 * oc);
+          const int off = cv_off(4 * q0 + pp, o0 + CRS * oc);
           *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
           *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
         }
@@ -176,10 +189,10 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
     const float* xnext = x_ptr(tnext);
     const float* anext = add_ptr(tnext);
     stamp(2);
-    // ---- MFMA phase: rows 64 wave .. +64, all 64 px, K = 256
-    f32x16 acc[2][2];
+    // ---- MFMA phase: rows 32 CMT wave .. + 32 CMT, all 64 px, K = 64 KBLK
+    f32x16 acc[CMT][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < CMT; ++mi)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -201,8 +214,8 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
           bl[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
         }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int s = 2 * i + mi;
+        for (int mi = 0; mi < CMT; ++mi) {
+          const int s = CMT * i + mi;
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[mi][j], 0, 0, 0);
 #pragma unroll
@@ -222,12 +235,12 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
     __syncthreads();
     stamp(4);   // every wave is done reading the x tile
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < CMT; ++mi)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = 64 * wave + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int row = 32 * (CMT * wave + mi) + (r & 3) + 8 * (r >> 2) + 4 * h;
           Os[row * CTN + 32 * j + l31] = acc[mi][j][r] * p.out_scale;
         }
     __syncthreads();
@@ -235,8 +248,8 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
     {
       float* og = p.out + (long)z * p.out_bs + roff;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(Os + (o0 + 16 * i) * CTN + 4 * q0);
+      for (int i = 0; i < CRPT; ++i) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(Os + (o0 + CRS * i) * CTN + 4 * q0);
         v += brow[i];
         if (p.add_mode == 1) v += addv[i];
         if (p.act == 1) {
@@ -244,13 +257,13 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
         if (p.add_mode == 2) v += addv[i];
-        if (c_ok) *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
+        if (c_ok) *reinterpret_cast<f32x4*>(og + (long)(CRS * i) * p.HW) = v;
         // next tile's addend row, one per step (every lane: a lane beyond a ragged tile's edge still owns pixels of the next)
-        if (p.add) addn[i] = *reinterpret_cast<const f32x4*>(anext + (long)(16 * i) * p.HW);   // (workgroup-uniform)
+        if (p.add) addv[i] = *reinterpret_cast<const f32x4*>(anext + (long)(CRS * i) * p.HW);   // (workgroup-uniform)
         // next tile's pixels, one piece per step as well: with them out of the MFMA phase the weight ring no longer queues
         // behind HBM loads there (vmcnt retires in order): MFMA phase 12.0k -> 7.6k cycles, kernel -3 %
         {
-          const int ch = 8 * (o0 + 16 * (i >> 3)) + (i & 7);
+          const int ch = 8 * (o0 + CRS * (i >> 3)) + (i & 7);
           if (ch < p.Cin) xr[i >> 3][i & 7] = *reinterpret_cast<const f32x4*>(xnext + (long)ch * p.HW);
         }
         if (c_ok) {
@@ -259,15 +272,13 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) addv[i] = addn[i];
     stamp(6);
     // statistics flush at this workgroup's last tile of the image (see mlp_h3.hip)
     if (p.stats) {
       const int nt = tile + 1;
       if (nt >= t_end || nt / tpi != z) {   // workgroup-uniform
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < CRPT; ++i) {
           double s1 = psum[i], s2 = psq[i];
 #pragma unroll
           for (int m = 1; m < 16; m <<= 1) {
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
             s2 += __shfl_xor(s2, m, 64);
           }
           if (q0 == 0) {
-            double* st = p.stats + ((long)z * CE + o0 + 16 * i) * 2;
+            double* st = p.stats + ((long)z * CE + o0 + CRS * i) * 2;
             __hip_atomic_fetch_add(st, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(st + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void conv_h3_kernel(const ConvParams p) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { psum[i] = 0.0; psq[i] = 0.0; }
+      for (int i = 0; i < CRPT; ++i) { psum[i] = 0.0; psq[i] = 0.0; }
     }
     stamp(7);
     __syncthreads();   // the store phase is done with the LDS tile
@@ -303,7 +314,7 @@ extern "C" int sdy_conv256_h3_debug_stamps(unsigned long long* host64) {
 
 extern "C" int sdy_conv256_h3_supported(int Cin, int Cout) { return (Cin >= 1 && Cin <= CE && Cout == CE) ? 1 : 0; }
 
-extern "C" size_t sdy_conv256_h3_pack_bytes(void) { return (size_t)4 * CGPW * CGROUP * sizeof(f16x8); }
+extern "C" size_t sdy_conv256_h3_pack_bytes(void) { return (size_t)CNW * CGPW * CGROUP * sizeof(f16x8); }
 
 // w_host: (256, Cin) row-major (Cout, Cin), Cin <= 256 (zero-padded to 256 in the stream)
 extern "C" int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* dev, float* scale) {
@@ -317,15 +328,15 @@ extern "C" int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* dev, 
     s = std::ldexp(1.0f, 13 - e);
   }
   const size_t gh = (size_t)CGROUP * 8;
-  std::vector<_Float16> buf((size_t)4 * CGPW * gh);
+  std::vector<_Float16> buf((size_t)CNW * CGPW * gh);
   _Float16* d = buf.data();
-  for (int w = 0; w < 4; ++w)
+  for (int w = 0; w < CNW; ++w)
     for (int ks = 0; ks < CKS; ++ks)
-      for (int mi = 0; mi < 2; ++mi, d += gh)
+      for (int mi = 0; mi < CMT; ++mi, d += gh)
         for (int ln = 0; ln < 64; ++ln)
           for (int e = 0; e < 8; ++e) {
             const int kk = 16 * ks + 8 * (ln >> 5) + e;
-            const float v = kk < Cin ? w_host[(size_t)(64 * w + 32 * mi + (ln & 31)) * Cin + kk] * s : 0.0f;
+            const float v = kk < Cin ? w_host[(size_t)(32 * (CMT * w + mi) + (ln & 31)) * Cin + kk] * s : 0.0f;
             const _Float16 hv = (_Float16)v;
             d[ln * 8 + e] = hv;
             d[64 * 8 + ln * 8 + e] = (_Float16)(v - (float)hv);
@@ -369,10 +380,10 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   const long want = n_cu;   // persistent: one workgroup per CU
   dim3 grid((unsigned)(ntiles < want ? ntiles : want));
   switch ((a->Cin + 63) / 64) {
-    case 1: hipLaunchKernelGGL(conv_h3_kernel<1>, grid, dim3(256), 0, stream, p); break;
-    case 2: hipLaunchKernelGGL(conv_h3_kernel<2>, grid, dim3(256), 0, stream, p); break;
-    case 3: hipLaunchKernelGGL(conv_h3_kernel<3>, grid, dim3(256), 0, stream, p); break;
-    default: hipLaunchKernelGGL(conv_h3_kernel<4>, grid, dim3(256), 0, stream, p); break;
+    case 1: hipLaunchKernelGGL(conv_h3_kernel<1>, grid, dim3(CNT), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL(conv_h3_kernel<2>, grid, dim3(CNT), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL(conv_h3_kernel<3>, grid, dim3(CNT), 0, stream, p); break;
+    default: hipLaunchKernelGGL(conv_h3_kernel<4>, grid, dim3(CNT), 0, stream, p); break;
   }
   return sdy_launch_status();
 }
