@@ -12,7 +12,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    if "mlp" in r["Kernel_Name"] or "gemm" in r["Kernel_Name"] or "fft" in r["Kernel_Name"] or "instnorm" in r["Kernel_Name"]:
+    if any(t in r["Kernel_Name"] for t in ("mlp", "gemm", "fft", "instnorm", "leg_", "dh_h3", "conv_h3")):
         agg[(r["Kernel_Name"][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in agg.items():
     print(f"{k:62s} {c:12s} avg {sum(v)/len(v):14.1f} KB over {len(v)} dispatches")

@@ -7,7 +7,7 @@ import sdy_amd
 from sdy_amd._lib import lib, ptr, check, current_stream
 from sdy_amd.sht import ShtPlan
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+B = int(sys.argv[1]) if len(sys.argv) > 1 else int(os.environ.get("SDY_STAGE_B", "8"))
 E, H, W, L, M = 256, 180, 360, 180, 181
 dev = torch.device("cuda")
 plan = ShtPlan.get(H, W, L, M, "legendre-gauss", 0)
