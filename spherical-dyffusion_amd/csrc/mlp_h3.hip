@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   _Float16* Xs_lo = Xs_hi + TN * ME;
   _Float16* Hs = Xs_lo + TN * ME;          // [buf][hi | lo][px][HC]
   float* Cf = reinterpret_cast<float*>(Hs + 4 * TN * HC);   // per-image coefficients: pa | pd | add_a | add_d, [4][ME]
+  float* Cb2 = Cf + 4 * ME;                                 // fc2 bias [ME] (constant): the epilogue reads it at LDS latency
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int h = lane >> 5, l31 = lane & 31;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     Cf[2 * ME + tid] = p.add_a ? p.add_a[c] : 1.0f;
     Cf[3 * ME + tid] = p.add_a ? p.add_d[c] : 0.0f;
   };
+  Cb2[tid] = p.b2[tid];
   if (t_begin < t_end) load_coeffs(t_begin / tpi);
   __syncthreads();
   if (t_begin < t_end) prefetch_x(t_begin);
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       const int row0 = 64 * wave + 32 * mi + 4 * h;
       f32x4 bv[4];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) bv[g4] = *reinterpret_cast<const f32x4*>(p.b2 + row0 + 8 * g4);
+      for (int g4 = 0; g4 < 4; ++g4) bv[g4] = *reinterpret_cast<const f32x4*>(Cb2 + row0 + 8 * g4);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -638,7 +640,7 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   }
   const long ntiles = (long)((a->HW + TN - 1) / TN) * a->B;
   dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));   // persistent: one workgroup per CU (128 KB of LDS each)
-  constexpr size_t smem = (size_t)(2 * TN * ME + 4 * TN * HC) * sizeof(_Float16) + 4 * ME * sizeof(float);
+  constexpr size_t smem = (size_t)(2 * TN * ME + 4 * TN * HC) * sizeof(_Float16) + 5 * ME * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel<false>),
