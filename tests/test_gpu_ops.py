@@ -351,3 +351,27 @@ def test_conv_cin_to_256_persistent_kernel(sdy, Cin):
     assert rel_l2(out2, ref2) < TOL_OP
     want = torch.stack([ref2.sum((2, 3)), (ref2 * ref2).sum((2, 3))], -1)
     assert torch.allclose(st.cpu(), want, rtol=1e-4, atol=1e-5 * H * W)
+
+
+@pytest.mark.parametrize("grid", ["equiangular", "legendre-gauss"])
+@pytest.mark.parametrize("nlat,nlon,L,M,C,B", [
+    (180, 360, 180, 181, 16, 2),    # nlon = 360 FFT specialisation (C % 16 == 0) + folded Legendre kernel
+    (180, 360, 120, 100, 32, 1),    # truncated lmax / mmax
+    (90, 360, 90, 181, 16, 1),      # fewer rings, mmax > lmax
+    (33, 64, 33, 33, 4, 2),         # odd nlat: the unfolded Legendre kernel, generic FFT
+    (32, 64, 20, 17, 12, 2),        # truncated small grid
+])
+def test_sht_shapes_both_directions(sdy, nlat, nlon, L, M, C, B, grid):
+    """Shape coverage of the kernel selection inside RealSHT / InverseRealSHT (split-fp16 mode): nlon = 360 with 16-channel
+    blocks takes fft360.hip, even nlat takes leg_par.hip (equatorial symmetry folded), everything else the generic kernels."""
+    from oracle.sht import InverseRealSHT as OInv, RealSHT as OFwd
+
+    x = torch.randn(B, C, nlat, nlon, generator=_gen(61))
+    ref = OFwd(nlat, nlon, lmax=L, mmax=M, grid=grid).float()(x)
+    got = sdy.RealSHT(nlat, nlon, lmax=L, mmax=M, grid=grid, gemm_mode="h3").float()(x.cuda())
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < TOL_OP, f"RealSHT {nlat}x{nlon} L={L} M={M} {grid}"
+    c = torch.randn(B, C, L, M, dtype=torch.complex64, generator=_gen(62))
+    refi = OInv(nlat, nlon, lmax=L, mmax=M, grid=grid).float()(c)
+    goti = sdy.InverseRealSHT(nlat, nlon, lmax=L, mmax=M, grid=grid, gemm_mode="h3").float()(c.cuda())
+    assert rel_l2(goti, refi) < TOL_OP, f"InverseRealSHT {nlat}x{nlon} L={L} M={M} {grid}"
