@@ -24,6 +24,12 @@ static inline int sdy_launch_status() {
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 16-byte store of a streaming output (written once, read by a later kernel after 1.6 GB of other traffic)
+#ifdef SDY_NT_STORE
+#define SDY_STREAM_STORE(ptr, v) __builtin_nontemporal_store((v), reinterpret_cast<f32x4*>(ptr))
+#else
+#define SDY_STREAM_STORE(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- exact-erf GELU (nn.GELU default, src/models/sfno/sfnonet.py:602-603) ------------------------------

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
         if (p.add_mode == 2) v += addv[i];
-        if (c_ok) *reinterpret_cast<f32x4*>(og + (long)(CRS * i) * p.HW) = v;
+        if (c_ok) SDY_STREAM_STORE(og + (long)(CRS * i) * p.HW, v);
         // next tile's addend row, one per step (every lane: a lane beyond a ragged tile's edge still owns pixels of the next)
         if (p.add) addv[i] = *reinterpret_cast<const f32x4*>(anext + (long)(CRS * i) * p.HW);   // (workgroup-uniform)
         // next tile's pixels, one piece per step as well: with them out of the MFMA phase the weight ring no longer queues

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
           for (int hh = 0; hh < 2; ++hh) {
             const int row = 32 * j + 8 * g + srow + 4 * hh;
             const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (srow + 4 * hh) * 64 + 4 * sc4);
-            if (row0 + row < M) *reinterpret_cast<f32x4*>(og + (long)row * DN) = v;
+            if (row0 + row < M) SDY_STREAM_STORE(og + (long)row * DN, v);
           }
           __builtin_amdgcn_wave_barrier();
         }

@@ -297,8 +297,8 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
           vi[j] = X.y;
         }
         float* o = Xk + (long)m * mstride;
-        *reinterpret_cast<f32x4*>(o) = vr;
-        *reinterpret_cast<f32x4*>(o + im_off) = vi;
+        SDY_STREAM_STORE(o, vr);
+        SDY_STREAM_STORE(o + im_off, vi);
       }
     }
     __syncthreads();   // the rows are rewritten by the next ring
@@ -393,8 +393,8 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
     for (int r = 0; r < 4; ++r) {
       const float bs = BS[4 * L.wave + r];
       float* dst = yw + r * rstride + (long)k * NLON;
-      *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(zw + r * P) + bs;
-      if (tail) *reinterpret_cast<f32x4*>(dst + 256) = *reinterpret_cast<const f32x4*>(zw + r * P + 128) + bs;
+      SDY_STREAM_STORE(dst, *reinterpret_cast<const f32x4*>(zw + r * P) + bs);
+      if (tail) SDY_STREAM_STORE(dst + 256, *reinterpret_cast<const f32x4*>(zw + r * P + 128) + bs);
     }
     __syncthreads();   // the rows are rewritten by the next ring
   }

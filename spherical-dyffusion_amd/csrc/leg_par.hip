@@ -200,7 +200,7 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
       for (int i = 0; i < 16; ++i) {
         const int row = r0 + 12 * i;
         if (row >= row_lo && row < p.rows_out)
-          *reinterpret_cast<f32x4*>(cg + (long)row * p.ldc) = *reinterpret_cast<const f32x4*>(Os + row * PTN + 4 * q);
+          SDY_STREAM_STORE(cg + (long)row * p.ldc, *reinterpret_cast<const f32x4*>(Os + row * PTN + 4 * q));
       }
     }
   }

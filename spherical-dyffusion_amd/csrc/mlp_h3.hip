@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         const int row = (tid >> 4) + 16 * i;
         f32x4 v = *reinterpret_cast<const f32x4*>(os + 16 * i * TN);
         if (p.add) v += rres[i] * Cf[2 * ME + row] + Cf[3 * ME + row];
-        *reinterpret_cast<f32x4*>(og + (long)(16 * i) * p.HW) = v;
+        SDY_STREAM_STORE(og + (long)(16 * i) * p.HW, v);
         if (p.stats) {
           psum[i] += (double)((v.x + v.y) + (v.z + v.w));
           psq[i] += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
