@@ -926,7 +926,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, ilv, stream));
     }
     if (bw.fw.frag)
-      SDY_TRY(sdy_dhconv_frag(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, B, stream));
+      SDY_TRY(sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, B, ilv, (hipStream_t)stream));
     else if (c.gemm_mode == 1)
       SDY_TRY(sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     else

@@ -10,8 +10,10 @@
 // The generic tile GEMM (gemm_h3.hip) cuts N = 512 into four 128-column tiles, so every activation row is fetched and
 // split four times and both operands go through LDS.  Here a workgroup (8 waves) owns 64 rows and ALL 512 columns:
 //   * the 64 x 512 activation tile is fetched once, split hi/lo and parked in LDS ([row][k], XOR-swizzled, 128 KB);
-//   * wave w computes columns 64w .. 64w+63: the weight never touches LDS, it is packed per (l, wave) as a linear stream of
-//     MFMA B-fragment pairs (hi, lo) in consumption order and flows L2 -> registers through an 8-group ring;
+//   * wave w computes output channels 32w .. 32w+31, real AND imaginary part (out_re = x_re wr - x_im wi, out_im = x_re wi +
+//     x_im wr): the weight never touches LDS, it is packed per (l, wave) as a linear stream of (wr, wi) MFMA B-fragment
+//     pairs (hi, lo) in consumption order -- 512 KB per degree, half of the real-expanded matrix -- and flows L2 -> registers
+//     through an 8-group ring;
 //   * the accumulators (rows x columns, column = lane) are transposed per wave through a private 2 KB LDS area and stored
 //     as 16 bytes per lane, 256-byte row segments.
 // Work distribution: each degree l belongs to ONE XCD (boustrophedon over l, so the (l+1)-proportional work balances), and
@@ -32,19 +34,20 @@ constexpr int DE = 256;            // channels in = out
 constexpr int DK = 2 * DE;         // contraction length (ri, c)
 constexpr int DN = 2 * DE;         // output columns
 constexpr int DTN = 64;            // rows per tile
-constexpr int DKS = DK / 16;       // k-steps (32)
+constexpr int DCB = DE / 16;       // blocks of 16 input channels (16): one re k-step + one im k-step each
 constexpr int DWAVES = 8;
-constexpr int DRING = 8;           // groups in flight (4 k-steps x 2 n-tiles)
-constexpr int DGPW = 2 * DKS;      // groups per wave and degree (64)
+constexpr int DRING = 8;           // groups in flight (4 channel blocks x (wr, wi))
+constexpr int DGPW = 2 * DCB;      // groups per wave and degree (32)
 constexpr int DGROUP = 2 * 64;     // f16x8 elements per group (hi | lo)
-constexpr long DLSTRIDE = (long)DWAVES * DGPW * DGROUP;   // f16x8 elements per degree (1 MB)
+constexpr long DLSTRIDE = (long)DWAVES * DGPW * DGROUP;   // f16x8 elements per degree (512 KB)
 constexpr float DSX = 16.0f;
 
 struct DhParams {
   const float* X; long sX;         // Cs_in,  per-degree stride (floats)
   float* out; long sC;             // Cs_out, per-degree stride
-  const f16x8* w;                  // [l][8 waves][DGPW groups][hi | lo][64 lanes]
+  const f16x8* w;                  // [l][8 waves][16 channel blocks][wr | wi][hi | lo][64 lanes]
   int L, mtr, B;
+  int ilv;                         // order of the 2C axis: 0 = [ri][c], 1 = [c / 16][ri][16] (fft.h)
   float out_scale;
   unsigned long long* stamps;      // timing experiments only (SDY_DH_STAMPS)
 };
@@ -150,101 +153,99 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
     __syncthreads();
     stamp(2);
 
-    // ---- MFMA phase: all 64 rows x columns 64 wave .. +64, K = 512
+    // ---- MFMA phase.  Wave w owns the 32 output channels o = 32 w .. 32 w + 31 and computes BOTH parts of them:
+    //        out_re += x_re . wr - x_im . wi        out_im += x_re . wi + x_im . wr
+    // so one (wr, wi) fragment pair per block of 16 input channels feeds 24 MFMAs -- the real-expanded 512 x 512 matrix
+    // [[wr, wi], [-wi, wr]] holds every number twice and streaming it cost 1 MB per tile through the 64 B/clk vector-memory
+    // path (ablations in DESIGN.md).  The minus sign is applied to the x_im fragments (sign bits of hi and lo).
     const wptr_t wnext = w_base(pre.l);
-    f32x16 acc[2][2];   // [row tile j][column tile ni]
+    f32x16 acc[2][2];   // [part: re, im][row tile j]
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][ni][r] = 0.0f;
-    // Order inside a k-step: the four (x lo) x (w hi) products first -- then the x-lo fragments of the NEXT k-step are
-    // requested into the same registers -- then the eight products that read the x-hi fragments, whose successors are
-    // requested last and arrive under the next k-step's first four MFMAs.  (A wave that loads its fragments at the top of
-    // every k-step and waits keeps the matrix pipe about 60 % busy; double-buffered fragment registers do not fit.)
-    f16x8 ah[2], al[2];
-    auto load_lo = [&](int ks) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) al[j] = *reinterpret_cast<const f16x8*>(Xs_lo + dh_off(32 * j + l31, 2 * ks + h));
+        for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.0f;
+    auto mma3 = [&](f32x16& c, const f16x8& ah, const f16x8& al, const f16x8& bhi, const f16x8& blo) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi, c, 0, 0, 0);
     };
-    auto load_hi = [&](int ks) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) ah[j] = *reinterpret_cast<const f16x8*>(Xs_hi + dh_off(32 * j + l31, 2 * ks + h));
-    };
-    load_lo(0);
-    load_hi(0);
-#pragma unroll
-    for (int kb = 0; kb < DKS / 4; ++kb) {
-      if (kb == DKS / 4 - 1) {   // the refills of the last block fetch block 0 of the next tile's stream
+    for (int kb = 0; kb < DCB / 4; ++kb) {
+      if (kb == DCB / 4 - 1) {   // the refills of the last block fetch block 0 of the next tile's stream
         wp = wnext;
         asm volatile("" : "+v"(wp));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ks = 4 * kb + i, s0 = 2 * i, s1 = 2 * i + 1;
+        const int cb = 4 * kb + i, s0 = 2 * i, s1 = 2 * i + 1;   // ring slots of (wr, wi)
+        const int kre = p.ilv ? 2 * cb : cb, kim = p.ilv ? 2 * cb + 1 : DCB + cb;   // k-steps of x_re / x_im
+        f16x8 ah[2], al[2];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int j = 0; j < 2; ++j) {
+          const int off = dh_off(32 * j + l31, 2 * kre + h);
+          ah[j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
+          al[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
+        }
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], r_hi[s0 + ni], acc[j][ni], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef DH_NOLDS
-        if (ks + 1 < DKS) load_lo(ks + 1);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 2; ++j) mma3(acc[0][j], ah[j], al[j], r_hi[s0], r_lo[s0]);   // re += x_re . wr
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], r_lo[s0 + ni], acc[j][ni], 0, 0, 0);
-#ifndef DH_NOW
-        r_lo[s0] = wp[s0 * DGROUP + 64];
-        r_lo[s1] = wp[s1 * DGROUP + 64];
-#endif
+        for (int j = 0; j < 2; ++j) mma3(acc[1][j], ah[j], al[j], r_hi[s1], r_lo[s1]);   // im += x_re . wi
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int j = 0; j < 2; ++j) {
+          const int off = dh_off(32 * j + l31, 2 * kim + h);
+          ah[j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
+          al[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
+        }
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], r_hi[s0 + ni], acc[j][ni], 0, 0, 0);
-#ifndef DH_NOW
+        for (int j = 0; j < 2; ++j) mma3(acc[1][j], ah[j], al[j], r_hi[s0], r_lo[s0]);   // im += x_im . wr
         r_hi[s0] = wp[s0 * DGROUP];
+        r_lo[s0] = wp[s0 * DGROUP + 64];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // -x_im
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 uh = __builtin_bit_cast(u32x4, ah[j]) ^ 0x80008000u, ul = __builtin_bit_cast(u32x4, al[j]) ^ 0x80008000u;
+          ah[j] = __builtin_bit_cast(f16x8, uh);
+          al[j] = __builtin_bit_cast(f16x8, ul);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma3(acc[0][j], ah[j], al[j], r_hi[s1], r_lo[s1]);   // re -= x_im . wi
         r_hi[s1] = wp[s1 * DGROUP];
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef DH_NOLDS
-        if (ks + 1 < DKS) load_hi(ks + 1);
-#endif
+        r_lo[s1] = wp[s1 * DGROUP + 64];
 #ifndef DH_NOPREFETCH
-        if ((i & 1) == 0) {   // one 16-byte piece of the next tile per two k-steps, never a burst
-          const int g = 2 * kb + (i >> 1);   // 0..15
-          xr[g >> 1][g & 1] = *reinterpret_cast<const f32x4*>(x_ptr(pre, g >> 1) + 4 * (g & 1));
+        {   // one 16-byte piece of the next tile per channel block, never a burst
+          xr[cb >> 1][cb & 1] = *reinterpret_cast<const f32x4*>(x_ptr(pre, cb >> 1) + 4 * (cb & 1));
         }
 #endif
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads here (the scheduler otherwise sinks them next to their use)
       }
-#ifndef DH_WSAME
       wp += DRING * DGROUP;
-#endif
     }
 
     stamp(3);
-    // ---- epilogue: the accumulators hold column = lane, i.e. a direct store is 4 bytes per lane (measured: the 64 dword
+    // ---- epilogue: the accumulators hold channel = lane, i.e. a direct store is 4 bytes per lane (measured: the 64 dword
     // stores per lane took 40 % of the tile).  Each wave transposes 8-row chunks of its 64 x 64 block through a private
     // 2 KB LDS staging area (in-order LDS of one wave: no barrier) and stores 16 bytes per lane, 256-byte row segments.
     {
       float* stg = reinterpret_cast<float*>(smem + 2 * DTN * DK * sizeof(_Float16)) + wave * (8 * 64);
       const int srow = lane >> 4, sc4 = lane & 15;
-      float* og = p.out + (long)cur.l * p.sC + (long)row0 * DN + 64 * wave + 4 * sc4;
+      // staging column of (part t, channel 32 w + l31) and the global column of staging columns 4 sc4 .. + 3:
+      //   [c/16][ri][16]: the wave's 64 outputs are contiguous, [16-block l31 >> 4][t][l31 & 15]
+      //   [ri][c]       : two 32-float runs, [t][l31] -> column 256 t + 32 w + ...
+      const int scol = p.ilv ? 32 * (l31 >> 4) + (l31 & 15) : l31;   // + (ilv ? 16 : 32) * t
+      const int tstep = p.ilv ? 16 : 32;
+      const int gcol = p.ilv ? 64 * wave + 4 * sc4 : DE * (sc4 >> 3) + 32 * wave + 4 * (sc4 & 7);
+      float* og = p.out + (long)cur.l * p.sC + (long)row0 * DN + gcol;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) stg[(q + 4 * h) * 64 + 32 * ni + l31] = acc[j][ni][4 * g + q] * p.out_scale;
+            for (int q = 0; q < 4; ++q) stg[(q + 4 * h) * 64 + scol + tstep * t] = acc[t][j][4 * g + q] * p.out_scale;
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
@@ -278,16 +279,11 @@ extern "C" int sdy_dhconv_frag_supported(int Ci, int Co) { return (Ci == DE && C
 
 extern "C" size_t sdy_dhconv_frag_pack_bytes(int L) { return L > 0 ? (size_t)L * DLSTRIDE * sizeof(f16x8) : 0; }
 
-// w_host: (256, 256, L, 2) reference layout.  ilv: column / row order of the 2C axis, 0 = [ri][c], 1 = [c/16][ri][16]
+// w_host: (256, 256, L, 2) reference layout (i, o, l, re | im).  The stream does not depend on the order of the 2C axis
+// (the kernel maps its k-steps and output columns); `ilv` is accepted for the caller's convenience and ignored.
 int sdy_dh_h3_pack(const float* w, int L, void* dev, float* scale, int ilv) {
+  (void)ilv;
   if (!w || !dev || !scale || L <= 0) return SDY_ERR_ARG;
-  auto value = [&](int l, int op, int ip) {   // W'_l[ip][op]
-    const int ro = ilv ? (op >> 4) & 1 : op >= DE, o = ilv ? (op >> 5) * 16 + (op & 15) : op - ro * DE;
-    const int ri = ilv ? (ip >> 4) & 1 : ip >= DE, i = ilv ? (ip >> 5) * 16 + (ip & 15) : ip - ri * DE;
-    const float* e = w + (((size_t)i * DE + o) * L + l) * 2;
-    if (ri == ro) return e[0];
-    return ri ? -e[1] : e[1];
-  };
   float mx = 0.f;
   for (size_t i = 0; i < (size_t)DE * DE * L * 2; ++i) mx = std::fmax(mx, std::fabs(w[i]));
   float s = 1.0f;
@@ -301,11 +297,12 @@ int sdy_dh_h3_pack(const float* w, int L, void* dev, float* scale, int ilv) {
   for (int l = 0; l < L; ++l) {
     _Float16* d = buf.data();
     for (int wv = 0; wv < DWAVES; ++wv)
-      for (int ks = 0; ks < DKS; ++ks)
-        for (int ni = 0; ni < 2; ++ni, d += gh)
+      for (int cb = 0; cb < DCB; ++cb)
+        for (int comp = 0; comp < 2; ++comp, d += gh)
           for (int ln = 0; ln < 64; ++ln)
             for (int e = 0; e < 8; ++e) {
-              const float v = value(l, 64 * wv + 32 * ni + (ln & 31), 16 * ks + 8 * (ln >> 5) + e) * s;
+              const int i = 16 * cb + 8 * (ln >> 5) + e, o = 32 * wv + (ln & 31);
+              const float v = w[(((size_t)i * DE + o) * L + l) * 2 + comp] * s;
               const _Float16 hv = (_Float16)v;
               d[ln * 8 + e] = hv;
               d[64 * 8 + ln * 8 + e] = (_Float16)(v - (float)hv);
@@ -320,14 +317,14 @@ extern "C" int sdy_dhconv_frag_pack(const float* w_host, int L, void* packed_dev
   return sdy_dh_h3_pack(w_host, L, packed_dev, scale, 0);
 }
 
-extern "C" int sdy_dhconv_frag(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B,
-                               void* stream) {
+int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B, int ilv,
+                      hipStream_t stream) {
   if (!Cs_in || !packed || !Cs_out || L <= 0 || mtr <= 0 || B <= 0 || !(scale > 0.f)) return SDY_ERR_ARG;
   DhParams p;
   p.X = Cs_in; p.sX = (long)mtr * B * DK;
   p.out = Cs_out; p.sC = (long)mtr * B * DN;
   p.w = reinterpret_cast<const f16x8*>(packed);
-  p.L = L; p.mtr = mtr; p.B = B;
+  p.L = L; p.mtr = mtr; p.B = B; p.ilv = ilv ? 1 : 0;
   p.out_scale = 1.0f / (scale * DSX);
   p.stamps = nullptr;
   if (std::getenv("SDY_DH_STAMPS")) {
@@ -343,6 +340,10 @@ extern "C" int sdy_dhconv_frag(const float* Cs_in, const void* packed, float sca
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dh_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   }
   const int grid = n_cu >= 8 ? (n_cu / 8) * 8 : 8;   // whole slots of 8 XCDs: one workgroup per CU
-  hipLaunchKernelGGL(dh_h3_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(dh_h3_kernel, dim3(grid), dim3(512), smem, stream, p);
   return sdy_launch_status();
+}
+extern "C" int sdy_dhconv_frag(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B,
+                               void* stream) {
+  return sdy_dh_h3_launch(Cs_in, packed, scale, Cs_out, L, mtr, B, 0, (hipStream_t)stream);
 }
