@@ -24,6 +24,22 @@ static inline int sdy_launch_status() {
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// fp16 hi / lo split of 8 fp32 values (already scaled) for the split-precision MFMA kernels, written on 2-vectors so that it
+// compiles to packed conversions (v_cvt_pk_f16_f32, v_pk_add_f32 / fma_mix) instead of ~6 scalar VALU ops per element.
+typedef float sdy_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sdy_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sdy_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void sdy_split8(const float* v, sdy_f16x8& hi, sdy_f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const sdy_f32x2 x = {v[e], v[e + 1]};
+    const sdy_f16x2 h = __builtin_convertvector(x, sdy_f16x2);
+    const sdy_f32x2 r = x - __builtin_convertvector(h, sdy_f32x2);
+    const sdy_f16x2 l = __builtin_convertvector(r, sdy_f16x2);
+    hi[e] = h[0]; hi[e + 1] = h[1];
+    lo[e] = l[0]; lo[e + 1] = l[1];
+  }
+}
 // 16-byte store of a streaming output (written once, read by a later kernel after 1.6 GB of other traffic)
 #ifdef SDY_NT_STORE
 #define SDY_STREAM_STORE(ptr, v) __builtin_nontemporal_store((v), reinterpret_cast<f32x4*>(ptr))

@@ -167,13 +167,10 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
           f16x8 vh, vl;
+          float v[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = (ok && c0 + e < p.Cin) ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
-            const _Float16 hv = (_Float16)v;
-            vh[e] = hv;
-            vl[e] = (_Float16)(v - (float)hv);
-          }
+          for (int e = 0; e < 8; ++e) v[e] = (ok && c0 + e < p.Cin) ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
+          sdy_split8(v, vh, vl);
           const int off = cv_off(4 * q0 + pp, o0 + CRS * oc);
           *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
           *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;

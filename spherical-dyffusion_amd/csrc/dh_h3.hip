@@ -136,15 +136,12 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = r0 + 8 * i;
-      const bool ok = row0 + r < M;
+      const float sc = (row0 + r < M) ? DSX : 0.0f;   // rows past the ragged edge (clamped re-reads of a valid row): zero
       f16x8 vh, vl;
+      float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = ok ? xr[i][e >> 2][e & 3] * DSX : 0.0f;
-        const _Float16 hv = (_Float16)v;
-        vh[e] = hv;
-        vl[e] = (_Float16)(v - (float)hv);
-      }
+      for (int e = 0; e < 8; ++e) v[e] = xr[i][e >> 2][e & 3] * sc;
+      sdy_split8(v, vh, vl);
       const int off = dh_off(r, oc);
       *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
       *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;

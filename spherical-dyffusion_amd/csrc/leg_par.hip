@@ -111,19 +111,17 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) {
         f16x8 vh, vl;
+        float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float v;
           if (p.fwd) {
             const float a = xr[0][e][pp], b = xr[1][e][pp];
-            v = (ok && v_ok[0][e]) ? (hf == 0 ? a + b : a - b) * PSX : 0.0f;
+            v[e] = (ok && v_ok[0][e]) ? (hf == 0 ? a + b : a - b) * PSX : 0.0f;
           } else {
-            v = (ok && v_ok[hf][e]) ? xr[hf][e][pp] * PSX : 0.0f;
+            v[e] = (ok && v_ok[hf][e]) ? xr[hf][e][pp] * PSX : 0.0f;
           }
-          const _Float16 hv = (_Float16)v;
-          vh[e] = hv;
-          vl[e] = (_Float16)(v - (float)hv);
         }
+        sdy_split8(v, vh, vl);
         const int off = pr_off(4 * q + pp, o + 12 * hf);
         *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
         *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;

@@ -178,13 +178,10 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       for (int pp = 0; pp < 4; ++pp) {
         const int px = 4 * q0 + pp;
         f16x8 vh, vl;
+        float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = ok ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
-          const _Float16 hv = (_Float16)v;
-          vh[e] = hv;
-          vl[e] = (_Float16)(v - (float)hv);
-        }
+        for (int e = 0; e < 8; ++e) v[e] = ok ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
+        sdy_split8(v, vh, vl);
         const int off = xs_off(px, o0 + 16 * oc);
         *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
         *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;

@@ -7,5 +7,5 @@ for D in "$@"; do
   make CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $D" dh_h3.o > /dev/null 2>&1
   make > /dev/null 2>&1
   echo "== $D"
-  (cd $R && python tools/dh_stamps.py 2>&1 | grep -E "^ms")
+  (cd $R && python tools/dh_stamps.py 2>&1 | grep -E "^ms|stamp 2|stamp 3|stamp 5")
 done
