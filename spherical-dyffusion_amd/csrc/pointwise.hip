@@ -157,12 +157,14 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const SdyTimeMlp t, const
   __syncthreads();
   for (int o = threadIdx.x; o < T; o += 256) {
     float acc = t.b1[o];
+#pragma unroll 16   // independent loads in flight: the serial version paid one L2 round trip per term (0.27 ms per launch)
     for (int i = 0; i < E; ++i) acc += t.w1t[(long)i * T + o] * emb[i];
     h1[o] = gelu_erf_exact(acc);
   }
   __syncthreads();
   for (int o = threadIdx.x; o < T; o += 256) {
     float acc = t.b2[o];
+#pragma unroll 16
     for (int i = 0; i < T; ++i) acc += t.w2t[(long)i * T + o] * h1[i];
     tr[o] = acc;
   }
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const SdyTimeMlp t, const
   const float* bb = t.bb + (long)layer * 2 * E;
   for (int o = threadIdx.x; o < 2 * E; o += 256) {
     float acc = bb[o];
+#pragma unroll 16
     for (int i = 0; i < T; ++i) acc += wb[(long)i * 2 * E + o] * h1[i];
     ss_out[((long)b * L + layer) * 2 * E + o] = acc;
   }
