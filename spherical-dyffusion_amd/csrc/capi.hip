@@ -87,6 +87,11 @@ struct sdy_sht_plan {
   void* d_wq_par = nullptr;
   void* d_pct_par = nullptr;
   float s_wq_par = 1.f, s_pct_par = 1.f;
+  // Polar cut-off shared by fft360 and leg_par inside the fused forward: rows k' < kdead[m] (and their mirrors) of order m
+  // carry table entries below 1e-12 of the order's maximum in BOTH tables, so they are neither written, read nor multiplied;
+  // mcut[k] = number of orders that are live on ring k (kdead is non-decreasing in m).
+  int* d_kdead = nullptr;   // [mtr]
+  int* d_mcut = nullptr;    // [nlat]
 };
 
 static int env_gemm_mode() {
@@ -202,6 +207,40 @@ extern "C" int sdy_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, in
         return x->t[((size_t)m * x->lmax + l) * x->Kpad4 + k];
       }, &cx, p->d_pct_par, &p->s_pct_par);
       if (r != SDY_OK) { sdy_sht_plan_destroy(p); return r; }
+      // polar cut-off tables
+      std::vector<int> kdead(mtr, 0), mcut(nlat, mtr);
+      const int Kh = nlat / 2;
+      for (int m = 0; m < mtr; ++m) {
+        float mxa = 0.f, mxs = 0.f;
+        for (int k = 0; k < nlat; ++k)
+          for (int l = m; l < lmax; ++l) {
+            mxa = std::fmax(mxa, std::fabs(wqT[((size_t)m * nlat + k) * p->Lpad4 + l]));
+            mxs = std::fmax(mxs, std::fabs(pf[((size_t)m * lmax + l) * p->Kpad4 + k]));
+          }
+        int kd = 0;
+        for (; kd < Kh; ++kd) {
+          float ra = 0.f, rs = 0.f;
+          for (int kk : {kd, nlat - 1 - kd})
+            for (int l = m; l < lmax; ++l) {
+              ra = std::fmax(ra, std::fabs(wqT[((size_t)m * nlat + kk) * p->Lpad4 + l]));
+              rs = std::fmax(rs, std::fabs(pf[((size_t)m * lmax + l) * p->Kpad4 + kk]));
+            }
+          if (!(ra < 1e-12f * mxa && rs < 1e-12f * mxs)) break;
+        }
+        kdead[m] = kd;
+      }
+      for (int m = mtr - 2; m >= 0; --m) kdead[m] = std::min(kdead[m], kdead[m + 1]);   // non-decreasing in m (conservative)
+      for (int k = 0; k < nlat; ++k) {
+        const int kp = std::min(k, nlat - 1 - k);
+        int c = 0;
+        while (c < mtr && kdead[c] <= kp) ++c;
+        mcut[k] = c;
+      }
+      e = hipMalloc((void**)&p->d_kdead, mtr * sizeof(int));
+      if (e == hipSuccess) e = hipMalloc((void**)&p->d_mcut, nlat * sizeof(int));
+      if (e == hipSuccess) e = hipMemcpy(p->d_kdead, kdead.data(), mtr * sizeof(int), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(p->d_mcut, mcut.data(), nlat * sizeof(int), hipMemcpyHostToDevice);
+      if (e != hipSuccess) { sdy_sht_plan_destroy(p); return (int)e; }
     }
   }
   p->fft.tw = p->d_tw;
@@ -218,6 +257,8 @@ extern "C" void sdy_sht_plan_destroy(sdy_sht_plan* p) {
   if (p->d_pw) (void)hipFree(p->d_pw);
   if (p->d_wq_h3) (void)hipFree(p->d_wq_h3);
   if (p->d_pct_h3) (void)hipFree(p->d_pct_h3);
+  if (p->d_kdead) (void)hipFree(p->d_kdead);
+  if (p->d_mcut) (void)hipFree(p->d_mcut);
   if (p->d_wq_par) (void)hipFree(p->d_wq_par);
   if (p->d_pct_par) (void)hipFree(p->d_pct_par);
   if (p->d_wq_frag) (void)hipFree(p->d_wq_frag);
@@ -243,16 +284,27 @@ extern "C" int sdy_rfft_lon(const sdy_sht_plan* p, const float* x, const float* 
                             float* Xf, int B, int C, void* stream) {
   if (!p || !x || !Xf || B <= 0 || C <= 0) return SDY_ERR_ARG;
   if ((a == nullptr) != (d == nullptr)) return SDY_ERR_ARG;
-  return sdy_fft_launch_fwd(p->fft, x, a, d, xn_out, Xf, B, C, p->nlat, p->mtr, 0, (hipStream_t)stream);
+  return sdy_fft_launch_fwd(p->fft, x, a, d, xn_out, Xf, B, C, p->nlat, p->mtr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int sdy_irfft_lon(const sdy_sht_plan* p, const float* Yf, const float* bias, float* y, int B, int C,
                              void* stream) {
   if (!p || !Yf || !y || B <= 0 || C <= 0) return SDY_ERR_ARG;
-  return sdy_fft_launch_inv(p->fft, Yf, bias, y, B, C, p->nlat, p->mtr, 0, (hipStream_t)stream);
+  return sdy_fft_launch_inv(p->fft, Yf, bias, y, B, C, p->nlat, p->mtr, 0, nullptr, (hipStream_t)stream);
 }
 
+static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream);
 extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, void* stream) {
+  return legendre_fwd_impl(p, Xf, Cs, B, C, false, stream);
+}
+// polar: skip the rows / orders of the polar cut-off (only valid when the producer / consumer of Xf is fft360 with the same
+// cut-off: plan_polar_ok)
+static bool plan_polar_ok(const sdy_sht_plan* p, int C) {
+  static const bool off = std::getenv("SDY_NO_POLAR_SKIP") || std::getenv("SDY_NO_FFT360") || std::getenv("SDY_NO_LEG_PAR") ||
+                          std::getenv("SDY_NO_LEG_FRAG");
+  return !off && p->d_kdead && p->d_wq_par && p->fft.n == 180 && C % 16 == 0;
+}
+static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream) {
   if (!p || !Xf || !Cs || B <= 0 || C <= 0) return SDY_ERR_ARG;
   if (C & 1) return SDY_ERR_ALIGN;
   const int N = 2 * B * C;
@@ -266,7 +318,7 @@ extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* C
   static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
   if (p->d_wq_par && !no_frag && !no_par)
     return sdy_leg_par_launch(p->d_wq_par, p->s_wq_par, p->mtr, Xf, N, (long)p->nlat * N, Cs, (long)p->mtr * N, N, p->lmax,
-                              p->nlat, N, 1, (hipStream_t)stream);
+                              p->nlat, N, 1, polar ? p->d_kdead : nullptr, (hipStream_t)stream);
   if (p->d_wq_frag && !no_frag)
     return sdy_leg_h3_launch(p->d_wq_frag, p->s_wq_frag, p->mtr, Xf, N, (long)p->nlat * N, Cs, (long)p->mtr * N, N, p->lmax,
                              p->nlat, N, SDY_TRI_LEG_FWD, (hipStream_t)stream);
@@ -276,7 +328,11 @@ extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* C
   return sdy_gemm_launch(g, (hipStream_t)stream);
 }
 
+static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, bool polar, void* stream);
 extern "C" int sdy_legendre_inv(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, void* stream) {
+  return legendre_inv_impl(p, Cs, Yf, B, C, false, stream);
+}
+static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, bool polar, void* stream) {
   if (!p || !Cs || !Yf || B <= 0 || C <= 0) return SDY_ERR_ARG;
   if (C & 1) return SDY_ERR_ALIGN;
   const int N = 2 * B * C;
@@ -290,7 +346,7 @@ extern "C" int sdy_legendre_inv(const sdy_sht_plan* p, const float* Cs, float* Y
   static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
   if (p->d_pct_par && !no_frag && !no_par)
     return sdy_leg_par_launch(p->d_pct_par, p->s_pct_par, p->mtr, Cs, (long)p->mtr * N, N, Yf, N, (long)p->nlat * N, p->nlat,
-                              p->lmax, N, 0, (hipStream_t)stream);
+                              p->lmax, N, 0, polar ? p->d_kdead : nullptr, (hipStream_t)stream);
   if (p->d_pct_frag && !no_frag)
     return sdy_leg_h3_launch(p->d_pct_frag, p->s_pct_frag, p->mtr, Cs, (long)p->mtr * N, N, Yf, N, (long)p->nlat * N, p->nlat,
                              p->lmax, N, SDY_TRI_LEG_INV, (hipStream_t)stream);
@@ -918,12 +974,14 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
                                          (long)L * 2 * E, 1e-6f, ca, cd, stream));
     have_st0 = false;
     // SpectralConvS2.forward (s2convolutions.py:158-193)
+    const bool polar_in = plan_polar_ok(pin, E), polar_out = plan_polar_ok(pout, E);
     SDY_TRY(sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, B, E, pin->nlat,
-                               pin->mtr, ilv, stream));
-    SDY_TRY(sdy_legendre_fwd(pin, Xf, Cs, B, E, stream));
+                               pin->mtr, ilv, polar_in ? pin->d_mcut : nullptr, stream));
+    SDY_TRY(legendre_fwd_impl(pin, Xf, Cs, B, E, polar_in, stream));
     if (scale_residual) {  // residual = inverse_transform(forward_transform(x))
-      SDY_TRY(sdy_legendre_inv(pout, Cs, Xf, B, E, stream));
-      SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, ilv, stream));
+      SDY_TRY(legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream));
+      SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, ilv,
+                                 polar_out ? pout->d_mcut : nullptr, stream));
     }
     if (bw.fw.frag)
       SDY_TRY(sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, B, ilv, (hipStream_t)stream));
@@ -931,8 +989,9 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       SDY_TRY(sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     else
       SDY_TRY(sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
-    SDY_TRY(sdy_legendre_inv(pout, Cs2, Xf, B, E, stream));
-    SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, ilv, stream));
+    SDY_TRY(legendre_inv_impl(pout, Cs2, Xf, B, E, polar_out, stream));
+    SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, ilv,
+                               polar_out ? pout->d_mcut : nullptr, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
     conv_reset();
     cv.x = lazy_norm ? cur : xn; cv.x_bstride = lazy_norm ? ((cur == cat) ? cat_bs : (long)E * HW) : (long)E * HW;

@@ -11,10 +11,13 @@ struct SdyFftDesc {
   const float* pw; // dev [n+1][2]  exp(-2*pi*i*m/nlon)
 };
 
+// Polar cut-off (fused forward only): for latitude ring k only the orders m < mcut[k] are written (forward) / read (inverse);
+// the Legendre tables are negligible (< 1e-12 of their maximum) beyond it, see sdy_sht_plan::d_kdead.  nullptr = all orders.
+
 int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                       int B, int C, int K, int mtr, int ilv, hipStream_t stream);
+                       int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream);
 int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
-                       int ilv, hipStream_t stream);
+                       int ilv, const int* mcut, hipStream_t stream);
 
 // ilv selects the channel order of the m-major side (Xf / Yf, 2C floats per (m, k, b)):
 //   0: [ri][c]            -- the layout of the C ABI (include/sdy_amd.h)
@@ -23,6 +26,6 @@ int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, 
 //                            dhconv weights are packed for the same order (capi.hip).  Used inside the fused forward.
 // nlon = 360 specialisation (fft360.hip); SDY_ERR_UNSUPPORTED when the shape does not fit
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                          int B, int C, int K, int mtr, int ilv, hipStream_t stream);
+                          int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream);
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
-                          int mtr, int ilv, hipStream_t stream);
+                          int mtr, int ilv, const int* mcut, hipStream_t stream);

@@ -430,12 +430,13 @@ bool use_generic_only() {
 }  // namespace
 
 int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                       int B, int C, int K, int mtr, int ilv, hipStream_t stream) {
+                       int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream) {
   if (ilv && C % CB != 0) return SDY_ERR_UNSUPPORTED;
   if (f.n == 180 && !use_generic_only()) {
-    const int rc = sdy_fft360_launch_fwd(f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, stream);
+    const int rc = sdy_fft360_launch_fwd(f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut, stream);
     if (rc != SDY_ERR_UNSUPPORTED) return rc;
   }
+  if (mcut) return SDY_ERR_UNSUPPORTED;   // the polar cut-off is a contract between fft360 and leg_par only
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = 4;   // latitude rings per workgroup on the pipelined (compile-time size) paths
@@ -452,12 +453,13 @@ int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, cons
 }
 
 int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
-                       int ilv, hipStream_t stream) {
+                       int ilv, const int* mcut, hipStream_t stream) {
   if (ilv && C % CB != 0) return SDY_ERR_UNSUPPORTED;
   if (f.n == 180 && !use_generic_only()) {
-    const int rc = sdy_fft360_launch_inv(f, Yf, bias, y, B, C, K, mtr, ilv, stream);
+    const int rc = sdy_fft360_launch_inv(f, Yf, bias, y, B, C, K, mtr, ilv, mcut, stream);
     if (rc != SDY_ERR_UNSUPPORTED) return rc;
   }
+  if (mcut) return SDY_ERR_UNSUPPORTED;
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = 4;

@@ -204,7 +204,8 @@ template <int KPW>
 __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f, const float* __restrict__ x,
                                                            const float* __restrict__ pa, const float* __restrict__ pd,
                                                            float* __restrict__ xn_out, float* __restrict__ Xf, int B,
-                                                           int C, int K, int mtr, int ilv) {
+                                                           int C, int K, int mtr, int ilv,
+                                                           const int* __restrict__ mcut) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
   __shared__ c2 TW[TWN];
   __shared__ c2 AD[ROWS];   // per-slot affine (a, d)
@@ -282,10 +283,11 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
 
     // ---- split step + m-major stores: X[m] = h (A + conj B) + W (A - conj B), A = Z[m], B = Z[n - m]
     float* Xk = Xf + ((long)k * B + b) * 2 * C + re_off;
+    const int mlive = mcut ? min(mtr, mcut[k]) : mtr;   // polar cut-off: orders beyond it are never read downstream
 #pragma unroll
     for (int it = 0; it < MIT; ++it) {
       const int m = mg + 64 * it;
-      if (m < mtr) {
+      if (m < mlive) {
         f32x4 vr, vi;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
 template <int KPW>
 __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
                                                             const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                            int C, int K, int mtr, int ilv) {
+                                                            int C, int K, int mtr, int ilv,
+                                                            const int* __restrict__ mcut) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
   __shared__ c2 TW[TWN];
   __shared__ c2 PW[NH];       // exp(+2 pi i j / N)
@@ -336,11 +339,12 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
   f32x4 rr[MIT], ri[MIT];
   auto gload = [&](int k) {
     const float* Yk = Yf + ((long)k * B + b) * 2 * C + re_off;
+    const int mlive = mcut ? min(mtr, mcut[k]) : mtr;   // polar cut-off: orders beyond it were never written (zero)
 #pragma unroll
     for (int it = 0; it < MIT; ++it) {
       const int m = mg + 64 * it;
       f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
-      if (m < mtr) {
+      if (m < mlive) {
         const float* o = Yk + (long)m * mstride;
         vr = *reinterpret_cast<const f32x4*>(o);
         vi = *reinterpret_cast<const f32x4*>(o + im_off);
@@ -404,19 +408,19 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
 
 // nlon = 360 fast path; returns SDY_ERR_UNSUPPORTED when the shape does not fit (the caller falls back to fft.hip)
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                          int B, int C, int K, int mtr, int ilv, hipStream_t stream) {
+                          int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = SDY_FFT_KPW;
   dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
-  hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv);
+  hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut);
   return sdy_launch_status();
 }
 
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
-                          int mtr, int ilv, hipStream_t stream) {
+                          int mtr, int ilv, const int* mcut, hipStream_t stream) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = SDY_FFT_KPW;
   dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
-  hipLaunchKernelGGL((irfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, Yf, bias, y, B, C, K, mtr, ilv);
+  hipLaunchKernelGGL((irfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, Yf, bias, y, B, C, K, mtr, ilv, mcut);
   return sdy_launch_status();
 }

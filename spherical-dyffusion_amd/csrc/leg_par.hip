@@ -41,6 +41,7 @@ struct ParParams {
   float* C; long ldc, sC;        // output rows at C + z * sC + row * ldc
   int rows_out, K, N;            // output rows stored, input rows, columns
   int fwd;                       // 1 analysis, 0 synthesis
+  const int* kdead;              // polar cut-off per order (rows k' < kdead[m] and their mirrors are skipped) or nullptr
   float out_scale;
 };
 
@@ -61,8 +62,10 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
   const int Kh = p.K >> 1;                      // analysis: latitudes per hemisphere
   const int cE = z & 1, cO = cE ^ 1;            // degree l = 2 r + cE is an "E" degree (l + m even), 2 r + cO an "O" degree
 
-  const bool wave_dead = p.fwd && (64 * wave + 63 < z);   // analysis: all degrees of this wave are below m
-  const int ks0 = p.fwd ? 0 : z >> 5;                     // synthesis: k-steps whose degrees are all below m contribute nothing
+  const int kd = p.kdead ? p.kdead[z] : 0;                // polar rows of this order (table < 1e-12 of its maximum there)
+  const bool wave_dead = p.fwd ? (64 * wave + 63 < z)     // analysis: all degrees of this wave are below m
+                               : (32 * wave + 31 < kd);   // synthesis: all latitudes of this wave are polar
+  const int ks0 = p.fwd ? kd >> 4 : z >> 5;               // k-steps that contribute nothing: polar latitudes / degrees below m
   const int row_lo = p.fwd ? z : 0;                       // analysis: degrees l < m are never read downstream
 
   // ---- table ring (slot = 2 * (k-step % 4) + half)
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
     f32x4 xr[2][8];
     bool v_ok[2][8];
     // synthesis: an octet whose 16 degrees are all below m is zero -- no loads at all (half of the octets on average)
-    const bool oct_live = p.fwd || (16 * o + 15 >= z);
+    const bool oct_live = p.fwd ? (8 * o + 7 >= kd) : (16 * o + 15 >= z);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       xr[0][e] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
       int rowA, rowB;
       if (p.fwd) {   // latitude k' and its mirror
         rowA = r; rowB = p.K - 1 - r;
-        v_ok[0][e] = v_ok[1][e] = r < Kh;
+        v_ok[0][e] = v_ok[1][e] = r < Kh && r >= kd;
       } else {       // the "E" and the "O" degree of position r
         rowA = 2 * r + cE; rowB = 2 * r + cO;
         v_ok[0][e] = rowA < p.K && rowA >= z;      // degrees below m were never written
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = r0 + 12 * i;
-        if (row >= row_lo && row < p.rows_out)
+        if (row >= row_lo && row < p.rows_out && (p.fwd || (row >= kd && row < p.rows_out - kd)))
           SDY_STREAM_STORE(cg + (long)row * p.ldc, *reinterpret_cast<const f32x4*>(Os + row * PTN + 4 * q));
       }
     }
@@ -259,7 +262,7 @@ int sdy_leg_par_pack(int nz, int nlat, int lmax, int fwd, sdy_leg_value_fn value
 }
 
 int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, long ldx, long sX, float* C, long ldc,
-                       long sC, int rows_out, int K, int N, int fwd, hipStream_t stream) {
+                       long sC, int rows_out, int K, int N, int fwd, const int* kdead, hipStream_t stream) {
   if (!table || !X || !C || nz <= 0 || N <= 0) return SDY_ERR_ARG;
   if (rows_out > PM || K > PM || nz > PM) return SDY_ERR_UNSUPPORTED;
   if ((fwd ? K : rows_out) & 1) return SDY_ERR_UNSUPPORTED;
@@ -268,7 +271,7 @@ int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, l
   p.table = reinterpret_cast<const f16x8*>(table);
   p.X = X; p.ldx = ldx; p.sX = sX;
   p.C = C; p.ldc = ldc; p.sC = sC;
-  p.rows_out = rows_out; p.K = K; p.N = N; p.fwd = fwd;
+  p.rows_out = rows_out; p.K = K; p.N = N; p.fwd = fwd; p.kdead = kdead;
   p.out_scale = 1.0f / (scale * PSX);
   dim3 grid((N + PTN - 1) / PTN, nz);
   hipLaunchKernelGGL(leg_par_kernel, grid, dim3(192), 0, stream, p);
