@@ -17,6 +17,9 @@
  * Internal spectral layouts (fp32):
  *   grid-frequency  Xf[m][k][b][ri][c]   m < mtr = min(mmax, lmax), k < nlat, ri in {re, im}
  *   coefficients    Cs[l][m][b][ri][c]   l < lmax, m < mtr; entries with m > l are never read or written
+ * (These are the layouts of the stage-level entry points below.  sdy_sfno_forward keeps its own spectral workspace in a
+ *  private variant: the 2C axis ordered [c/16][ri][16], and (order, latitude) pairs whose Legendre table entries are below
+ *  1e-12 of the order's maximum omitted altogether -- DESIGN.md section 3.)
  *
  * Dropout stream (the reference uses torch's global generator: src/models/sfno/layers.py:76-78,
  * src/models/modules/drop_path.py:19 -- not reproducible across devices, so the product defines its own):
