@@ -949,6 +949,10 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   cv.x = xa; cv.x_bstride = (long)E * HW; use_w(n->e2w); cv.ldw = E; cv.out = xb; cv.out_bstride = (long)E * HW;
   cv.Cin = E; cv.Cout = E;
   if (c.pos_embed) { cv.add = n->pos.p; cv.add_bstride = 0; cv.add_mode = 2; }
+  {   // block 0's norm0 statistics from this convolution's epilogue (persistent kernel only): no pass over its output
+    static const bool no_stats0 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
+    if (cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats0) { cv.stats = st0; have_st0 = true; }
+  }
   SDY_TRY(sdy_conv1x1(&cv, stream));
 
   float* cur = xb;
