@@ -63,6 +63,25 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float hq = 0.5f * q;
   return x >= 0.0f ? x * (1.0f - hq) : x * hq;
 }
+// Two values at once: the Horner chain, the products and the final blend as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 run at
+// the scalar rate for two lanes of data); rcp and exp2 stay scalar.  Same arithmetic as gelu_erf, term by term.
+typedef float sdy_gf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sdy_gf2 gelu_erf2(sdy_gf2 x) {
+  const sdy_gf2 ax = __builtin_elementwise_abs(x);
+  const sdy_gf2 z = ax * 0.70710678118654752440f;
+  const sdy_gf2 d = z * 0.3275911f + 1.0f;
+  const sdy_gf2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  sdy_gf2 q = t * 1.061405429f + -1.453152027f;
+  q = q * t + 1.421413741f;
+  q = q * t + -0.284496736f;
+  q = q * t + 0.254829592f;
+  const sdy_gf2 e2 = z * z * -1.44269504088896340736f;
+  const sdy_gf2 e = {__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
+  const sdy_gf2 hq = q * t * e * 0.5f;                 // erfc(z) / 2
+  // x >= 0: x (1 - hq);  x < 0: x hq   ==   0.5 (x + |x|) - |x| hq ... written as x*hq' with hq' = (x >= 0 ? 1 - hq : hq)
+  const sdy_gf2 pos = x * (1.0f - hq), neg = x * hq;
+  return sdy_gf2{x.x >= 0.0f ? pos.x : neg.x, x.y >= 0.0f ? pos.y : neg.y};
+}
 __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 

@@ -250,8 +250,8 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
         v += brow[i];
         if (p.add_mode == 1) v += addv[i];
         if (p.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          const sdy_gf2 g0 = gelu_erf2(sdy_gf2{v.x, v.y}), g1 = gelu_erf2(sdy_gf2{v.z, v.w});
+          v = f32x4{g0.x, g0.y, g1.x, g1.y};
         }
         if (p.add_mode == 2) v += addv[i];
         if (c_ok) SDY_STREAM_STORE(og + (long)(CRS * i) * p.HW, v);
