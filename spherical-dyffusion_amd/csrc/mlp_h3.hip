@@ -278,47 +278,71 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       s.k0 += 0x9E3779B9u; s.k1 += 0xBB67AE85u;
     }
     switch (st) {
+      // (the arithmetic stages work on value PAIRS: v_pk_fma_f32 / v_pk_mul_f32 do two values per instruction at the scalar
+      // rate -- the chain is what bounds the interleaved fc2, see the timeline in DESIGN.md; rcp / exp2 stay scalar)
       case 0:
 #pragma unroll
         for (int r = 0; r < 4; ++r) s.v[r] = acc[j][4 * g4 + r] * p.s1 + bv[g4][r];
         break;
-      // exact-erf GELU times SX in 20 instructions per value: with z = |v| / sqrt(2), t = 1 / (1 + p z) and
+      // exact-erf GELU times SX: with z = |v| / sqrt(2), t = 1 / (1 + p z) and
       // Q = SX * erfc(z) / 2 = t * poly(t) * exp(-z^2) (A&S 7.1.26, coefficients pre-multiplied by SX / 2),
       //   SX * gelu(v) = (SX/2) v + |v| (SX/2 - Q)          (both signs of v, no compare / select)
       case 1:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s.t[r] = fmaf(0.3275911f * 0.70710678118654752440f, fabsf(s.v[r]), 1.0f);
-          s.e[r] = s.v[r] * s.v[r];
+        for (int r = 0; r < 4; r += 2) {
+          const sdy_gf2 v2 = {s.v[r], s.v[r + 1]};
+          const sdy_gf2 t2 = __builtin_elementwise_abs(v2) * (0.3275911f * 0.70710678118654752440f) + 1.0f;
+          const sdy_gf2 e2 = v2 * v2;
+          s.t[r] = t2.x; s.t[r + 1] = t2.y;
+          s.e[r] = e2.x; s.e[r + 1] = e2.y;
         }
         break;
-      case 2:
+      case 2: {
         s.t[0] = __builtin_amdgcn_rcpf(s.t[0]); s.t[1] = __builtin_amdgcn_rcpf(s.t[1]);
-        s.e[0] *= -0.5f * 1.44269504088896340736f; s.e[1] *= -0.5f * 1.44269504088896340736f;
+        const sdy_gf2 e2 = sdy_gf2{s.e[0], s.e[1]} * (-0.5f * 1.44269504088896340736f);
+        s.e[0] = e2.x; s.e[1] = e2.y;
         break;
-      case 3:
+      }
+      case 3: {
         s.t[2] = __builtin_amdgcn_rcpf(s.t[2]); s.t[3] = __builtin_amdgcn_rcpf(s.t[3]);
-        s.e[2] *= -0.5f * 1.44269504088896340736f; s.e[3] *= -0.5f * 1.44269504088896340736f;
+        const sdy_gf2 e2 = sdy_gf2{s.e[2], s.e[3]} * (-0.5f * 1.44269504088896340736f);
+        s.e[2] = e2.x; s.e[3] = e2.y;
         break;
+      }
       case 4: s.e[0] = __builtin_amdgcn_exp2f(s.e[0]); s.e[1] = __builtin_amdgcn_exp2f(s.e[1]); break;
       case 5: s.e[2] = __builtin_amdgcn_exp2f(s.e[2]); s.e[3] = __builtin_amdgcn_exp2f(s.e[3]); break;
       case 6:
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          s.q[r] = fmaf(fmaf(1.061405429f * (0.5f * SX), s.t[r], -1.453152027f * (0.5f * SX)), s.t[r], 1.421413741f * (0.5f * SX));
+        for (int r = 0; r < 4; r += 2) {
+          const sdy_gf2 t2 = {s.t[r], s.t[r + 1]};
+          sdy_gf2 q2 = t2 * (1.061405429f * (0.5f * SX)) + (-1.453152027f * (0.5f * SX));
+          q2 = q2 * t2 + (1.421413741f * (0.5f * SX));
+          s.q[r] = q2.x; s.q[r + 1] = q2.y;
+        }
         break;
       case 7:
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          s.q[r] = fmaf(fmaf(s.q[r], s.t[r], -0.284496736f * (0.5f * SX)), s.t[r], 0.254829592f * (0.5f * SX));
+        for (int r = 0; r < 4; r += 2) {
+          const sdy_gf2 t2 = {s.t[r], s.t[r + 1]};
+          sdy_gf2 q2 = sdy_gf2{s.q[r], s.q[r + 1]} * t2 + (-0.284496736f * (0.5f * SX));
+          q2 = q2 * t2 + (0.254829592f * (0.5f * SX));
+          s.q[r] = q2.x; s.q[r + 1] = q2.y;
+        }
         break;
       case 8:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s.q[r] = s.q[r] * s.t[r] * s.e[r];   // Q
+        for (int r = 0; r < 4; r += 2) {
+          const sdy_gf2 q2 = sdy_gf2{s.q[r], s.q[r + 1]} * sdy_gf2{s.t[r], s.t[r + 1]} * sdy_gf2{s.e[r], s.e[r + 1]};   // Q
+          s.q[r] = q2.x; s.q[r + 1] = q2.y;
+        }
         break;
       case 9:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s.v[r] = fmaf(0.5f * SX, s.v[r], fabsf(s.v[r]) * (0.5f * SX - s.q[r]));
+        for (int r = 0; r < 4; r += 2) {
+          const sdy_gf2 v2 = {s.v[r], s.v[r + 1]};
+          const sdy_gf2 o2 = v2 * (0.5f * SX) + __builtin_elementwise_abs(v2) * ((0.5f * SX) - sdy_gf2{s.q[r], s.q[r + 1]});
+          s.v[r] = o2.x; s.v[r + 1] = o2.y;
+        }
         break;
       case 10: {
         if (do_drop) {
