@@ -489,10 +489,17 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         for (int j = 0; j < 2; ++j) {
           const int px = 32 * j + l31;
 #pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            float o = oacc[mi][j][4 * g4 + r4] * p.s2 + bv[g4][r4];
-            if (do_drop) o = sdy_keep16(words[r4], j, p.drop_thr) ? o * p.drop_scale : 0.0f;
-            Os[(row0 + 8 * g4 + r4) * TN + px] = o * bscale;
+          for (int r4 = 0; r4 < 4; r4 += 2) {   // value pairs: packed fp32 FMA / MUL
+            sdy_gf2 o = sdy_gf2{oacc[mi][j][4 * g4 + r4], oacc[mi][j][4 * g4 + r4 + 1]} * p.s2 +
+                        sdy_gf2{bv[g4][r4], bv[g4][r4 + 1]};
+            if (do_drop) {
+              const sdy_gf2 od = o * p.drop_scale;
+              o = sdy_gf2{sdy_keep16(words[r4], j, p.drop_thr) ? od.x : 0.0f,
+                          sdy_keep16(words[r4 + 1], j, p.drop_thr) ? od.y : 0.0f};
+            }
+            o = o * bscale;
+            Os[(row0 + 8 * g4 + r4) * TN + px] = o.x;
+            Os[(row0 + 8 * g4 + r4 + 1) * TN + px] = o.y;
           }
         }
       }
