@@ -282,7 +282,10 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       // rate -- the chain is what bounds the interleaved fc2, see the timeline in DESIGN.md; rcp / exp2 stay scalar)
       case 0:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s.v[r] = acc[j][4 * g4 + r] * p.s1 + bv[g4][r];
+        for (int r = 0; r < 4; r += 2) {
+          const sdy_gf2 v2 = sdy_gf2{acc[j][4 * g4 + r], acc[j][4 * g4 + r + 1]} * p.s1 + sdy_gf2{bv[g4][r], bv[g4][r + 1]};
+          s.v[r] = v2.x; s.v[r + 1] = v2.y;
+        }
         break;
       // exact-erf GELU times SX: with z = |v| / sqrt(2), t = 1 / (1 + p z) and
       // Q = SX * erfc(z) / 2 = t * poly(t) * exp(-z^2) (A&S 7.1.26, coefficients pre-multiplied by SX / 2),
@@ -357,10 +360,12 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         _Float16* Hl = Hh + TN * HC;
         f16x4 vh, vl;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const _Float16 hv = (_Float16)s.v[r];
-          vh[r] = hv;
-          vl[r] = (_Float16)(s.v[r] - (float)hv);
+        for (int r = 0; r < 4; r += 2) {   // fp16 hi / lo split on pairs (packed conversions)
+          const sdy_f32x2 x2 = {s.v[r], s.v[r + 1]};
+          const sdy_f16x2 h2 = __builtin_convertvector(x2, sdy_f16x2);
+          const sdy_f16x2 l2 = __builtin_convertvector(x2 - __builtin_convertvector(h2, sdy_f32x2), sdy_f16x2);
+          vh[r] = h2[0]; vh[r + 1] = h2[1];
+          vl[r] = l2[0]; vl[r + 1] = l2[1];
         }
         // local k of these 4 values: 32 wave + 8 g4 + 4 h .. +3  ->  16-byte chunk 4 wave + g4, half h
         const int off = hs_off(px, 4 * wave + g4) + 4 * h;
