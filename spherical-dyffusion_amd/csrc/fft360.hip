@@ -43,7 +43,7 @@ constexpr int MIT = 3;                    // m-major iterations: m = mg + 64*it 
 #define SDY_FFT_MINB_I 4
 #endif
 #ifndef SDY_FFT_KPW
-#define SDY_FFT_KPW 2
+#define SDY_FFT_KPW 1
 #endif
 constexpr int MINB_F = SDY_FFT_MINB_F, MINB_I = SDY_FFT_MINB_I;   // workgroups per CU the register budgets are set for
 
