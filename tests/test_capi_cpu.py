@@ -88,3 +88,28 @@ def test_philox_known_answers():
     for ctr, key, exp in kat:
         got = tuple(int(x) for x in philox4x32_10(*ctr, *key))
         assert got == exp
+
+
+def test_element_dropout_stream_definition():
+    """The documented element-dropout stream (include/sdy_amd.h), re-derived value by value from the generator:
+    one Philox call per (4 channels, pixel pair n / n + 32), word = channel & 3, half-word = bit 5 of the pixel,
+    keep <=> half-word >= floor(p * 2^16)."""
+    import numpy as np
+
+    from oracle.philox import drop_threshold16, element_keep_mask, philox4x32_10
+
+    seed, call, layer, kind, p = 0x1234_5678_9ABC, 7, 3, 1, 0.13
+    B, C, H, W, boff = 2, 8, 3, 40, 5
+    mask = element_keep_mask(seed, call, layer, kind, p, B, C, H, W, batch_offset=boff)
+    thr = drop_threshold16(p)
+    assert thr == int(np.float32(p) * 65536.0)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        b, c, pix = int(rng.integers(B)), int(rng.integers(C)), int(rng.integers(H * W))
+        words = philox4x32_10(np.uint32(pix & ~32), np.uint32((b + boff) * (C // 4) + (c >> 2)), np.uint32(2 * layer + kind),
+                              np.uint32(call), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        w = int(words[c & 3])
+        half = (w >> 16) if (pix >> 5) & 1 else (w & 0xFFFF)
+        assert mask.reshape(B, C, H * W)[b, c, pix] == (1.0 if half >= thr else 0.0)
+    # the two pixels of a pair come from the same call: flipping bit 5 changes only the half-word
+    assert 0.05 < 1.0 - mask.mean() < 0.25
