@@ -42,6 +42,9 @@ constexpr int MIT = 3;                    // m-major iterations: m = mg + 64*it 
 #ifndef SDY_FFT_MINB_I
 #define SDY_FFT_MINB_I 4
 #endif
+// latitude rings per workgroup (the ring loop prefetches ring k + 1 under ring k's passes when > 1).  Measured end to end:
+// 4 rings 130.9, 2 rings 131.6 / 139.2, 1 ring 139.9 member-forecast-steps/s -- more, smaller workgroups balance better than
+// the prefetch helps (4 workgroups per CU already overlap each other's loads).
 #ifndef SDY_FFT_KPW
 #define SDY_FFT_KPW 1
 #endif
