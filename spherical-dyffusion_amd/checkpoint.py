@@ -10,6 +10,10 @@ A checkpoint here is the dictionary `torch.load(path)` returns for a Lightning `
 checkpoint does not hold the interpolator's weights (`on_save_checkpoint` drops them), so the interpolator's own
 checkpoint is a second argument, exactly as the reference loads it from a second run.
 
+Which weights: the forecaster's EMA shadows iff its `use_ema` hyper-parameter is set (the stepper runs every step under
+`module.ema_scope()`), the interpolator's iff `diffusion_config.interpolator_use_ema` of the FORECASTER is set
+(`src/diffusion/dyffusion.py:236-237`) - the interpolator's own `use_ema` is not consulted.
+
 MI355X-first difference: EMA weights are baked ONCE at load time (the reference swaps EMA weights in and out of the
 module on every `ema_scope()`, i.e. every autoregressive step); `ema_scope()` of the resulting module is free.
 Dataset statistics (`data_dir_stats/*.nc` in the reference) are passed as plain `{name: float}` dictionaries.
@@ -68,6 +72,29 @@ def select_weights(state_dict: Mapping[str, torch.Tensor], net_prefix: str, ema_
     return out
 
 
+def module_weights(state: Mapping[str, Any], interpolator_state: Mapping[str, Any], use_ema: Optional[bool] = None,
+                   interpolator_use_ema: Optional[bool] = None) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+    """(forecaster weights, interpolator weights) as the reference samples with them.
+
+    Forecaster: the stepper wraps every step in `module.ema_scope()` (stepper_multistep.py:387), which swaps the EMA
+    shadows in iff the forecaster's `use_ema` hyper-parameter is set (`_base_experiment.py:386-401`).
+    Interpolator: the reference enters ITS `ema_scope` only when the FORECASTER's `diffusion_config.interpolator_use_ema`
+    is set (`src/diffusion/dyffusion.py:236-237`); the interpolator's own `use_ema` merely decides whether its checkpoint
+    carries `model_ema.*` shadows (loaded next to the raw weights, never copied in by the loader, `src/interface.py:158-166`).
+    Shipped configs: every module trains with `use_ema: True` (`configs/experiment/fv3gfs.yaml:14`) and
+    `configs/diffusion/dyffusion.yaml:41` sets `interpolator_use_ema: False`, i.e. the published interpolator samples
+    with its RAW weights."""
+    hp = _plain(state["hyper_parameters"])
+    dc = _plain(hp.get("diffusion_config"))
+    if use_ema is None:
+        use_ema = bool(hp.get("use_ema", False))
+    if interpolator_use_ema is None:
+        interpolator_use_ema = bool(dc.get("interpolator_use_ema", False))
+    fw = select_weights(state["state_dict"], "model.model.", "model.", use_ema)
+    iw = select_weights(interpolator_state["state_dict"], "model.", "", interpolator_use_ema)
+    return fw, iw
+
+
 def _build_net(model_config: Mapping[str, Any], n_in: int, n_out: int, n_cond: int, spatial_shape: Tuple[int, int],
                weights: Mapping[str, torch.Tensor], **net_kwargs) -> SphericalFourierNeuralOperatorNet:
     mc = dict(model_config)
@@ -93,12 +120,7 @@ def module_from_state(state: Mapping[str, Any], interpolator_state: Mapping[str,
     in_names = [n for n in in_names if n not in forcing]
     n_in, n_out, n_cond = len(in_names), len(out_names), len(forcing)
     horizon = int(dm.get("horizon", dc.get("timesteps", 6)))
-    if use_ema is None:
-        use_ema = bool(hp.get("use_ema", False))
-    if interpolator_use_ema is None:
-        interpolator_use_ema = bool(ihp.get("use_ema", False))
-    fw = select_weights(state["state_dict"], "model.model.", "model.", use_ema)
-    iw = select_weights(interpolator_state["state_dict"], "model.", "", interpolator_use_ema)
+    fw, iw = module_weights(state, interpolator_state, use_ema, interpolator_use_ema)
     # the interpolator sees (x_0, x_h) stacked on the channel axis (interpolation.py: window + 1 snapshot)
     with torch.cuda.device(device):
         fnet = _build_net(_plain(hp["model_config"]), n_in, n_out, n_cond, spatial_shape, fw, **net_kwargs)

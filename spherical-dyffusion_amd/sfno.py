@@ -52,10 +52,27 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         data_grid: str = "equiangular",
         seed: int = 0,
         gemm_mode: Optional[str] = None,   # "f32" (fp32 MFMA) | "h3" (split-fp16 3-pass MFMA); default $SDY_GEMM_MODE or "f32"
-        **unused,
+        **other,
     ):
         super().__init__()
         unsupported = []
+        # Keywords of the reference constructor that cannot change the numerics of this configuration (linear dhconv
+        # filter, dense weights): accepted and ignored.  `dropout_filter` is one of them - the reference itself prints
+        # "Dropout is not used for linear filters!" and drops it (sfnonet.py:136-137).  Everything else is an error,
+        # so a checkpoint whose `model_config` asks for a different stochastic model cannot load silently.
+        inert = {"params", "dropout_filter", "num_blocks", "sparsity_threshold", "use_complex_kernels", "rank",
+                 "complex_network", "complex_activation", "spectral_layers", "checkpointing", "verbose", "name",
+                 "loss_function", "loss_function_weights", "datamodule_config", "num_output_channels_raw",
+                 "spatial_shape_out"}
+        if float(other.get("pos_emb_dropout", 0.0) or 0.0) > 0.0:       # nn.Dropout on the embedding (sfnonet.py:621,827)
+            unsupported.append(f"pos_emb_dropout={other['pos_emb_dropout']}")
+        if other.get("debug_mode", False):                               # shrinks the network (sfnonet.py:468-471)
+            unsupported.append("debug_mode=True")
+        if other.get("params"):
+            unsupported.append("params=<non-empty> (modulus-style parameter object)")
+        unknown = sorted(set(other) - inert - {"pos_emb_dropout", "debug_mode"})
+        if unknown:
+            raise TypeError(f"SphericalFourierNeuralOperatorNet: unexpected keyword arguments {unknown}")
         if spectral_transform != "sht": unsupported.append(f"spectral_transform={spectral_transform}")
         if filter_type != "linear": unsupported.append(f"filter_type={filter_type}")
         if operator_type != "dhconv": unsupported.append(f"operator_type={operator_type}")

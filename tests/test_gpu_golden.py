@@ -217,14 +217,17 @@ def test_checkpoint_ingestion_reproduces_reference_stepper():
     names = {k: json.loads(str(z[k])) for k in ("in_names", "out_names", "forcing_names")}
     pr = json.loads(str(z["prescriber"]))
 
-    def ckpt(kind, weights, prefix, ema):
+    def ckpt(kind, weights, prefix, has_ema, sample_with_ema, interpolator_use_ema=False):
+        """A Lightning-shaped checkpoint.  `has_ema`: trained with use_ema (model_ema.* shadows present);
+        `sample_with_ema`: which copy holds the fixture's weights - the other copy is noise and must not be used."""
         hp = json.loads(json.dumps(lay[kind]["hyper_parameters"]))
-        hp["use_ema"] = ema
+        hp["use_ema"] = has_ema
         if kind == "forecaster":     # the data module of the stepper fixture (HGTsfc input-only, prescriber)
             hp["datamodule_config"].update(in_names=names["in_names"], out_names=names["out_names"],
                                            forcing_names=names["forcing_names"],
                                            prescriber=dict(_target_="x.Prescriber", **pr))
             hp["diffusion_config"]["enable_interpolator_dropout"] = False
+            hp["diffusion_config"]["interpolator_use_ema"] = interpolator_use_ema
         else:
             hp["model_config"].update(dropout_mlp=0.0, drop_path_rate=0.0)
         keys = lay[kind]["state_dict_keys"]
@@ -235,11 +238,15 @@ def test_checkpoint_ingestion_reproduces_reference_stepper():
                 w = weights[k[len(prefix):].replace("mlp.fwd.3", "mlp.fwd.2")]
                 k = k.replace("mlp.fwd.3", "mlp.fwd.2")
             sd[k] = w.clone()
-        if ema:
+        if has_ema:
             handle = "model." if kind == "forecaster" else ""
             for k in list(sd):
-                sd["model_ema." + (handle + k[len(prefix):]).replace(".", "")] = sd[k].clone()
-                sd[k] = torch.randn_like(sd[k])          # the raw weights must not be used
+                shadow = "model_ema." + (handle + k[len(prefix):]).replace(".", "")
+                if sample_with_ema:
+                    sd[shadow] = sd[k].clone()
+                    sd[k] = torch.randn_like(sd[k])          # the raw weights must not be used
+                else:
+                    sd[shadow] = torch.randn_like(sd[k])     # the shadows must not be used
             sd["model_ema.decay"] = torch.tensor(0.9999)
         return {"hyper_parameters": hp, "state_dict": sd}
 
@@ -247,14 +254,18 @@ def test_checkpoint_ingestion_reproduces_reference_stepper():
     stds = {k[5:]: float(z[k]) for k in z.files if k.startswith("std::")}
     data = {k[6:]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("data::")}
     n_steps = int(z["n_steps"])
-    for ema in (False, True):
-        stepper = sdy_amd.checkpoint.stepper_from_state(ckpt("forecaster", fsd, "model.model.", ema),
-                                                        ckpt("interpolator", isd, "model.", ema), means, stds, (32, 64))
+    # (forecaster use_ema, interpolator trained with EMA, diffusion_config.interpolator_use_ema): the reference samples
+    # the interpolator from its EMA shadows only under the LAST flag (dyffusion.py:236-237); the middle case is the
+    # shipped configuration (fv3gfs.yaml use_ema: True for both, dyffusion.yaml interpolator_use_ema: False)
+    for f_ema, i_has_ema, i_use_ema in ((False, False, False), (True, True, False), (True, True, True)):
+        stepper = sdy_amd.checkpoint.stepper_from_state(
+            ckpt("forecaster", fsd, "model.model.", f_ema, f_ema, interpolator_use_ema=i_use_ema),
+            ckpt("interpolator", isd, "model.", i_has_ema, i_use_ema), means, stds, (32, 64))
         assert stepper.prescriber is not None and stepper.prescriber.prescribed_name == pr["prescribed_name"]
         out = stepper.run_on_batch(data, None, n_forward_steps=n_steps)
         for n in names["out_names"]:
             e = rel_l2(out.gen_data[n], torch.from_numpy(z["gen::" + n]))
-            assert e < TOL_TIGHT, f"ema={ema} {n}: {e:.3e}"
+            assert e < TOL_TIGHT, f"ema={(f_ema, i_has_ema, i_use_ema)} {n}: {e:.3e}"
 
 
 def test_ensemble_metrics_vs_reference():

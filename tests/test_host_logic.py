@@ -98,6 +98,16 @@ def test_state_dict_contract_matches_reference_fixture(sdy):
     assert "blocks.0.mlp.fwd.2.weight" in net0.state_dict() and "blocks.0.mlp.fwd.3.weight" not in net0.state_dict()
     with pytest.raises(NotImplementedError):
         sdy.SphericalFourierNeuralOperatorNet(4, 4, operator_type="diagonal")
+    # keywords that would change the (stochastic) model are refused, the inert ones of the shipped sfno.yaml are accepted
+    with pytest.raises(NotImplementedError):
+        sdy.SphericalFourierNeuralOperatorNet(4, 4, pos_emb_dropout=0.1)
+    with pytest.raises(NotImplementedError):
+        sdy.SphericalFourierNeuralOperatorNet(4, 4, debug_mode=True)
+    with pytest.raises(TypeError):
+        sdy.SphericalFourierNeuralOperatorNet(4, 4, no_such_option=1)
+    sdy.SphericalFourierNeuralOperatorNet(4, 4, spatial_shape_in=(32, 64), embed_dim=8, num_layers=1, dropout_filter=0.0,
+                                          pos_emb_dropout=0.0, spectral_layers=3, sparsity_threshold=0.0, num_blocks=8,
+                                          checkpointing=0, loss_function="mse", verbose=False, name="")
 
 
 def test_partition(sdy):
@@ -162,3 +172,41 @@ def test_checkpoint_weight_selection_follows_lightning_layout():
         select_weights({"foo.bar": torch.zeros(1)}, "model.model.", "model.", False)
     with pytest.raises(KeyError):
         select_weights({k: v for k, v in sd.items() if "model_ema" not in k}, "model.model.", "model.", True)
+
+
+def test_interpolator_ema_follows_forecaster_diffusion_config():
+    """checkpoint.module_weights: the interpolator's EMA shadows are used iff the FORECASTER's
+    diffusion_config.interpolator_use_ema is set (reference dyffusion.py:236-237), never because the interpolator's own
+    checkpoint says use_ema (shipped: fv3gfs.yaml use_ema True everywhere, dyffusion.yaml interpolator_use_ema False)."""
+    import pytest
+    import torch
+
+    from sdy_amd.checkpoint import module_weights
+
+    def ck(prefix, handle, use_ema, diffusion=None):
+        sd = {prefix + "encoder.0.weight": torch.full((1,), 1.0), prefix + "decoder.2.weight": torch.full((1,), 2.0)}
+        if use_ema:
+            for k in list(sd):
+                sd["model_ema." + (handle + k[len(prefix):]).replace(".", "")] = sd[k] + 100.0
+        hp = {"use_ema": use_ema}
+        if diffusion is not None:
+            hp["diffusion_config"] = diffusion
+        return {"hyper_parameters": hp, "state_dict": sd}
+
+    # shipped: both trained with EMA, interpolator_use_ema False -> forecaster EMA, interpolator RAW
+    fw, iw = module_weights(ck("model.model.", "model.", True, {"interpolator_use_ema": False}), ck("model.", "", True))
+    assert float(fw["encoder.0.weight"]) == 101.0 and float(iw["encoder.0.weight"]) == 1.0
+    # key absent from the diffusion config: the reference's default is False (dyffusion.py:52)
+    fw, iw = module_weights(ck("model.model.", "model.", True, {}), ck("model.", "", True))
+    assert float(iw["decoder.2.weight"]) == 2.0
+    # interpolator_use_ema True -> shadows
+    fw, iw = module_weights(ck("model.model.", "model.", False, {"interpolator_use_ema": True}), ck("model.", "", True))
+    assert float(fw["encoder.0.weight"]) == 1.0 and float(iw["encoder.0.weight"]) == 101.0
+    # ... and an interpolator checkpoint without shadows cannot serve that request (the reference has no model_ema then)
+    with pytest.raises(KeyError):
+        module_weights(ck("model.model.", "model.", False, {"interpolator_use_ema": True}), ck("model.", "", False))
+    # explicit overrides win
+    fw, iw = module_weights(ck("model.model.", "model.", True, {}), ck("model.", "", True), use_ema=False,
+                            interpolator_use_ema=True)
+    assert float(fw["encoder.0.weight"]) == 1.0 and float(iw["encoder.0.weight"]) == 101.0
+
