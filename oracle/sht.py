@@ -18,8 +18,13 @@ Published algorithm (torch-harmonics 0.6.x, `norm="ortho"`, `csphase=True`):
   forward        : X = 2*pi*rfft(x, norm="forward"); out[l,m] = sum_k X[k,m] P[m,l,k] w_k
   inverse        : Y[k,m] = sum_l c[l,m] P[m,l,k]; x = irfft(Y, n=nlon, norm="forward")
 
-PARITY UNPINNED by the reference (it holds no test or fixture at this boundary);
-pinned analytically in tests/test_oracle_sht.py.
+PARITY UNPINNED by the reference (it holds no test or fixture at this boundary).
+Pinned instead against independent implementations at PRODUCTION size
+(tests/test_sht_pin_scipy.py: every (m, l, k) of both 180 x 360 tables vs
+scipy.special.sph_harm_y, quadrature vs a Chebyshev moment solve /
+scipy.special.roots_legendre, transform known answers from scipy fields,
+addition theorem, full-band Gauss orthonormality) and analytically at small
+sizes (tests/test_oracle_sht.py).
 """
 from __future__ import annotations
 
