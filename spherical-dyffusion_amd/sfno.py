@@ -175,13 +175,74 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                 missing.append(k)
         for k in state_dict:
             if k not in self._params:
-                if ".weights" in k or ".pct" in k:   # persistent SHT buffers of old torch-harmonics (Appendix A.5)
+                spec = self._persisted_sht_table(k)
+                if spec is not None:     # persistent SHT buffer of an old torch-harmonics: the authoritative table
+                    self._check_persisted_sht_table(k, state_dict[k], *spec)
                     continue
                 unexpected.append(k)
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing={missing[:5]}... unexpected={unexpected[:5]}...")
         self._native_dirty = True
         return missing, unexpected
+
+    # ---- persisted SHT tables --------------------------------------------------------
+    def _persisted_sht_table(self, key: str):
+        """Older torch-harmonics releases registered `RealSHT.weights` / `InverseRealSHT.pct` as PERSISTENT buffers, so a
+        checkpoint written with them carries the tables the network was trained with (under the four transform modules
+        of `sfnonet.py:551-554` and again under every block's `filter.filter.{forward,inverse}_transform`).  Returns
+        (kind, grid) for such a key, None for anything else."""
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf not in ("weights", "pct"):
+            return None
+        owner = key[: -len(leaf) - 1]
+        lg, dg = "legendre-gauss", self.data_grid
+        fixed = {"trans_down": ("weights", dg), "itrans_up": ("pct", dg), "trans": ("weights", lg), "itrans": ("pct", lg)}
+        if owner in fixed:
+            return fixed[owner] if fixed[owner][0] == leaf else None
+        parts = owner.split(".")
+        if len(parts) == 5 and parts[0] == "blocks" and parts[1].isdigit() and parts[2:4] == ["filter", "filter"]:
+            i = int(parts[1])
+            if parts[4] == "forward_transform" and leaf == "weights":       # sfnonet.py:676: first block reads the data grid
+                return "weights", (dg if i == 0 else lg)
+            if parts[4] == "inverse_transform" and leaf == "pct":           # sfnonet.py:677: last block writes the data grid
+                return "pct", (dg if i == self.num_layers - 1 else lg)
+        return None
+
+    _table_cache: Dict[tuple, torch.Tensor] = {}
+
+    def _computed_sht_table(self, kind: str, grid: str) -> torch.Tensor:
+        """fp32 table exactly as the native plan uploads it (fp64 on the host, cast like `.float()`)."""
+        nlat, nlon = self.img_shape
+        L, M = self.modes_lat, self.modes_lon
+        key = (kind, grid, nlat, nlon, L, M)
+        if key not in self._table_cache:
+            pct = torch.zeros(M, L, nlat, dtype=torch.float64)
+            w = torch.zeros(nlat, dtype=torch.float64)
+            check(lib.sdy_sht_tables_host(nlat, nlon, L, M, _lib.SDY_GRID[grid], ptr(pct), ptr(w), None),
+                  "sdy_sht_tables_host")
+            t = pct * w[None, None, :] if kind == "weights" else pct
+            self._table_cache[key] = t.to(torch.float32)
+        return self._table_cache[key]
+
+    def _check_persisted_sht_table(self, key: str, value: torch.Tensor, kind: str, grid: str) -> None:
+        """First-contact check: the product recomputes its tables, so a checkpoint that was trained with different ones
+        (another normalisation, phase convention, node order or quadrature) must not load silently."""
+        mine = self._computed_sht_table(kind, grid)
+        theirs = value.detach().to("cpu", torch.float64)
+        if tuple(theirs.shape) != tuple(mine.shape):
+            raise _lib.SdyError(f"persisted SHT table {key}: shape {tuple(theirs.shape)} != computed {tuple(mine.shape)} "
+                                f"([mmax][lmax][nlat] for {grid}); this checkpoint's torch-harmonics lays its tables out "
+                                f"differently - refusing to guess")
+        scale = float(mine.abs().max())
+        diff = float((theirs - mine.double()).abs().max())
+        if not diff <= 4e-6 * scale:          # fp32 rounding of either side is <= 6e-8 * scale; a convention change is O(scale)
+            i = int((theirs - mine.double()).abs().argmax())
+            m, rem = divmod(i, mine.shape[1] * mine.shape[2])
+            l, k = divmod(rem, mine.shape[2])
+            raise _lib.SdyError(f"persisted SHT table {key} ({kind}, {grid}) differs from the table this library computes: "
+                                f"max |diff| {diff:.3e} (table scale {scale:.3e}) at (m={m}, l={l}, k={k}).  The checkpoint "
+                                f"was trained with different Legendre tables (torch-harmonics version / norm / csphase); "
+                                f"results would not match the reference.")
 
     # ---- reference helpers ----------------------------------------------------------------------------------
     def set_min_max_time(self, min_time: float, max_time: float):     # sfnonet.py:761-773

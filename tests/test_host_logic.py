@@ -210,3 +210,46 @@ def test_interpolator_ema_follows_forecaster_diffusion_config():
                             interpolator_use_ema=True)
     assert float(fw["encoder.0.weight"]) == 1.0 and float(iw["encoder.0.weight"]) == 101.0
 
+
+
+def test_persisted_sht_buffers_are_checked(sdy):
+    """checkpoints written with an old torch-harmonics carry `*.weights` / `*.pct`; those are the
+    tables the network was trained with (reference sfnonet.py:551-554).  Matching ones load, different ones raise."""
+    from oracle.sht import sht_tables
+    from sdy_amd._lib import SdyError
+
+    H, W, E, Lr = 16, 32, 8, 2
+    net = sdy.SphericalFourierNeuralOperatorNet(4, 4, spatial_shape_in=(H, W), embed_dim=E, num_layers=Lr)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    tabs = {g: sht_tables(H, W, H, W // 2 + 1, g) for g in ("equiangular", "legendre-gauss")}
+    f32 = lambda a: torch.from_numpy(a).float()  # noqa: E731
+    eq, lg = tabs["equiangular"], tabs["legendre-gauss"]
+    persisted = {
+        "trans_down.weights": f32(eq[1]), "itrans_up.pct": f32(eq[0]), "trans.weights": f32(lg[1]), "itrans.pct": f32(lg[0]),
+        "blocks.0.filter.filter.forward_transform.weights": f32(eq[1]),      # first block reads the data grid
+        "blocks.0.filter.filter.inverse_transform.pct": f32(lg[0]),
+        "blocks.1.filter.filter.forward_transform.weights": f32(lg[1]),
+        "blocks.1.filter.filter.inverse_transform.pct": f32(eq[0]),          # last block writes the data grid
+    }
+    missing, unexpected = net.load_state_dict({**sd, **persisted}, strict=True)
+    assert not missing and not unexpected
+    # a table from another convention (no Condon-Shortley phase) is refused, naming the key
+    bad = dict(persisted)
+    nocs = eq[0].copy()
+    nocs[1::2] *= -1
+    bad["itrans_up.pct"] = f32(nocs)
+    with pytest.raises(SdyError, match="itrans_up.pct"):
+        net.load_state_dict({**sd, **bad}, strict=True)
+    # the Gauss table where the equiangular one belongs (wrong grid for the first block)
+    bad = dict(persisted)
+    bad["blocks.0.filter.filter.forward_transform.weights"] = f32(lg[1])
+    with pytest.raises(SdyError, match="blocks.0.filter"):
+        net.load_state_dict({**sd, **bad}, strict=False)
+    # another layout
+    bad = dict(persisted)
+    bad["trans.weights"] = f32(lg[1]).permute(1, 0, 2).contiguous()
+    with pytest.raises(SdyError, match="shape"):
+        net.load_state_dict({**sd, **bad}, strict=True)
+    # keys that merely end in .weights elsewhere are still unexpected
+    with pytest.raises(RuntimeError):
+        net.load_state_dict({**sd, "something.else.weights": torch.zeros(1)}, strict=True)
