@@ -511,8 +511,6 @@ extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
   g.batch_scale = a->batch_scale;
   if (a->w_h3) {
     const int Mp = h3_mpad(a->Cout), Kp = h3_kpad(a->Cin);
-    static const int use_ws = [] { const char* e = std::getenv("SDY_H3_WS"); return (e && e[0] == '1') ? 1 : 0; }();
-    if (use_ws) return sdy_gemm_h3_ws_launch(g, a->w_h3, Mp, Kp, (long)Mp * Kp, a->w_h3_scale, (hipStream_t)stream);
     return sdy_gemm_h3_launch(g, a->w_h3, Mp, Kp, 0, (long)Mp * Kp, a->w_h3_scale, 0, (hipStream_t)stream);
   }
   return sdy_gemm_launch(g, (hipStream_t)stream);

@@ -23,6 +23,31 @@ static inline int sdy_launch_status() {
   return e == hipSuccess ? SDY_OK : (int)e;
 }
 
+// Per-DEVICE launch caches: one process may drive several devices (sfno.py keeps one native handle per device index), so
+// nothing about "the" device is cached per process.  hipGetDevice is a thread-local read.
+constexpr int SDY_MAX_DEVICES = 64;
+static inline int sdy_current_device(int* dev) {
+  SDY_HIP_TRY(hipGetDevice(dev));
+  return (*dev >= 0 && *dev < SDY_MAX_DEVICES) ? SDY_OK : SDY_ERR_ARG;
+}
+inline int sdy_cu_count(int* n_cu) {                 // compute units of the CURRENT device
+  static int cache[SDY_MAX_DEVICES] = {};
+  int dev = 0;
+  SDY_TRY(sdy_current_device(&dev));
+  if (!cache[dev]) SDY_HIP_TRY(hipDeviceGetAttribute(&cache[dev], hipDeviceAttributeMultiprocessorCount, dev));
+  *n_cu = cache[dev];
+  return SDY_OK;
+}
+struct SdyOncePerDevice {                            // `static SdyOncePerDevice once;` next to a kernel's attribute setup
+  bool done[SDY_MAX_DEVICES] = {};
+  int slot(bool** flag) {
+    int dev = 0;
+    SDY_TRY(sdy_current_device(&dev));
+    *flag = &done[dev];
+    return SDY_OK;
+  }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // fp16 hi / lo split of 8 fp32 values (already scaled) for the split-precision MFMA kernels, written on 2-vectors so that it
 // compiles to packed conversions (v_cvt_pk_f16_f32, v_pk_add_f32 / fma_mix) instead of ~6 scalar VALU ops per element.
@@ -157,10 +182,6 @@ int sdy_gemm_launch(const GemmParams& p, hipStream_t stream);
 //   rows_mode 0: packed = A [M][K], p.B = fp32 [K][N];  rows_mode 1: p.A = fp32 [M][K] (k contiguous), packed = B [N][K]
 int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, int Kpad, long bstride, long plane_halfs,
                        float w_scale, int rows_mode, hipStream_t stream);
-
-// persistent warp-specialised variant for conv mode (gemm_h3_ws.hip)
-int sdy_gemm_h3_ws_launch(const GemmParams& p, const void* packed, int rows_pad, int Kpad, long plane_halfs, float w_scale,
-                          hipStream_t stream);
 
 // ---- persistent 256 -> 256 convolution (conv_h3.hip)
 int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream);

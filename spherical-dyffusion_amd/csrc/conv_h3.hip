@@ -367,12 +367,8 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
     if (!g_cstamps) SDY_HIP_TRY(hipMalloc(&g_cstamps, 64 * sizeof(unsigned long long)));
     p.stamps = g_cstamps;
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    SDY_HIP_TRY(hipGetDevice(&dev));
-    SDY_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  int n_cu = 0;
+  SDY_TRY(sdy_cu_count(&n_cu));
   const long ntiles = (long)((a->HW + CTN - 1) / CTN) * a->B;
   const long want = n_cu;   // persistent: one workgroup per CU
   dim3 grid((unsigned)(ntiles < want ? ntiles : want));

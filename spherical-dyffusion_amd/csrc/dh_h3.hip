@@ -328,13 +328,15 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
     if (!g_dstamps) SDY_HIP_TRY(hipMalloc(&g_dstamps, 256 * sizeof(unsigned long long)));
     p.stamps = g_dstamps;
   }
-  static int n_cu = 0;
+  int n_cu = 0;
+  SDY_TRY(sdy_cu_count(&n_cu));
   const int smem = 2 * DTN * DK * (int)sizeof(_Float16) + DWAVES * 8 * 64 * (int)sizeof(float);   // x tile + staging
-  if (!n_cu) {
-    int dev = 0;
-    SDY_HIP_TRY(hipGetDevice(&dev));
-    SDY_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  static SdyOncePerDevice once;
+  bool* attr_done = nullptr;
+  SDY_TRY(once.slot(&attr_done));
+  if (!*attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dh_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    *attr_done = true;
   }
   const int grid = n_cu >= 8 ? (n_cu / 8) * 8 : 8;   // whole slots of 8 XCDs: one workgroup per CU
   hipLaunchKernelGGL(dh_h3_kernel, dim3(grid), dim3(512), smem, stream, p);

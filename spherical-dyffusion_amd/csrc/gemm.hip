@@ -218,13 +218,15 @@ int launch_inst(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int LDA_S = A_KCONTIG ? BM + 1 : BM;
   constexpr size_t smem = (size_t)2 * BK * (LDA_S + BN) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SdyOncePerDevice once;
+  bool* attr_done = nullptr;
+  SDY_TRY(once.slot(&attr_done));
+  if (!*attr_done) {
     if (smem > 48 * 1024) {
       SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<WM, WN, A_KCONTIG, B_CPLX, TAG>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
-    attr_done = true;
+    *attr_done = true;
   }
   const unsigned gn = (p.N + BN - 1) / BN, gm = (p.M + BM - 1) / BM;
   dim3 grid(p.tri_mode == SDY_TRI_NONE ? gm : gn, p.tri_mode == SDY_TRI_NONE ? gn : gm, p.nbatch);

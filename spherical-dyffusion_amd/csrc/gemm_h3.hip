@@ -307,11 +307,13 @@ template <int WM, int WN, int MODE, int TAG>
 int launch_h3(const GemmParams& p, const H3Packed& pk, float sx, float out_scale, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr size_t smem = (size_t)(2 * BM + 2 * BN) * HLD * sizeof(_Float16);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SdyOncePerDevice once;
+  bool* attr_done = nullptr;
+  SDY_TRY(once.slot(&attr_done));
+  if (!*attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<WM, WN, MODE, TAG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
+    *attr_done = true;
   }
   dim3 grid((p.M_store + BM - 1) / BM, (p.N + BN - 1) / BN, p.nbatch);
   hipLaunchKernelGGL((gemm_h3_kernel<WM, WN, MODE, TAG>), grid, dim3(256), smem, stream, p, pk, sx, out_scale);
@@ -469,11 +471,13 @@ __global__ __launch_bounds__(512) void gemm_h3_wide_kernel(const GemmParams p, c
 template <int TAG>
 int launch_h3_wide(const GemmParams& p, const H3Packed& pk, float sx, float out_scale, hipStream_t stream) {
   constexpr size_t smem = (size_t)(2 * 256 + 2 * 128) * WLD * sizeof(_Float16);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SdyOncePerDevice once;
+  bool* attr_done = nullptr;
+  SDY_TRY(once.slot(&attr_done));
+  if (!*attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_wide_kernel<TAG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
+    *attr_done = true;
   }
   dim3 grid((p.M_store + 255) / 256, (p.N + 127) / 128, p.nbatch);
   hipLaunchKernelGGL((gemm_h3_wide_kernel<TAG>), grid, dim3(512), smem, stream, p, pk, sx, out_scale);

@@ -665,22 +665,20 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
     if (!g_stamps) SDY_HIP_TRY(hipMalloc(&g_stamps, 64 * sizeof(unsigned long long)));
     p.stamps = g_stamps;
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    SDY_HIP_TRY(hipGetDevice(&dev));
-    SDY_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  int n_cu = 0;
+  SDY_TRY(sdy_cu_count(&n_cu));
   const long ntiles = (long)((a->HW + TN - 1) / TN) * a->B;
   dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));   // persistent: one workgroup per CU (128 KB of LDS each)
   constexpr size_t smem = (size_t)(2 * TN * ME + 4 * TN * HC) * sizeof(_Float16) + 5 * ME * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SdyOncePerDevice once;
+  bool* attr_done = nullptr;
+  SDY_TRY(once.slot(&attr_done));
+  if (!*attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
+    *attr_done = true;
   }
   if (p.drop_thr != 0u)
     hipLaunchKernelGGL(mlp_h3_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, p);

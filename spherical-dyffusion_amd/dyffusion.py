@@ -16,7 +16,6 @@ from __future__ import annotations
 from types import SimpleNamespace
 from typing import Any, Dict, List, Optional, Sequence, Union
 
-import numpy as np
 import torch
 from torch import Tensor
 
@@ -61,6 +60,11 @@ class DYffusion(torch.nn.Module):
         assert additional_interpolation_steps_factor == 0, \
             "additional_interpolation_steps_factor must be 0 when using before_t1_only schedule"
         assert interpolate_before_t1, "interpolate_before_t1 must be True when using before_t1_only schedule"
+        if refine_intermediate_predictions:
+            raise NotImplementedError("refine_intermediate_predictions=True (a second interpolator sweep, dyffusion.py:551-563) "
+                                      "is outside the shipped configuration")
+        if log_every_t is not None:
+            raise NotImplementedError("log_every_t (intermediate-state logging) is not on the sampling path")
         assert timesteps > 1, f"horizon must be > 1, but got {timesteps}. Please use datamodule.horizon with > 1"
         self.model = model
         self.interpolator = interpolator
@@ -119,44 +123,24 @@ class DYffusion(torch.nn.Module):
 
     @sampling_schedule.setter
     def sampling_schedule(self, schedule):
-        name = schedule
+        """Diffusion steps the sampler visits (reference setter: dyffusion.py:384-455).  Explicit lists and the named
+        schedule "only_dynamics" (= [0] + every step that lands on a data time step) are in scope; the reference's other
+        names pick subsets of ARTIFICIAL steps, which do not exist in the shipped configuration
+        (additional_interpolation_steps = 0), and raise here."""
         if isinstance(schedule, str):
-            base = [0] + list(self.dynamical_steps.keys())
-            artificial = list(self.artificial_interpolation_steps.keys())
-            if "only_dynamics" in name:
-                schedule = []
-                if "only_dynamics_plus" in name:
-                    plus_n = int(name.replace("only_dynamics_plus", "").replace("_discrete", ""))
-                    schedule = list(np.linspace(0, base[1], plus_n + 1, endpoint=False))
-                    if "_discrete" in name:
-                        schedule = [int(np.floor(s)) for s in schedule]
-                else:
-                    assert name == "only_dynamics", f"Invalid sampling schedule: {schedule}"
-            elif name.startswith("every"):
-                nth = int(name.replace("every", "").replace("th", "").replace("nd", "").replace("rd", ""))
-                assert 1 <= nth <= self.num_timesteps, f"Invalid sampling schedule: {name}"
-                schedule = artificial[::nth]
-            elif name.startswith("first"):
-                first_n = float(name.replace("first", "").replace("v2", ""))
-                if first_n < 1:
-                    assert 0 < first_n < 1, f"Invalid sampling schedule: {name}, must end with number/float > 0"
-                    schedule = artificial[: int(np.ceil(first_n * len(artificial)))]
-                else:
-                    assert first_n.is_integer() and 1 <= first_n <= self.num_timesteps, f"Invalid sampling schedule: {name}"
-                    schedule = artificial[: int(first_n)]
-            else:
-                raise ValueError(f"Invalid sampling schedule: ``{name}``. ")
-            schedule = list(sorted(set(schedule + base)))
-        schedule = list(schedule)
-        assert 1 <= schedule[-1] <= self.num_timesteps, \
-            f"Invalid sampling schedule: {schedule}, must end with number/float <= {self.num_timesteps}"
-        if schedule[0] != 0:
-            schedule = [0] + schedule
-        for i in range(1, len(schedule)):
-            assert schedule[i] > schedule[i - 1], f"Invalid sampling schedule not monotonically increasing: {schedule}"
-        if all(float(s).is_integer() for s in schedule):
-            schedule = [int(s) for s in schedule]
-        self._sampling_schedule = schedule
+            if schedule != "only_dynamics":
+                raise NotImplementedError(f"sampling_schedule={schedule!r}: named schedules other than 'only_dynamics' "
+                                          "select artificial interpolation steps (outside the shipped configuration); "
+                                          "pass the list of diffusion steps instead")
+            schedule = sorted({0, *self.dynamical_steps})
+        steps = [int(v) if float(v).is_integer() else float(v) for v in schedule]
+        if not steps or steps[0] != 0:
+            steps = [0] + steps
+        assert 1 <= steps[-1] <= self.num_timesteps, \
+            f"Invalid sampling schedule: {steps}, must end with number/float <= {self.num_timesteps}"
+        assert all(b > a for a, b in zip(steps, steps[1:])), \
+            f"Invalid sampling schedule not monotonically increasing: {steps}"
+        self._sampling_schedule = steps
 
     # ---- network calls ------------------------------------------------------------------------------------------
     @staticmethod
@@ -214,69 +198,55 @@ class DYffusion(torch.nn.Module):
         return self.model.predict_forward(x_t, time=time, condition=cond, **kwargs)
 
     # ---- sampler (dyffusion.py:457-577) -----------------------------------------------------------------------------
+    def _drop_carried_channel(self, x: Tensor) -> Tensor:
+        """`hack_for_imprecise_interpolation`: the state carries one input-only channel in front (dyffusion.py:41-44),
+        which every emitted prediction drops again (:509-510,532-533)."""
+        return x[:, 1:] if self.hparams.hack_for_imprecise_interpolation else x
+
     def sample_loop(self, initial_condition, log_every_t=None, num_predictions: int = None, verbose=True, **kwargs):
+        """Cold sampling (Alg. 2 of the paper; reference dyffusion.py:457-567): per visited diffusion step s one forecaster
+        call x_hat = F(x_s, s), then x_{s'} = x_s + I(x_0, x_hat, s') - I(x_0, x_hat, s) with the interpolator I drawing
+        fresh dropout masks on every call.  Returns (final state, {"t{k}_preds": ...}) like the reference; the
+        `log_every_t` diagnostics and `refine_intermediate_predictions` are refused by the constructor."""
         hp = self.hparams
-        log_every_t = log_every_t or hp.log_every_t
-        log_every_t = log_every_t if log_every_t != "auto" else 1
-        sched = self.sampling_schedule
+        if log_every_t is not None:
+            raise NotImplementedError("log_every_t: intermediate-state logging is not on the sampling path")
+        if hp.sampling_type not in ("cold", "naive"):
+            raise ValueError(f"unknown sampling type {hp.sampling_type}")
         assert len(initial_condition.shape) == 4, f"condition.shape: {initial_condition.shape} (should be 4D)"
-        N = self.num_timesteps
-        hack = hp.hack_for_imprecise_interpolation
-        intermediates, xhat_th, dynamics_pred_step = dict(), None, 0
-        last_p1 = sched[-1] + 1
-        triples = zip(sched, sched[1:] + [last_p1], sched[2:] + [last_p1, last_p1 + 1])
-        x_s = initial_condition
-        for s, s_next, s_nnext in triples:
-            is_last_step = s == N - 1
-            xhat_th = self.predict_x_last(initial_condition=initial_condition, x_t=x_s, t=s, **dict(kwargs))
-            time_i_n = self.diffusion_step_to_interpolation_step(s_next) if not is_last_step else np.inf
-            is_dynamics_pred = float(time_i_n).is_integer() or is_last_step
-            q_kwargs = dict(x0=xhat_th, x_end=initial_condition, is_artificial_step=not is_dynamics_pred)
-            if s_next <= N - 1:
-                x_ip_next = self.q_sample(**q_kwargs, t=s_next, **dict(kwargs))
+        sched, last = self.sampling_schedule, self.num_timesteps - 1
+        cold = hp.sampling_type == "cold"
+        preds: Dict[str, Tensor] = {}
+        x_s, x_hat, k = initial_condition, None, 0
+        for pos, s in enumerate(sched):
+            s_next = sched[pos + 1] if pos + 1 < len(sched) else sched[-1] + 1
+            final = s == last                      # the forecast itself is the last state: no interpolation to s_next
+            x_hat = self.predict_x_last(initial_condition=initial_condition, x_t=x_s, t=s, **dict(kwargs))
+            i_next = self.diffusion_step_to_interpolation_step(s_next) if not final else None
+            lands_on_data = final or float(i_next).is_integer()
+            ipol = dict(x0=x_hat, x_end=initial_condition, is_artificial_step=not lands_on_data)
+            if final:
+                assert s_next > last, f"Invalid s_next: {s_next} (should be <= {last})"
+                x_next = ops.concat_channels([initial_condition[:, :1], x_hat]) if hp.hack_for_imprecise_interpolation \
+                    else x_hat
             else:
-                assert is_last_step, f"Invalid s_next: {s_next} (should be <= {N - 1})"
-                x_ip_next = xhat_th
-                if hack:
-                    x_ip_next = ops.concat_channels([initial_condition[:, :1], x_ip_next])
-            x_ip_s = None
-            if hp.sampling_type == "cold":
-                if not hp.use_cold_sampling_for_last_step and is_last_step:
-                    if self.use_cold_sampling_for_init_of_ar_step:
-                        x_ip_s = self.q_sample(**q_kwargs, t=s, **dict(kwargs))
-                        ar_init = ops.cold_update(x_s, xhat_th, x_ip_s)
-                        intermediates["preds_autoregressive_init"] = ar_init[:, 1:] if hack else ar_init
-                    x_s = xhat_th
-                else:
-                    x_ip_s = self.q_sample(**q_kwargs, t=s, **dict(kwargs)) if s > 0 else None
-                    x_s = ops.cold_update(x_s, x_ip_next, x_ip_s)     # x_s + (x_ip_next - x_ip_s); s=0: x_ip_s == x_s
-            elif hp.sampling_type == "naive":
-                x_s = x_ip_next
+                assert s_next <= last, f"Invalid s_next: {s_next} (should be <= {last})"
+                x_next = self.q_sample(**ipol, t=s_next, **dict(kwargs))
+            if not cold:
+                x_s = x_next
+            elif final and not hp.use_cold_sampling_for_last_step:
+                if self.use_cold_sampling_for_init_of_ar_step:       # cold state only seeds the next AR window (:503-510)
+                    ar_init = ops.cold_update(x_s, x_hat, self.q_sample(**ipol, t=s, **dict(kwargs)))
+                    preds["preds_autoregressive_init"] = self._drop_carried_channel(ar_init)
+                x_s = x_hat
             else:
-                raise ValueError(f"unknown sampling type {hp.sampling_type}")
-            dynamics_pred_step = int(time_i_n) if s < N - 1 else dynamics_pred_step + 1
-            if is_dynamics_pred:
-                preds_t = x_s if (hp.use_cold_sampling_for_intermediate_steps or is_last_step) else x_ip_next
-                intermediates[f"t{dynamics_pred_step}_preds"] = preds_t[:, 1:] if hack else preds_t
-                if log_every_t is not None:
-                    intermediates[f"t{dynamics_pred_step}_preds2"] = x_ip_next
-            if log_every_t is not None:
-                intermediates[f"x_{s}_dmodel"] = x_s
-                intermediates[f"intermediate_{s}_x0hat"] = xhat_th
-                intermediates[f"xipol_{s}_dmodel"] = x_ip_next
-                if hp.sampling_type == "cold" and x_ip_s is not None:
-                    intermediates[f"xipol_{s}_dmodel2"] = x_ip_s
-        if hp.refine_intermediate_predictions:
-            steps = hp.prediction_timesteps or list(self.dynamical_steps.values())
-            for i_n in [i for i in steps if i < N]:
-                key = int(i_n) if float(i_n).is_integer() else i_n
-                assert not float(i_n).is_integer() or f"t{key}_preds" in intermediates, f"t{key}_preds not in intermediates"
-                r = self.q_sample(x0=xhat_th, x_end=initial_condition, is_artificial_step=False, t=None,
-                                  interpolation_time=i_n, **dict(kwargs))
-                intermediates[f"t{key}_preds"] = r[:, 1:] if hack else r
-        if last_p1 < N:
-            return x_s, intermediates
-        return xhat_th, intermediates
+                # x_s + (x_next - I(x_0, x_hat, s)); at s = 0 the interpolation "at time 0" is x_s itself
+                x_s = ops.cold_update(x_s, x_next, self.q_sample(**ipol, t=s, **dict(kwargs)) if s > 0 else None)
+            k = int(i_next) if not final else k + 1
+            if lands_on_data:
+                emit = x_s if (hp.use_cold_sampling_for_intermediate_steps or final) else x_next
+                preds[f"t{k}_preds"] = self._drop_carried_channel(emit)
+        return (x_hat if sched[-1] + 1 >= self.num_timesteps else x_s), preds
 
     @torch.inference_mode()
     def sample(self, initial_condition, num_samples=1, **kwargs) -> Dict[str, Tensor]:

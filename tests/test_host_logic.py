@@ -35,8 +35,18 @@ def test_schedule_maths_matches_reference_semantics(sdy):
     assert d2.dynamical_steps == {3: 1, 4: 2, 5: 3, 6: 4, 7: 5}
     d2.sampling_schedule = "only_dynamics"
     assert d2.sampling_schedule == [0, 3, 4, 5, 6, 7]
-    d2.sampling_schedule = "every2"
-    assert d2.sampling_schedule == [0, 1, 3, 4, 5, 6, 7]
+    d2.sampling_schedule = [3, 4.0, 5, 6, 7]          # explicit lists: 0 is prepended, integral floats become ints
+    assert d2.sampling_schedule == [0, 3, 4, 5, 6, 7]
+    with pytest.raises(NotImplementedError):         # names that select artificial steps are outside the shipped config
+        d2.sampling_schedule = "every2"
+    with pytest.raises(AssertionError):
+        d2.sampling_schedule = [0, 2, 2]
+    with pytest.raises(AssertionError):
+        d2.sampling_schedule = [0, 9]
+    with pytest.raises(NotImplementedError):
+        _sampler(sdy, refine_intermediate_predictions=True)
+    with pytest.raises(NotImplementedError):
+        _sampler(sdy, log_every_t=1)
     with pytest.raises(AssertionError):
         d.diffusion_step_to_interpolation_step(6)
     with pytest.raises(ValueError):
