@@ -328,6 +328,17 @@ int sdy_lp_rel_terms(const float* gen, const sdy_var_table* targets, int t, int 
 int sdy_ensemble_metrics(const float* pred, const float* truth, const float* weights, int M, long member_stride,
                          int n_planes, int HW, double* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Measurement.  While enabled, every kernel launch of sdy_sfno_forward is bracketed by a pair of
+ * hipEvents recorded ON THE LAUNCH STREAM, tagged with its stage (fused MLP with / without dropout, inner-skip conv,
+ * Legendre analysis / synthesis, rfft, irfft, dhconv, encoder / decoder convs, ...).  sdy_profile_read synchronises
+ * those events, returns per stage the summed elapsed milliseconds and the launch count since the last read, and resets.
+ * Not for timed regions: the extra event records add a few microseconds between kernels.  Process-wide switch. */
+int sdy_profile_enable(int on);
+int sdy_profile_stage_count(void);
+const char* sdy_profile_stage_name(int stage);
+int sdy_profile_read(double* total_ms, long* launches, int n);   /* arrays of n >= sdy_profile_stage_count() */
+
 #ifdef __cplusplus
 }
 #endif

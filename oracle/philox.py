@@ -63,8 +63,18 @@ def drop_threshold16(p: float) -> int:
     return min(max(int(p32 * 65536.0), 1 if p32 > 0.0 else 0), 0xFFFF)   # p > 0 never rounds to "no dropout"
 
 
+def _global_rows(B: int, batch_offset: int, rows) -> np.ndarray:
+    """Global trajectory index of every batch row: `batch_offset + b` (what the C ABI does), or an explicit table for an
+    oracle that walks the trajectories in another order than the device batch."""
+    if rows is None:
+        return np.arange(B, dtype=np.uint64) + np.uint64(batch_offset)
+    rows = np.asarray(rows, dtype=np.uint64)
+    assert rows.shape == (B,)
+    return rows
+
+
 def element_keep_mask(seed: int, call: int, layer: int, kind: int, p: float,
-                      B: int, C: int, H: int, W: int, batch_offset: int = 0) -> np.ndarray:
+                      B: int, C: int, H: int, W: int, batch_offset: int = 0, rows=None) -> np.ndarray:
     """Keep mask (B, C, H, W) of 0/1 float32 for MLP dropout (kind 0 = hidden, 1 = output).
 
     One Philox call covers 4 channels x the pixel pair (n & ~32, n | 32): word = ch & 3, low half-word for the pixel
@@ -74,7 +84,7 @@ def element_keep_mask(seed: int, call: int, layer: int, kind: int, p: float,
     npix = np.arange(H * W, dtype=np.uint32)
     pix = (npix & np.uint32(0xFFFFFFDF))[None, None, :]
     half = ((npix >> np.uint32(5)) & np.uint32(1))[None, None, None, :]
-    b = (np.arange(B, dtype=np.uint64) + np.uint64(batch_offset))[:, None, None]
+    b = _global_rows(B, batch_offset, rows)[:, None, None]
     g = np.arange(C // 4, dtype=np.uint64)[None, :, None]
     c1 = ((b * np.uint64(C // 4) + g) & MASK32).astype(np.uint32)
     words = philox4x32_10(pix, c1, np.uint32(2 * layer + kind), np.uint32(call & 0xFFFFFFFF),
@@ -85,10 +95,10 @@ def element_keep_mask(seed: int, call: int, layer: int, kind: int, p: float,
     return keep.reshape(B, C, H, W)
 
 
-def drop_path_keep(seed: int, call: int, layer: int, p: float, B: int, batch_offset: int = 0) -> np.ndarray:
+def drop_path_keep(seed: int, call: int, layer: int, p: float, B: int, batch_offset: int = 0, rows=None) -> np.ndarray:
     """Keep flags (B,) of 0/1 float32 for drop path of `layer`."""
     thr = np.uint32(drop_threshold(p))
-    b = ((np.arange(B, dtype=np.uint64) + np.uint64(batch_offset)) & MASK32).astype(np.uint32)
+    b = (_global_rows(B, batch_offset, rows) & MASK32).astype(np.uint32)
     w0, _, _, _ = philox4x32_10(b, np.uint32(0xFFFFFFFF), np.uint32(0x1000 + layer),
                                 np.uint32(call & 0xFFFFFFFF), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     return (w0 >= thr).astype(np.float32)

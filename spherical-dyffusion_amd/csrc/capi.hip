@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -887,6 +888,71 @@ extern "C" int sdy_sfno_time_embed(sdy_sfno* n, const float* time, int B, float*
   return sdy_time_mlp_launch(n->tm, time, B, t_repr, ss, nullptr, nullptr, 0, 0, 0, 0, (hipStream_t)stream);
 }
 
+// ---- stage timing of the forward (measurement only; off by default) ------------------------------------------------
+namespace {
+enum SdyStage {
+  ST_CONCAT, ST_TIME_MLP, ST_ENC0, ST_ENC2, ST_NORM_COEFFS, ST_FFT_FWD, ST_LEG_FWD, ST_LEG_INV, ST_FFT_INV, ST_DHCONV,
+  ST_SKIP_CONV, ST_MLP_FUSED, ST_MLP_FUSED_DROP, ST_FC1, ST_FC2, ST_DEC0, ST_DEC2, ST_COUNT
+};
+const char* const kStageNames[ST_COUNT] = {
+  "concat", "time_mlp", "encoder.0 conv", "encoder.2 conv", "instnorm coefficients", "rfft (lon)", "legendre analysis",
+  "legendre synthesis", "irfft (lon)", "dhconv", "inner-skip conv", "mlp fused", "mlp fused (dropout)", "mlp fc1", "mlp fc2",
+  "decoder.0 conv", "decoder.2 conv"};
+struct SdyProfiler {
+  bool on = false;
+  struct Rec { int stage; hipEvent_t e0, e1; };
+  std::vector<Rec> recs;
+  std::mutex mu;
+  int begin(int stage, hipStream_t s) {
+    Rec r{stage, nullptr, nullptr};
+    SDY_HIP_TRY(hipEventCreate(&r.e0));
+    SDY_HIP_TRY(hipEventCreate(&r.e1));
+    SDY_HIP_TRY(hipEventRecord(r.e0, s));
+    std::lock_guard<std::mutex> g(mu);
+    recs.push_back(r);
+    return SDY_OK;
+  }
+  int end(hipStream_t s) {
+    std::lock_guard<std::mutex> g(mu);
+    SDY_HIP_TRY(hipEventRecord(recs.back().e1, s));
+    return SDY_OK;
+  }
+} g_prof;
+}  // namespace
+
+#define SDY_STAGE(stage, call)                                   \
+  do {                                                           \
+    if (g_prof.on) SDY_TRY(g_prof.begin((stage), stream));       \
+    SDY_TRY(call);                                               \
+    if (g_prof.on) SDY_TRY(g_prof.end(stream));                  \
+  } while (0)
+
+extern "C" int sdy_profile_enable(int on) {
+  g_prof.on = on != 0;
+  return SDY_OK;
+}
+extern "C" int sdy_profile_stage_count(void) { return ST_COUNT; }
+extern "C" const char* sdy_profile_stage_name(int stage) {
+  return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : "";
+}
+extern "C" int sdy_profile_read(double* total_ms, long* launches, int n) {
+  if (!total_ms || !launches || n < ST_COUNT) return SDY_ERR_ARG;
+  for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+  std::lock_guard<std::mutex> g(g_prof.mu);
+  int rc = SDY_OK;
+  for (auto& r : g_prof.recs) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(r.e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.e0, r.e1);
+    if (e != hipSuccess) rc = (int)e;
+    else { total_ms[r.stage] += ms; launches[r.stage] += 1; }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_prof.recs.clear();
+  return rc;
+}
+
 extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* stream_v) {
   if (!n || !a || !a->out || !a->ws || a->B <= 0) return SDY_ERR_ARG;
   SDY_TRY(sdy_sfno_ready(n));
@@ -917,12 +983,12 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   if (ns == 0 || ctot != Cin) return SDY_ERR_SHAPE;
   const long cat_bs = (long)n->catC * HW;
   float* cat_in = cat + (size_t)(n->catC - Cin) * HW;
-  SDY_TRY(sdy_concat_launch(srcs, chans, ns, cat_in, cat_bs, B, HW, stream));
+  SDY_STAGE(ST_CONCAT, sdy_concat_launch(srcs, chans, ns, cat_in, cat_bs, B, HW, stream));
 
   // ---- time embedding + per-layer (scale|shift) + drop-path scales
   const bool drop = a->enable_dropout != 0;
-  SDY_TRY(sdy_time_mlp_launch(n->tm, a->time, B, trep, ss, dp, a->drop_path_keep, drop ? 1 : 0, a->seed, a->call,
-                              a->batch_offset, stream));
+  SDY_STAGE(ST_TIME_MLP, sdy_time_mlp_launch(n->tm, a->time, B, trep, ss, dp, a->drop_path_keep, drop ? 1 : 0, a->seed,
+                                             a->call, a->batch_offset, stream));
 
   sdy_conv_args cv;
   static const bool no_frag = std::getenv("SDY_NO_CONV_FRAG") != nullptr;
@@ -942,7 +1008,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   conv_reset();
   cv.x = cat_in; cv.x_bstride = cat_bs; use_w(n->e0w); cv.ldw = E; cv.out = xa; cv.out_bstride = (long)E * HW;
   cv.Cin = Cin; cv.Cout = E; cv.bias = n->e0b.p; cv.act = 1;
-  SDY_TRY(sdy_conv1x1(&cv, stream));
+  SDY_STAGE(ST_ENC0, sdy_conv1x1(&cv, stream));
   conv_reset();
   cv.x = xa; cv.x_bstride = (long)E * HW; use_w(n->e2w); cv.ldw = E; cv.out = xb; cv.out_bstride = (long)E * HW;
   cv.Cin = E; cv.Cout = E;
@@ -951,7 +1017,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     static const bool no_stats0 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
     if (cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats0) { cv.stats = st0; have_st0 = true; }
   }
-  SDY_TRY(sdy_conv1x1(&cv, stream));
+  SDY_STAGE(ST_ENC2, sdy_conv1x1(&cv, stream));
 
   float* cur = xb;
   float* nxt = xa;
@@ -969,31 +1035,33 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     const bool lazy_norm = fused_mlp && !scale_residual;
     // norm0 + time scale/shift folded into a*x+d (sfnonet.py:292,298-299)
     if (have_st0)   // statistics were accumulated by the previous block's MLP epilogue: no pass over `cur`
-      SDY_TRY(sdy_instnorm_from_stats(st0, B, E, HW, bw.n0w.p, bw.n0b.p, c.with_time_emb ? ss + (size_t)i * 2 * E : nullptr,
-                                      (long)L * 2 * E, 1e-6f, ca, cd, stream));
+      SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_from_stats(st0, B, E, HW, bw.n0w.p, bw.n0b.p,
+                                                        c.with_time_emb ? ss + (size_t)i * 2 * E : nullptr, (long)L * 2 * E,
+                                                        1e-6f, ca, cd, stream));
     else
-      SDY_TRY(sdy_instnorm_coeffs_launch(cur, B, E, HW, bw.n0w.p, bw.n0b.p, c.with_time_emb ? ss + (size_t)i * 2 * E : nullptr,
-                                         (long)L * 2 * E, 1e-6f, ca, cd, stream));
+      SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_coeffs_launch(cur, B, E, HW, bw.n0w.p, bw.n0b.p,
+                                                           c.with_time_emb ? ss + (size_t)i * 2 * E : nullptr,
+                                                           (long)L * 2 * E, 1e-6f, ca, cd, stream));
     have_st0 = false;
     // SpectralConvS2.forward (s2convolutions.py:158-193)
     const bool polar_in = plan_polar_ok(pin, E), polar_out = plan_polar_ok(pout, E);
-    SDY_TRY(sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, B, E, pin->nlat,
-                               pin->mtr, ilv, polar_in ? pin->d_mcut : nullptr, stream));
-    SDY_TRY(legendre_fwd_impl(pin, Xf, Cs, B, E, polar_in, stream));
+    SDY_STAGE(ST_FFT_FWD, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, B, E,
+                                             pin->nlat, pin->mtr, ilv, polar_in ? pin->d_mcut : nullptr, stream));
+    SDY_STAGE(ST_LEG_FWD, legendre_fwd_impl(pin, Xf, Cs, B, E, polar_in, stream));
     if (scale_residual) {  // residual = inverse_transform(forward_transform(x))
-      SDY_TRY(legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream));
-      SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, ilv,
-                                 polar_out ? pout->d_mcut : nullptr, stream));
+      SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream));
+      SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, ilv,
+                                               polar_out ? pout->d_mcut : nullptr, stream));
     }
     if (bw.fw.frag)
-      SDY_TRY(sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, B, ilv, (hipStream_t)stream));
+      SDY_STAGE(ST_DHCONV, sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, B, ilv, (hipStream_t)stream));
     else if (c.gemm_mode == 1)
-      SDY_TRY(sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
+      SDY_STAGE(ST_DHCONV, sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     else
-      SDY_TRY(sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
-    SDY_TRY(legendre_inv_impl(pout, Cs2, Xf, B, E, polar_out, stream));
-    SDY_TRY(sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, ilv,
-                               polar_out ? pout->d_mcut : nullptr, stream));
+      SDY_STAGE(ST_DHCONV, sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
+    SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs2, Xf, B, E, polar_out, stream));
+    SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, ilv,
+                                             polar_out ? pout->d_mcut : nullptr, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
     conv_reset();
     cv.x = lazy_norm ? cur : xn; cv.x_bstride = lazy_norm ? ((cur == cat) ? cat_bs : (long)E * HW) : (long)E * HW;
@@ -1003,12 +1071,12 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     static const bool no_stats1 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
     const bool stats1 = cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats1;
     if (stats1) cv.stats = st1;
-    SDY_TRY(sdy_conv1x1(&cv, stream));
+    SDY_STAGE(ST_SKIP_CONV, sdy_conv1x1(&cv, stream));
     // norm1 (sfnonet.py:313-320) folded into the fc1 prologue; its statistics come from the convolution's epilogue
     if (stats1)
-      SDY_TRY(sdy_instnorm_from_stats(st1, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+      SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_from_stats(st1, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
     else
-      SDY_TRY(sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+      SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
     // MLP (layers.py:73-80): fc1 + GELU + dropout
     float* dst = (i == L - 1) ? cat : nxt;
     const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;
@@ -1027,13 +1095,13 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       if (drop && n->tm.dp_rate[i] > 0.f) ma.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
       static const bool no_stats = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
       if (i < L - 1 && !no_stats) { ma.stats = st0; have_st0 = true; }   // the next block's norm0 statistics
-      SDY_TRY(sdy_mlp_h3(&ma, stream));
+      SDY_STAGE(pm > 0.f ? ST_MLP_FUSED_DROP : ST_MLP_FUSED, sdy_mlp_h3(&ma, stream));
     } else {
       conv_reset();
       cv.x = y; cv.x_bstride = (long)E * HW; use_w(bw.w1); cv.ldw = Hd; cv.out = hid; cv.out_bstride = (long)Hd * HW;
       cv.Cin = E; cv.Cout = Hd; cv.pa = ca1; cv.pd = cd1; cv.bias = bw.b1.p; cv.act = 1; cv.kernel_tag = 1;
       cv.drop_p = pm; cv.stream_id = 2u * i; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i] : nullptr;
-      SDY_TRY(sdy_conv1x1(&cv, stream));
+      SDY_STAGE(ST_FC1, sdy_conv1x1(&cv, stream));
       // fc2 + dropout, DropPath, + residual (sfnonet.py:325-335)
       conv_reset();
       cv.x = hid; cv.x_bstride = (long)Hd * HW; use_w(bw.w2); cv.ldw = E; cv.out = dst; cv.out_bstride = dst_bs;
@@ -1041,7 +1109,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       cv.drop_p = pm; cv.stream_id = 2u * i + 1u; cv.keep_mask = (pm > 0.f && a->keep_masks) ? a->keep_masks[2 * i + 1] : nullptr;
       if (drop && n->tm.dp_rate[i] > 0.f) cv.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
       cv.add = xn; cv.add_bstride = (long)E * HW; cv.add_mode = 2;
-      SDY_TRY(sdy_conv1x1(&cv, stream));
+      SDY_STAGE(ST_FC2, sdy_conv1x1(&cv, stream));
     }
     cur = dst;
     nxt = (dst == xa) ? xb : xa;
@@ -1052,10 +1120,10 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   conv_reset();
   cv.x = cat; cv.x_bstride = cat_bs; use_w(n->d0w); cv.ldw = E;
   cv.out = dh; cv.out_bstride = (long)E * HW; cv.Cin = n->decC; cv.Cout = E; cv.bias = n->d0b.p; cv.act = 1;
-  SDY_TRY(sdy_conv1x1(&cv, stream));
+  SDY_STAGE(ST_DEC0, sdy_conv1x1(&cv, stream));
   conv_reset();
   cv.x = dh; cv.x_bstride = (long)E * HW; use_w(n->d2w); cv.ldw = n->ldo; cv.out = a->out;
   cv.out_bstride = (long)c.out_chans * HW; cv.Cin = E; cv.Cout = c.out_chans;
-  SDY_TRY(sdy_conv1x1(&cv, stream));
+  SDY_STAGE(ST_DEC2, sdy_conv1x1(&cv, stream));
   return SDY_OK;
 }

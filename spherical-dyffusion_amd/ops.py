@@ -282,3 +282,23 @@ def concat_channels(tensors) -> torch.Tensor:
     with torch.cuda.device(out.device):
         check(lib.sdy_concat_channels(srcs, ch, len(ts), ptr(out), B, H * W, current_stream()), "sdy_concat_channels")
     return out
+
+
+class stage_timer:
+    """Context manager around `sdy_profile_*`: per-stage HIP-event timing of every SFNO forward issued inside the block
+    (events on the launch stream).  `.stages` afterwards: {stage name: (launches, total_ms)}.  Measurement only."""
+
+    def __enter__(self):
+        n = lib.sdy_profile_stage_count()
+        check(lib.sdy_profile_read((C.c_double * n)(), (C.c_long * n)(), n))      # drop stale records
+        check(lib.sdy_profile_enable(1))
+        self.stages = {}
+        return self
+
+    def __exit__(self, *exc):
+        check(lib.sdy_profile_enable(0))
+        n = lib.sdy_profile_stage_count()
+        ms, cnt = (C.c_double * n)(), (C.c_long * n)()
+        check(lib.sdy_profile_read(ms, cnt, n), "sdy_profile_read")
+        self.stages = {lib.sdy_profile_stage_name(i).decode(): (int(cnt[i]), float(ms[i])) for i in range(n) if cnt[i]}
+        return False

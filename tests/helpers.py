@@ -30,13 +30,15 @@ class PhiloxMasks:
     def __init__(self, cfg: SFNOConfig, seed: int, batch_offset: int = 0):
         self.cfg, self.seed, self.batch_offset = cfg, seed, batch_offset
         self.call = 0
+        self.rows = None      # optional: global trajectory index of every batch row (overrides batch_offset + b)
 
     def __call__(self, kind, layer, shape):
         c = self.cfg
         if kind == "drop_path":
-            keep = drop_path_keep(self.seed, self.call, layer, c.drop_path_rates[layer], shape[0], self.batch_offset)
+            keep = drop_path_keep(self.seed, self.call, layer, c.drop_path_rates[layer], shape[0], self.batch_offset,
+                                  self.rows)
             return torch.from_numpy(keep).reshape(-1, 1, 1, 1)
         B, C, H, W = shape
         k = 0 if kind == "mlp_hidden" else 1
         return torch.from_numpy(element_keep_mask(self.seed, self.call, layer, k, c.dropout_mlp, B, C, H, W,
-                                                  self.batch_offset))
+                                                  self.batch_offset, self.rows))

@@ -1,5 +1,8 @@
-"""world_size-2 gloo test of the N>1 path: units are sharded with no data-path collective, the dropout stream of a
-trajectory depends only on its global index, and the bench's max-over-ranks timing reduction works."""
+"""world_size-2 gloo tests of the N>1 path (CPU): the product's own sharding plumbing - `ensemble.shard` ->
+`ensemble.plan_rows` -> `MultiHorizonForecastingDYffusion.set_batch_offset` - gives every (initial condition, member)
+trajectory the same global index on every world size, ranks tile the job exactly with no data-path collective, and the
+bench's max-over-ranks timing reduction works.  (The arithmetic itself needs a GPU: `-m gpu`,
+tests/test_gpu_dyffusion.py::test_sharding_invariance_of_trajectories.)"""
 import os
 import socket
 
@@ -17,39 +20,82 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_units, ret):
+def _tiny_module():
+    import sdy_amd
+
+    kw = dict(spatial_shape_in=(16, 32), embed_dim=8, num_layers=1, with_time_emb=True)
+    fnet = sdy_amd.SphericalFourierNeuralOperatorNet(4, 4, num_conditional_channels=1, **kw)
+    inet = sdy_amd.SphericalFourierNeuralOperatorNet(8, 4, num_conditional_channels=1, dropout_mlp=0.1, drop_path_rate=0.1,
+                                                     **kw)
+    return sdy_amd.MultiHorizonForecastingDYffusion(fnet, sdy_amd.InterpolationExperiment(inet, horizon=6), horizon=6)
+
+
+def _worker(rank, world, port, n_ics, members, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import sdy_amd
     from oracle.philox import drop_path_keep, element_keep_mask
+    from sdy_amd import ensemble
 
-    start, cnt = sdy_amd.ensemble.partition(n_units, world)[rank]
-    # this rank's share of the dropout stream, addressed by GLOBAL trajectory index (batch_offset = start)
-    m = element_keep_mask(seed=99, call=3, layer=1, kind=0, p=0.1, B=cnt, C=8, H=4, W=8, batch_offset=start)
-    dpk = drop_path_keep(seed=99, call=3, layer=2, p=0.3, B=cnt, batch_offset=start)
+    # the product's plumbing, exactly as loop.run_inference / bench.py drive it
+    start, cnt, ic_lo, n_ic = ensemble.shard(n_ics, members, rank, world)
+    s2, c2, ic_rows, mem, rect = ensemble.plan_rows(n_ic, members, first_ic=ic_lo, unit_range=(start, cnt))
+    module = _tiny_module()
+    module.set_batch_offset(s2)
+    offs = (module.model.model.batch_offset, module.model.interpolator.model.batch_offset)
+    units = [(ic_lo + r, m) for r, m in zip(ic_rows, mem)]                    # (global IC, member) of every device row
+    glob = [offs[1] + r for r in range(c2)]                                   # global index the C ABI gives row r
+    # this rank's share of the dropout stream, addressed the way the device addresses it (batch_offset + row)
+    m = element_keep_mask(seed=99, call=3, layer=1, kind=0, p=0.1, B=cnt, C=8, H=4, W=8, batch_offset=offs[1])
+    dpk = drop_path_keep(seed=99, call=3, layer=2, p=0.3, B=cnt, batch_offset=offs[1])
     t = torch.tensor([0.5 + rank], dtype=torch.float64)        # per-rank wall time
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # bench.py: max over ranks
     counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([cnt]))
-    ret[rank] = (start, cnt, m, dpk, float(t), [int(c) for c in counts])
+    ret[rank] = dict(start=start, cnt=cnt, offs=offs, units=units, glob=glob, mask=m, dp=dpk, t=float(t),
+                     counts=[int(c) for c in counts], rect=rect, ics=(ic_lo, n_ic))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_is_invariant():
-    world, n_units = 2, 5
+def _run(world, n_ics, members):
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, n_units, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n_ics, members, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def test_two_rank_member_split_is_invariant():
+    """BASELINE C4 shape in miniature: ONE initial condition, 5 members over 2 ranks -> 3 + 2."""
     from oracle.philox import drop_path_keep, element_keep_mask
 
-    full = element_keep_mask(seed=99, call=3, layer=1, kind=0, p=0.1, B=n_units, C=8, H=4, W=8)
-    full_dp = drop_path_keep(seed=99, call=3, layer=2, p=0.3, B=n_units)
-    got = np.concatenate([ret[r][2] for r in range(world)], axis=0)
-    got_dp = np.concatenate([ret[r][3] for r in range(world)], axis=0)
-    assert np.array_equal(got, full) and np.array_equal(got_dp, full_dp)
-    assert [ret[r][1] for r in range(world)] == [3, 2] and ret[0][5] == [3, 2]
-    assert ret[0][4] == ret[1][4] == 1.5
+    n_ics, members = 1, 5
+    r = _run(2, n_ics, members)
+    assert [x["cnt"] for x in r] == [3, 2] and r[0]["counts"] == [3, 2]
+    assert [x["offs"] for x in r] == [(0, 0), (3, 3)]                          # both networks keyed by the first global unit
+    assert r[0]["units"] + r[1]["units"] == [(0, m) for m in range(members)]
+    assert r[0]["glob"] + r[1]["glob"] == list(range(members))                 # global index = ic * members + member
+    full = element_keep_mask(seed=99, call=3, layer=1, kind=0, p=0.1, B=members, C=8, H=4, W=8)
+    full_dp = drop_path_keep(seed=99, call=3, layer=2, p=0.3, B=members)
+    assert np.array_equal(np.concatenate([x["mask"] for x in r], 0), full)
+    assert np.array_equal(np.concatenate([x["dp"] for x in r], 0), full_dp)
+    assert r[0]["t"] == r[1]["t"] == 1.5
+
+
+def test_two_rank_ragged_ic_member_split():
+    """BASELINE C5 shape in miniature: 3 initial conditions x 3 members over 2 ranks -> 5 + 4, the cut falls inside IC 1."""
+    n_ics, members = 3, 3
+    r = _run(2, n_ics, members)
+    assert [x["cnt"] for x in r] == [5, 4]
+    assert r[0]["ics"] == (0, 2) and r[1]["ics"] == (1, 2)                      # IC 1 is needed by both ranks
+    assert not r[0]["rect"] and not r[1]["rect"]
+    units = r[0]["units"] + r[1]["units"]
+    assert units == [(ic, m) for ic in range(n_ics) for m in range(members)]   # exact tiling, IC-major
+    glob = r[0]["glob"] + r[1]["glob"]
+    assert glob == [ic * members + m for ic, m in units]                       # what ensemble.rank_units promises
+    # the same job on ONE rank numbers every trajectory identically
+    from sdy_amd import ensemble
+    s, c, rows, mem, rect = ensemble.plan_rows(n_ics, members)
+    assert rect and [s + i for i in range(c)] == glob and list(zip(rows, mem)) == units

@@ -141,7 +141,8 @@ def test_stepper_interpolating_prescriber_matches_oracle():
 
 def test_window_driver_batched_members_match_serial_oracle():
     """run_inference with dropout ON: 3 members x 2 samples batched on the device over two windows == the oracle's
-    serial member loop, every trajectory (member m, sample s) drawing the Philox stream of global row m * n_sample + s."""
+    serial member loop, every trajectory (sample s, member m) drawing the Philox stream of its global index
+    s * members + m (ensemble.rank_units), whatever the batch it runs in."""
     import types
 
     import sdy_amd
@@ -179,7 +180,7 @@ def test_window_driver_batched_members_match_serial_oracle():
             state["window"] += 1
         state["last_member"] = m
         oracle._calls["n"] = 10 * state["window"]          # 10 interpolator calls per horizon-6 pass = per window
-        oracle._masks.batch_offset = m * n_sample
+        oracle._masks.rows = [s_ * members + m for s_ in range(n_sample)]      # global index of (IC s_, member m)
         return run_on_batch(data, OMod(), in_names, out_names, forcing_names, tm, ts, n_mem, None, hack=True)
 
     wref, aref = oracle_run(windows, rob, n_total, n_mem, members)
@@ -201,3 +202,93 @@ def test_window_driver_batched_members_match_serial_oracle():
     # members really differ (dropout streams are per trajectory)
     v = got[0][1][out_names[0]]
     assert float((v[0] - v[1]).abs().max()) > 1e-3
+
+
+def _run_sharded(exp, stepper, windows, n_total, n_mem, members, **kw):
+    """One run_inference from a fresh dropout-call counter; returns {global trajectory: (time, H, W) per variable}."""
+    import types
+
+    import sdy_amd
+
+    exp.model.model._call = 0
+    exp.model.interpolator.model._call = 0
+    got = []
+
+    class W:
+        def append_batch(self, target, prediction, start_timestep, start_sample, batch_times=None):
+            got.append((start_sample, {k: v.clone() for k, v in prediction.items()},
+                        {k: tuple(v.shape) for k, v in target.items()}))
+
+    sdy_amd.run_inference(None, stepper, [types.SimpleNamespace(data=w, times=None) for w in windows], n_total, n_mem,
+                          members, writer=W(), **kw)
+    return got
+
+
+def test_sharding_invariance_of_trajectories():
+    """a trajectory's result does not depend on how (initial condition x member) units are sharded.
+    (a) one IC x 5 members on one process == members 0-2 on one shard + members 3-4 on another (`unit_range`, the
+        BASELINE 25-member split); (b) 2 ICs x 2 members on one process == one IC per process (`trajectory_offset`, the
+        reference's IC sharding) == a ragged 3 + 1 split.  Dropout is ON: equality needs every row to draw the stream of
+        its GLOBAL index ic * members + member.  Masks are bit-identical; values agree to fp32 rounding (the InstanceNorm
+        sums are accumulated in an order that depends on the batch size)."""
+    import sdy_amd
+    from sdy_amd import ensemble
+
+    exp, _, cs, n_forc = _build(hack=True, dropout=True)
+    in_names = ["HGTsfc"] + [f"v{i}" for i in range(1, cs)]
+    out_names, forcing_names = in_names[1:], ["f0", "f1"]
+    g = torch.Generator(device="cpu").manual_seed(17)
+    n_mem, n_total = 6, 12
+    means = {n: 0.1 * i for i, n in enumerate(in_names + forcing_names)}
+    stds = {n: 1.0 + 0.1 * i for i, n in enumerate(in_names + forcing_names)}
+    stepper = sdy_amd.MultiStepStepper(exp, in_names + forcing_names, out_names, forcing_names, means, stds, None)
+
+    def series(n_sample):
+        s = {n: torch.randn(n_sample, n_total + 1, 32, 64, generator=g) * stds[n] + means[n]
+             for n in in_names + forcing_names}
+        return [{k: v[:, i * n_mem:(i + 1) * n_mem + 1] for k, v in s.items()} for i in range(n_total // n_mem)]
+
+    def close(a, b, what):
+        e = rel_l2(a, b)
+        assert e < 2e-5, f"{what}: {e:.3e}"
+
+    # ---- (a) members of one IC split 3 + 2
+    wins = series(1)
+    members = 5
+    full = _run_sharded(exp, stepper, wins, n_total, n_mem, members)
+    assert full[0][1][out_names[0]].shape[:2] == (members, 1)
+    for rank in range(2):
+        start, cnt, ic_lo, n_ic = ensemble.shard(1, members, rank, 2)
+        assert (start, cnt, ic_lo, n_ic) == ((0, 3, 0, 1) if rank == 0 else (3, 2, 0, 1))
+        part = _run_sharded(exp, stepper, wins, n_total, n_mem, members, unit_range=(start, cnt))
+        for w in range(len(wins)):
+            assert part[w][0] == start
+            for n in out_names:
+                assert part[w][1][n].shape[0] == cnt
+                close(part[w][1][n], full[w][1][n][start:start + cnt, 0], f"members split, window {w}, {n}, rank {rank}")
+    v = full[0][1][out_names[0]]
+    assert float((v[0] - v[1]).abs().max()) > 1e-3          # members really differ
+
+    # ---- (b) 2 ICs x 2 members: whole, one IC per process, ragged 3 + 1
+    wins = series(2)
+    members = 2
+    full = _run_sharded(exp, stepper, wins, n_total, n_mem, members)
+    for ic in range(2):
+        part = _run_sharded(exp, stepper, [{k: v[ic:ic + 1] for k, v in w.items()} for w in wins], n_total, n_mem,
+                            members, trajectory_offset=ic)
+        for w in range(len(wins)):
+            for n in out_names:
+                assert part[w][1][n].shape[:2] == (members, 1)
+                close(part[w][1][n][:, 0], full[w][1][n][:, ic], f"IC sharding, window {w}, {n}, ic {ic}")
+    for start, cnt in ((0, 3), (3, 1)):
+        part = _run_sharded(exp, stepper, wins, n_total, n_mem, members, unit_range=(start, cnt))
+        for w in range(len(wins)):
+            n_ic_touched = (start + cnt - 1) // members - start // members + 1
+            assert all(s[0] == n_ic_touched for s in part[w][2].values())
+            for n in out_names:
+                for r in range(cnt):
+                    ic, m = divmod(start + r, members)
+                    close(part[w][1][n][r], full[w][1][n][m, ic], f"ragged, window {w}, {n}, unit {start + r}")
+    with pytest.raises(ValueError):      # a shard that needs an IC the window does not hold
+        _run_sharded(exp, stepper, [{k: v[:1] for k, v in w.items()} for w in wins], n_total, n_mem, members,
+                     unit_range=(1, 3))

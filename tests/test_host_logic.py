@@ -263,3 +263,34 @@ def test_persisted_sht_buffers_are_checked(sdy):
     # keys that merely end in .weights elsewhere are still unexpected
     with pytest.raises(RuntimeError):
         net.load_state_dict({**sd, "something.else.weights": torch.zeros(1)}, strict=True)
+
+
+def test_window_stitcher_carries_state_per_trajectory(sdy):
+    """loop.WindowStitcher on the IC-major flat layout: generated variables are carried per trajectory, everything else per
+    initial condition (reference loop.py:85-117), the writer sees the running time index."""
+    from sdy_amd.loop import WindowStitcher
+
+    calls = []
+
+    class W:
+        def append_batch(self, **kw):
+            calls.append((kw["start_timestep"], kw["start_sample"]))
+
+    n_sample, members, T1, H, Wd = 2, 3, 4, 2, 2
+    st = WindowStitcher(n_forward_steps=6, writer=W(), is_ensemble=True)
+    target = {"a": torch.arange(n_sample * T1 * H * Wd, dtype=torch.float32).view(n_sample, T1, H, Wd),
+              "forc": torch.ones(n_sample, T1, H, Wd)}
+    rows = n_sample * members
+    last = {"a": torch.arange(rows, dtype=torch.float32).view(rows, 1, 1).expand(rows, H, Wd) + 100.0}
+    gen = {"a": torch.zeros(members, n_sample, T1, H, Wd)}
+    st.append(target, gen, None, last_state=last)
+    assert calls == [(0, 0)] and st.i_time == T1
+    ic_rows = torch.tensor([0, 0, 0, 1, 1, 1])
+    batch = {"a": torch.zeros(rows, T1, H, Wd), "forc": torch.zeros(rows, T1, H, Wd)}
+    st.apply_initial_condition(batch, ic_rows)
+    assert torch.equal(batch["a"][:, 0, 0, 0], torch.arange(rows, dtype=torch.float32) + 100.0)   # per trajectory
+    assert torch.equal(batch["forc"][:, 0], target["forc"][:, -1].index_select(0, ic_rows))         # per IC
+    st.append({k: v[:, 1:] for k, v in target.items()}, gen, None, last_state=last)
+    assert calls[-1] == (T1, 0) and st.i_time == 2 * T1 - 1
+    with pytest.raises(ValueError):
+        st.apply_initial_condition(batch, ic_rows)
