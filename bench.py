@@ -1,22 +1,38 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: 25-member ensemble DYffusion sampling on the 180x360 grid.
+"""Benchmark of the hot path: 25-member ensemble DYffusion sampling on the 180x360 grid (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak]
+
+works by itself for any N (the parent starts one child process per GPU BEFORE anything touches HIP and relays rank 0's
+JSON line), and also under an external launcher:
+
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one horizon-6 sampling pass (6 forecaster + 10 interpolator SFNO forwards, interpolator dropout stream
-on, cold-sampling updates, autoregressive feedback x0 <- t6) for the 25 ensemble members this rank owns, i.e.
-25 x 6 = 150 member-forecast-steps per rank per step.  Ranks own independent initial conditions (the reference
-shards ICs over ranks: src/ace_inference/core/data_loading/inference.py:110-113); no collective on the data path.
+on, cold-sampling updates, autoregressive feedback x0 <- t6) of the whole job.
 
-Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is measured live with HIP events on the stream the
-kernels run on; `cpu_baseline` times the CPU oracle (same op sequence as the reference's PyTorch path) on the host
-cores on a bounded sample.
+  --scaling strong (default; the BASELINE metric "25-member ensemble at 1/2/4/8 GPU"): ONE initial condition, 25 members
+      split over the ranks by `ensemble.partition` (N = 8: 4,3,3,3,3,3,3,3), every member keyed by its global index
+      (`batch_offset`), 150 member-forecast-steps per step in total.  At N > 1 a weak-scaling leg (25 members of its own
+      initial condition on every rank, the reference's IC sharding: src/ace_inference/core/data_loading/inference.py:110-113)
+      is timed as well and reported under config.weak_scaling.
+  --scaling weak: only that leg; value = N * 150 member-forecast-steps per step.
+There is no collective on the data path; RCCL serves the barriers and the max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Beyond the contract keys:
+  roofline      dominant kernel (`mlp_h3_kernel<true>`, the fused MLP with the Philox dropout of the interpolator), timed
+                IN THE NETWORK with HIP events on the launch stream (sdy_profile_*), plus `kernels`: the same measurement
+                for every stage of the forward with its algorithmic flops / bytes and both roofline fractions.
+  cpu_baseline  the CPU oracle (same torch op sequence as the reference's CPU path) on the host cores, bounded sample.
+  latency       B = 1: one interpolator forward (BASELINE config C2) and one horizon-6 pass (C3).
+  c5_extrapolation  wall time of the 10-year job (4 ICs x 25 members x 14600 steps) at the measured rate.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,13 +46,55 @@ STATE_CH = 63          # BASELINE.json metric: "180x360, 63ch" (nominal; the shi
 FORCING_CH = 2
 NLAT, NLON = 180, 360
 EMBED, LAYERS = 256, 8
+HIDDEN = 2 * EMBED
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: BF16/FP16 MFMA dense peak
-MLP_TRAFFIC_B25 = 5.656e9   # bytes per launch, PMC passes at B = 25 (profiles/r1f/pmc_traffic_mlp.txt)
-PEAK_HBM_GBS = 8000.0           # same guide: HBM3E peak (6.3 TB/s measured with a float4 copy)
+PEAK_HBM_GBS = 8000.0          # same guide: HBM3E peak (6.3 TB/s measured with a float4 copy)
+# HBM bytes per launch of the dominant kernel at B = 25 from separate rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
+# the guide's gfx950 correction); source file under profiles/
+MLP_TRAFFIC_B25 = 5.656e9
+MLP_TRAFFIC_SRC = "profiles/r1f/pmc_traffic_mlp.txt"
+POLAR_LIVE = 0.77              # share of (order, latitude) pairs the polar cut-off keeps
+NZ_PAIRS, ALL_PAIRS = 16290, 32580   # (l, m) pairs with m <= l / dense
 
 
-def build_models(device, rank):
+# ---- self-launch ---------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_children(n: int) -> int:
+    """One child per GPU, started before this process imports torch or touches HIP.  Children inherit stdout (only rank 0
+    prints).  Returns the worst exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            r = p.poll()
+            if r is None:
+                continue
+            pending.remove(p)
+            if r != 0:
+                rc = rc or r
+                for q in pending:       # a rank failed: the others would wait in a barrier forever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ---- models / one step -------------------------------------------------------------------------------------------------
+def build_models(device):
     import torch
 
     import sdy_amd
@@ -50,11 +108,10 @@ def build_models(device, rank):
                       max_time=HORIZON - 1.0)
     with torch.cuda.device(device):
         fnet, fora, _ = make_pair(fcfg, STATE_CH, FORCING_CH, seed=4321)
-        inet, _, _ = make_pair(icfg, 2 * STATE_CH, FORCING_CH, seed=4322, net_seed=1000)
-    inet.batch_offset = rank * MEMBERS          # global trajectory index: results do not depend on the sharding
+        inet, iora, _ = make_pair(icfg, 2 * STATE_CH, FORCING_CH, seed=4322, net_seed=1000)
     exp = sdy_amd.MultiHorizonForecastingDYffusion(fnet, sdy_amd.InterpolationExperiment(inet, horizon=HORIZON),
                                                    horizon=HORIZON)
-    return exp, fora, fcfg
+    return exp, (fora, iora)
 
 
 def one_pass(exp, x0, forcings):
@@ -69,114 +126,197 @@ def one_pass(exp, x0, forcings):
     return out[f"t{HORIZON}_preds_normed"]
 
 
-def roofline_probe(device, B, reps=5):
-    """Dominant kernel, timed with HIP events on the launch stream.
-    gemm_mode h3 (default): the fused MLP kernel `mlp_h3_kernel` (fc1 256->512 + GELU + fc2 512->256 in one launch).
-    gemm_mode f32: the fp32-MFMA fc1 GEMM.  Algorithmic flops / bytes per launch: DESIGN.md 'Kernels'."""
+def synthetic_state(ic_index, B, device):
+    """B members starting from initial condition `ic_index` (fields and forcings N(0, 1): the data are standardised)."""
+    import torch
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + ic_index)
+    x = torch.randn(1, STATE_CH, NLAT, NLON, generator=g).expand(B, -1, -1, -1).contiguous().to(device)
+    f = torch.randn(1, FORCING_CH, NLAT, NLON, generator=g).expand(B, -1, -1, -1).contiguous().to(device)
+    return x, f
+
+
+# ---- roofline ------------------------------------------------------------------------------------------------------------
+def stage_work(B):
+    """Algorithmic work per LAUNCH of every stage of one SFNO forward at batch B: (flops, HBM bytes, bound).
+    Flops are the useful count (m > l zeros skipped, no credit for the three split-f16 passes or the parity fold);
+    bytes are the tensors a launch must read and write once (fp32), weights once per launch."""
+    HW, E, Hd = NLAT * NLON, EMBED, HIDDEN
+    act = 4.0 * E * HW * B                                  # one (B, 256, 180, 360) fp32 tensor
+    xf = POLAR_LIVE * 4.0 * 2 * E * NLAT * NLAT * B         # grid-frequency tensor, m < 180, polar cut-off
+    cs = 4.0 * 2 * E * NZ_PAIRS * B                         # triangular coefficient tensor
+    leg_f = 4.0 * NZ_PAIRS * NLAT * E * B
+    cin_f, cin_i = STATE_CH + FORCING_CH, 2 * STATE_CH + FORCING_CH
+    w = {
+        "mlp fused (dropout)": (4.0 * E * Hd * HW * B, 3 * act, "mfma"),
+        "mlp fused": (4.0 * E * Hd * HW * B, 3 * act, "mfma"),
+        "inner-skip conv": (2.0 * E * E * HW * B, 3 * act, "hbm"),
+        "legendre analysis": (leg_f, xf + cs, "hbm"),
+        "legendre synthesis": (leg_f, xf + cs, "hbm"),
+        "rfft (lon)": (0.0, act + xf, "hbm"),
+        "irfft (lon)": (0.0, act + xf, "hbm"),
+        "dhconv": (8.0 * E * E * NZ_PAIRS * B, 2 * cs + 4.0 * 2 * E * E * NLAT, "hbm"),
+        "encoder.2 conv": (2.0 * E * E * HW * B, 2 * act + 4.0 * E * HW, "hbm"),
+        # the two networks differ in their input width: per-launch average over the 6 + 10 forwards of a pass
+        "encoder.0 conv": (2.0 * E * HW * B * (6 * cin_f + 10 * cin_i) / 16, act + 4.0 * HW * B * (6 * cin_f + 10 * cin_i) / 16,
+                           "hbm"),
+        "decoder.0 conv": (2.0 * E * HW * B * (E + (6 * cin_f + 10 * cin_i) / 16),
+                           2 * act + 4.0 * HW * B * (6 * cin_f + 10 * cin_i) / 16, "hbm"),
+        "decoder.2 conv": (2.0 * E * STATE_CH * HW * B, act + 4.0 * STATE_CH * HW * B, "hbm"),
+    }
+    return w
+
+
+def profile_pass(exp, x, forc, B):
+    """One sampling pass under the stage timer (HIP events on the launch stream around every kernel launch of the 16
+    forwards).  Returns (per-stage list sorted by time, total kernel ms)."""
     import torch
 
     import sdy_amd
 
-    HW, hid = NLAT * NLON, 2 * EMBED
-    x = torch.randn(B, EMBED, NLAT, NLON, device=device)
-    w = torch.randn(hid, EMBED, device=device) / 16.0
-    bias = torch.randn(hid, device=device) * 0.1
-    pa = torch.rand(B, EMBED, device=device) + 0.5
-    pd = torch.randn(B, EMBED, device=device) * 0.1
-    h3 = os.environ.get("SDY_GEMM_MODE", "h3") == "h3"
-    if h3:
-        w2 = torch.randn(EMBED, hid, device=device) / 22.0
-        b2 = torch.randn(EMBED, device=device) * 0.1
-        res = torch.randn(B, EMBED, NLAT, NLON, device=device)
-        out = torch.empty_like(x)
-        prep = sdy_amd.ops.pack_mlp_h3(w, w2, device)
-        run = lambda: sdy_amd.ops.mlp_fused(x, w, bias, w2, b2, pre_affine=(pa, pd), add=res, out=out, prepared=prep)
-    else:
-        wt = w.t().contiguous()
-        out = torch.empty(B, hid, NLAT, NLON, device=device)
-        kw = dict(pre_affine=(pa, pd), gelu=True, kernel_tag=1, out=out, wt_prepared=wt)
-        run = lambda: sdy_amd.ops.conv1x1(x, w, bias, **kw)
-    run()
-    torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize(device)
-    ms = e0.elapsed_time(e1) / reps
-    if not h3:
-        flops = 2.0 * EMBED * hid * HW * B
-        achieved = flops / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "gemm_f32_kernel<2,2,false,false,1>, MLP fc1 256->512, B=%d" % B,
-                "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
-    # Fused MLP: algorithmic flops 2 * 2*E*hid per pixel, algorithmic bytes 3 tensors of B*E*HW fp32 (x, residual, out):
-    # 170 flop/B.  Split precision issues 3 f16 MFMA passes, so the machine balance is (2500/3 TF) / 8 TB/s = 104 flop/B:
-    # the kernel is matrix-bound.  `achieved` counts the algorithmic flops ONCE against the dense f16 peak (the 3-pass
-    # ceiling is peak / 3).  `traffic`: FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 PMC passes at B = 25
-    # (profiles/r1f/pmc_traffic_mlp.txt).
-    flops = 4.0 * EMBED * hid * HW * B
-    alg_bytes = 3.0 * B * EMBED * HW * 4
-    achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": MLP_TRAFFIC_B25 if B == 25 else None,
-            "kernel": "mlp_h3_kernel<false> (fused MLP 256->512->256, 3-pass split-f16 MFMA), B=%d" % B,
-            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
-            "three_pass_ceiling_frac": round(3.0 * achieved / PEAK_F16_MFMA_TFLOPS, 4),
-            "hbm_view": {"achieved_gbs": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak_gbs": PEAK_HBM_GBS}}
+    torch.cuda.synchronize()
+    with sdy_amd.ops.stage_timer() as t:
+        one_pass(exp, x, forc)
+        torch.cuda.synchronize()
+    work = stage_work(B)
+    total = sum(ms for _, ms in t.stages.values())
+    rows = []
+    for name, (cnt, ms) in sorted(t.stages.items(), key=lambda kv: -kv[1][1]):
+        avg = ms / cnt
+        fl, by, bound = work.get(name, (0.0, 0.0, "hbm"))
+        rows.append({"name": name, "launches_per_step": cnt, "ms": round(avg, 4), "share": round(ms / total, 4),
+                     "gflop": round(fl / 1e9, 2), "gbytes": round(by / 1e9, 3), "bound": bound,
+                     "frac_mfma": round(fl / (avg * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4) if fl else None,
+                     "frac_hbm": round(by / (avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if by else None})
+    return rows, total
 
 
-def cpu_baseline(fora, fcfg):
-    """CPU oracle (same torch op sequence as the reference's CPU PyTorch path) on the host cores: ONE forecaster forward at
-    B=1, scaled by 16 forwards per 6 forecast steps."""
+def roofline_from(rows, total_ms, B, h3):
+    dom = next((r for r in rows if r["name"] == "mlp fused (dropout)"), rows[0])
+    fl, by = dom["gflop"] * 1e9, dom["gbytes"] * 1e9
+    ms = dom["ms"]
+    hbm_ms = sum(r["ms"] * r["launches_per_step"] for r in rows if r["bound"] == "hbm")
+    hbm_bytes = sum(r["gbytes"] * 1e9 * r["launches_per_step"] for r in rows if r["bound"] == "hbm")
+    peak = PEAK_F16_MFMA_TFLOPS if h3 else PEAK_F32_MFMA_TFLOPS
+    achieved = fl / (ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "traffic": MLP_TRAFFIC_B25 if B == 25 else None, "traffic_source": MLP_TRAFFIC_SRC if B == 25 else None,
+        "kernel": "mlp_h3_kernel<true> = stage '%s' (fused MLP 256->512->256 + GELU + Philox dropout + residual, 3-pass "
+                  "split-f16 MFMA), B=%d, timed in the network" % (dom["name"], B),
+        "ms_per_launch": ms, "launches_per_step": dom["launches_per_step"],
+        "flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+        "three_pass_ceiling_frac": round(3.0 * achieved / peak, 4) if h3 else None,
+        "timing": "HIP events on the launch stream around every launch of one sampling pass (sdy_profile_*)",
+        "kernel_ms_per_step": round(total_ms, 2),
+        "hbm_bound_kernels": {"share_of_step": round(hbm_ms / total_ms, 4),
+                              "achieved_gbs": round(hbm_bytes / (hbm_ms * 1e-3) / 1e9, 1), "peak_gbs": PEAK_HBM_GBS,
+                              "frac": round(hbm_bytes / (hbm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+        "kernels": rows,
+    }
+
+
+# ---- extras ----------------------------------------------------------------------------------------------------------------
+def latency_b1(exp, device):
+    """BASELINE C2: one interpolator forward at B = 1 (dropout stream on); C3: one horizon-6 sampling pass at B = 1."""
     import torch
 
+    x, f = synthetic_state(0, 1, device)
+    ip = exp.model.interpolator
+    inp = torch.cat([x, x], dim=1)
+    t = torch.full((1,), 3.0, device=device)
+
+    def fwd():
+        with ip.inference_dropout_scope(condition=True):
+            return ip.predict_packed(inp, time=t, static_condition=f)["preds"]
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    c2 = timed(fwd, 10)
+    c3 = timed(lambda: one_pass(exp, x, f), 3)
+    return {"c2_interpolator_forward_b1_ms": round(c2, 3), "c3_horizon6_pass_b1_ms": round(c3, 2),
+            "c3_forecast_steps_per_s_b1": round(HORIZON / (c3 * 1e-3), 2)}
+
+
+def cpu_baseline(oracles, threads):
+    """CPU oracle (same torch op sequence as the reference's CPU PyTorch path) on the host cores: one forecaster and one
+    interpolator forward at B = 1 (about 20-30 s of CPU work), scaled to a horizon-6 pass = 6 + 10 forwards."""
+    import torch
+
+    fora, iora = oracles
+    torch.set_num_threads(threads)
     g = torch.Generator(device="cpu").manual_seed(1234)
     x = torch.randn(1, STATE_CH, NLAT, NLON, generator=g)
     c = torch.randn(1, FORCING_CH, NLAT, NLON, generator=g)
-    t = torch.tensor([2.0])
     t0 = time.perf_counter()
-    fora(x, time=t, condition=c)
-    dt = time.perf_counter() - t0
-    steps_per_s = HORIZON / (16.0 * dt)
-    return {"value": round(steps_per_s, 5), "unit": "member-forecast-steps/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": "1 oracle SFNO forward (B=1, 180x360, E=256, 8 layers, fp32): %.2f s; "
-            "16 forwards per 6 forecast steps" % dt}
+    fora(x, time=torch.tensor([2.0]), condition=c)
+    tf = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    iora(torch.cat([x, x], 1), time=torch.tensor([3.0]), condition=c)
+    ti = time.perf_counter() - t0
+    steps_per_s = HORIZON / (6 * tf + 10 * ti)
+    return {"value": round(steps_per_s, 5), "unit": "member-forecast-steps/s", "cores": threads, "kind": "port",
+            "sample": "oracle SFNO forwards at B=1 (180x360, E=256, 8 layers, fp32, torch.set_num_threads(%d) of %d "
+                      "host CPUs): forecaster %.2f s, interpolator %.2f s; a horizon-6 pass = 6 + 10 forwards"
+                      % (threads, os.cpu_count() or 0, tf, ti)}
 
 
+# ---- main ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--members", type=int, default=MEMBERS, help="ensemble members per GPU (default 25)")
+    ap.add_argument("--steps", type=int, default=10,
+                    help="timed sampling passes (6 forecast steps each); use >= 100 (600 steps) for a C5-style long run")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--members", type=int, default=MEMBERS, help="ensemble members of the job (strong) / per GPU (weak)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(32, host CPUs))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stage profile, B=1 latencies and the weak leg")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: all ranks on GPU 0 with the gloo backend (exercises the N>1 path on a 1-GPU box; "
+                         "the numbers mean nothing)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Stand-alone multi-GPU run: become the launcher.  Nothing in this process has touched HIP (torch is not even
+        # imported), and the children are fresh processes, not re-executions of this one.
+        sys.exit(launch_children(args.gpus))
 
     import torch
     import torch.distributed as dist
 
+    import sdy_amd
+    from sdy_amd import ensemble
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE={world})")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or run "
+                         f"`python bench.py --gpus {args.gpus}` without a launcher")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+    red_dev = torch.device("cpu") if args.share_gpu else device
 
-    B = args.members
-    exp, fora, fcfg = build_models(device, rank)
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)      # one initial condition per rank
-    x_ic = torch.randn(1, STATE_CH, NLAT, NLON, generator=g)
-    x0 = x_ic.expand(B, -1, -1, -1).contiguous().to(device)          # 25 members start from the same IC
-    forc = torch.randn(1, FORCING_CH, NLAT, NLON, generator=g).expand(B, -1, -1, -1).contiguous().to(device)
+    exp, oracles = build_models(device)
+    h3 = sdy_amd._lib.default_gemm_mode() == "h3"
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -184,48 +324,91 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    x = x0
-    for _ in range(args.warmup):
-        x = one_pass(exp, x, forc)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        x = one_pass(exp, x, forc)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert torch.isfinite(x).all(), "non-finite state after the rollout"
+    def timed_leg(ic_index, first_unit, B):
+        """W warm-up + K timed sampling passes of this rank's B trajectories; returns the max-over-ranks seconds."""
+        exp.set_batch_offset(first_unit)
+        if B > 0:
+            x, forc = synthetic_state(ic_index, B, device)
+        for _ in range(args.warmup):
+            if B > 0:
+                x = one_pass(exp, x, forc)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if B > 0:
+                x = one_pass(exp, x, forc)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        if B > 0:
+            assert torch.isfinite(x).all(), "non-finite state after the rollout"
+        return dt
+
+    M = args.members
+    parts = ensemble.partition(M, world)                   # strong: members of ONE initial condition over the ranks
+    legs = {}
+    if args.scaling == "strong":
+        start, cnt = parts[rank]
+        legs["strong"] = (timed_leg(0, start, cnt), M)
+        if world > 1 and not args.no_extras:
+            legs["weak"] = (timed_leg(rank, rank * M, M), world * M)
+    else:
+        legs["weak"] = (timed_leg(rank, rank * M, M), world * M)
+    dt, n_traj = legs[args.scaling]
+    value = n_traj * HORIZON * args.steps / dt
 
     if rank == 0:
-        total_steps = world * B * HORIZON * args.steps
+        B0 = parts[0][1] if args.scaling == "strong" else M
         res = {
             "metric": "forecast-steps/sec (180x360, 63ch), 25-member ensemble DYffusion sampling, whole job",
-            "value": round(total_steps / dt, 3),
+            "value": round(value, 3),
             "unit": "member-forecast-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32 (1x1-conv GEMMs as 3-pass split-f16 MFMA with f32 accumulation)" if os.environ.get("SDY_GEMM_MODE", "h3") == "h3" else "f32",
-            "data": "synthetic",
+            "dtype": ("f32 tensors; every GEMM-class kernel (1x1 convs, fused MLP, Legendre analysis/synthesis, dhconv) as "
+                      "3-pass split-f16 MFMA with f32 accumulation; FFT / norms / pointwise in f32 (statistics f64)")
+            if h3 else "f32 (fp32-input MFMA)",
+            "data": "synthetic" + (" (TEST MODE --share-gpu: all ranks on one GPU, numbers meaningless)"
+                                   if args.share_gpu else ""),
             "config": {
-                "workload": "25-member ensemble x horizon-6 DYffusion sampling pass (6 forecaster + 10 interpolator SFNO "
-                            "forwards, dropout stream on, AR feedback), 180x360, %d state + %d forcing channels, "
-                            "embed 256, 8 blocks; one initial condition per GPU" % (STATE_CH, FORCING_CH),
-                "members_per_gpu": B, "horizon": HORIZON, "forwards_per_step": 16,
-                "per_gpu_forecast_steps_per_s": round(total_steps / dt / world, 3),
-                "parallelism": "ICs sharded over GPUs, no data-path collective",
+                "workload": "%d-member ensemble x horizon-6 DYffusion sampling pass (6 forecaster + 10 interpolator SFNO "
+                            "forwards, dropout stream on, AR feedback), 180x360, %d state + %d forcing channels, embed 256, "
+                            "8 blocks" % (M, STATE_CH, FORCING_CH),
+                "horizon": HORIZON, "forwards_per_step": 16,
+                "members_per_gpu": [c for _, c in parts] if args.scaling == "strong" else [M] * world,
+                "forecast_steps_per_step": n_traj * HORIZON,
+                "per_gpu_forecast_steps_per_s": round(value / world, 3),
+                "ensemble_steps_per_s": round(value / n_traj, 4),
+                "parallelism": ("members of one initial condition sharded over GPUs" if args.scaling == "strong" else
+                                "one initial condition (x %d members) per GPU" % M) + ", no data-path collective",
             },
         }
-        res["roofline"] = roofline_probe(device, B)
+        if "weak" in legs and args.scaling == "strong":
+            wdt, wn = legs["weak"]
+            res["config"]["weak_scaling"] = {"value": round(wn * HORIZON * args.steps / wdt, 3),
+                                             "ms_per_step": round(wdt / args.steps * 1e3, 2), "members_per_gpu": M,
+                                             "note": "one initial condition x %d members per GPU" % M}
+        # C5 (10 years = 14600 steps, 4 ICs x 25 members) at the measured whole-job rate
+        res["c5_extrapolation"] = {"trajectories": 100, "steps": 14600, "measured_steps": HORIZON * args.steps,
+                                   "hours_at_this_rate": round(100 * 14600 / value / 3600.0, 2), "n_gpus": world,
+                                   "note": "extrapolated from the measured rate; run --steps >= 100 for a 600-step sample"}
+        if not args.no_extras:
+            x, forc = synthetic_state(0, B0, device)
+            exp.set_batch_offset(0)
+            rows, total = profile_pass(exp, x, forc, B0)
+            res["roofline"] = roofline_from(rows, total, B0, h3)
+            if world == 1:
+                res["latency"] = latency_b1(exp, device)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(fora, fcfg)
+            res["cpu_baseline"] = cpu_baseline(oracles, args.cpu_threads or min(32, os.cpu_count() or 1))
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
