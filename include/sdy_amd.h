@@ -329,6 +329,19 @@ int sdy_ensemble_metrics(const float* pred, const float* truth, const float* wei
                          int n_planes, int HW, double* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Sticky status word of the CURRENT device.  Kernels only ever set bits; the host reads (and optionally clears) it once per
+ * window, not per launch (MultiStepStepper.run_on_batch does, after the window's single loss read-back).
+ *   SDY_FLAG_NONFINITE  an InstanceNorm statistic (sum or sum of squares over H x W) came out inf / NaN: the tensor feeding
+ *                       that norm holds non-finite values.
+ *   SDY_FLAG_F16_RANGE  a split-precision ("h3") kernel was handed an activation with |value * scale| >= 65504, the fp16
+ *                       range of its hi part (scale is 16 for the convolutions and the MLP): the products turn into inf / NaN.
+ *                       The fp32-MFMA mode (gemm_mode 0, SDY_GEMM_MODE=f32) has no such limit.
+ * sdy_status_flags synchronises `stream` before reading. */
+#define SDY_FLAG_NONFINITE 1u
+#define SDY_FLAG_F16_RANGE 2u
+int sdy_status_flags(unsigned* flags, int reset, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Measurement.  While enabled, every kernel launch of sdy_sfno_forward is bracketed by a pair of
  * hipEvents recorded ON THE LAUNCH STREAM, tagged with its stage (fused MLP with / without dropout, inner-skip conv,
  * Legendre analysis / synthesis, rfft, irfft, dhconv, encoder / decoder convs, ...).  sdy_profile_read synchronises

@@ -173,6 +173,7 @@ SIGNATURES = {
     "sdy_cold_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdy_concat_channels": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p]),
+    "sdy_status_flags": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
     "sdy_profile_enable": (C.c_int, [C.c_int]),
     "sdy_profile_stage_count": (C.c_int, []),
     "sdy_profile_stage_name": (C.c_char_p, [C.c_int]),

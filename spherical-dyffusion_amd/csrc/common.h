@@ -38,6 +38,8 @@ inline int sdy_cu_count(int* n_cu) {                 // compute units of the CUR
   *n_cu = cache[dev];
   return SDY_OK;
 }
+// Device address of the current device's sticky status word (allocated and zeroed on first use; pointwise.hip).
+int sdy_flags_ptr(unsigned** flags);
 struct SdyOncePerDevice {                            // `static SdyOncePerDevice once;` next to a kernel's attribute setup
   bool done[SDY_MAX_DEVICES] = {};
   int slot(bool** flag) {
@@ -64,6 +66,19 @@ __device__ __forceinline__ void sdy_split8(const float* v, sdy_f16x8& hi, sdy_f1
     hi[e] = h[0]; hi[e + 1] = h[1];
     lo[e] = l[0]; lo[e + 1] = l[1];
   }
+}
+// The same, also tracking max |v| of everything a thread splits: fp16 overflows at 65504, and an overflowed `hi` turns into
+// inf / NaN products silently.  Kernels end with sdy_flag_range(flags, amax) (one v_max3_f32 per two values here; NaNs are
+// ignored by the max and are caught by the InstanceNorm statistics instead).
+__device__ __forceinline__ void sdy_split8(const float* v, sdy_f16x8& hi, sdy_f16x8& lo, float& amax) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+  sdy_split8(v, hi, lo);
+}
+// Sticky status word of a device (include/sdy_amd.h, sdy_status_flags): bits are only ever set by kernels.
+#define SDY_F16_LIMIT 65504.0f
+__device__ __forceinline__ void sdy_flag_range(unsigned* flags, float amax) {
+  if (flags && amax >= SDY_F16_LIMIT) atomicOr(flags, (unsigned)SDY_FLAG_F16_RANGE);
 }
 // 16-byte store of a streaming output (written once, read by a later kernel after 1.6 GB of other traffic)
 #ifdef SDY_NT_STORE

@@ -56,6 +56,7 @@ struct ConvParams {
   int HW, B;
   int Cin;                         // input channels (<= 256; the weight stream is zero-padded to KBLK * 64)
   float out_scale;
+  unsigned* flags;                 // sticky status word (sdy_status_flags)
   unsigned long long* stamps;    // timing experiments only (SDY_CONV_STAMPS)
 };
 
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
 
     // ---- phase 0: x tile (already in registers) -> LDS (fp16 hi / lo, [px][k]); thread = (pixel quad q0, octets o0 + CRS oc)
     {
+      float amax = 0.0f;   // range guard of the fp16 split, flagged per tile (no register lives across the MFMA loop)
       const bool ok = full || (n0 + 4 * q0 < p.HW);
 #pragma unroll
       for (int oc = 0; oc < COC; ++oc) {
@@ -170,12 +172,13 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (ok && c0 + e < p.Cin) ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
-          sdy_split8(v, vh, vl);
+          sdy_split8(v, vh, vl, amax);
           const int off = cv_off(4 * q0 + pp, o0 + CRS * oc);
           *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
           *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
         }
       }
+      sdy_flag_range(p.flags, amax);
     }
     __syncthreads();
     stamp(1);
@@ -360,6 +363,7 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   p.act = a->act;
   p.out = a->out; p.out_bs = a->out_bstride;
   p.stats = a->stats;
+  SDY_TRY(sdy_flags_ptr(&p.flags));
   p.HW = a->HW; p.B = a->B; p.Cin = a->Cin;
   p.out_scale = 1.0f / (a->w_frag_scale * CSX);
   p.stamps = nullptr;

@@ -49,6 +49,7 @@ struct DhParams {
   int L, mtr, B;
   int ilv;                         // order of the 2C axis: 0 = [ri][c], 1 = [c / 16][ri][16] (fft.h)
   float out_scale;
+  unsigned* flags;                 // sticky status word (sdy_status_flags)
   unsigned long long* stamps;      // timing experiments only (SDY_DH_STAMPS)
 };
 
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
     const TileIt pre = more ? nxt : cur;   // past the end: a harmless re-read
 
     // ---- phase 0: the tile (already in registers) -> LDS, fp16 hi / lo, [row][k]
+    float amax = 0.0f;   // range guard of the fp16 split, flagged per tile (no register lives across the MFMA loop)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = r0 + 8 * i;
@@ -141,11 +143,12 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = xr[i][e >> 2][e & 3] * sc;
-      sdy_split8(v, vh, vl);
+      sdy_split8(v, vh, vl, amax);
       const int off = dh_off(r, oc);
       *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
       *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
     }
+    sdy_flag_range(p.flags, amax);
     stamp(1);
     __syncthreads();
     stamp(2);
@@ -323,6 +326,7 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
   p.w = reinterpret_cast<const f16x8*>(packed);
   p.L = L; p.mtr = mtr; p.B = B; p.ilv = ilv ? 1 : 0;
   p.out_scale = 1.0f / (scale * DSX);
+  SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;
   if (std::getenv("SDY_DH_STAMPS")) {
     if (!g_dstamps) SDY_HIP_TRY(hipMalloc(&g_dstamps, 256 * sizeof(unsigned long long)));

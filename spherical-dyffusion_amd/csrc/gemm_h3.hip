@@ -43,6 +43,7 @@ struct H3Packed {
   const _Float16* lo;
   int rows_pad, Kpad;
   long bstride;         // halfs between batches (0 = shared)
+  unsigned* flags;      // sticky status word (sdy_status_flags): fp16 range guard of the activation split
 };
 
 __device__ __forceinline__ void split4(const f32x4 v, f16x4& vh, f16x4& vl) {
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  float amax = 0.0f;   // largest |scaled activation| this thread split into fp16 (range guard)
   struct Stage {
     f32x4 rp_hi[NP], rp_lo[NP];                  // raw 16-byte chunks of the pre-split operand
     f32x4 rb[MODE == MODE_COLS ? NBLK : 1][4];   // MODE_COLS: 4 k x 4 n
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, con
 #pragma unroll
           for (int pp = 0; pp < 4; ++pp) {
             const float v = fmaf(S.rb[bi][kk][pp], a, d);
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
             const _Float16 hv = (_Float16)v;
             hi[kk][pp] = hv;
             lo[kk][pp] = (_Float16)(v - (float)hv);
@@ -236,7 +239,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, con
         const int idx = tid + i * 256;
         const int row = idx / HKQ, q = idx % HKQ;
         f16x4 vh, vl;
-        split4(S.rr[i] * sx, vh, vl);
+        const f32x4 sv = S.rr[i] * sx;
+        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(sv.x), __builtin_fabsf(sv.y)),
+                                                     __builtin_fmaxf(__builtin_fabsf(sv.z), __builtin_fabsf(sv.w))));
+        split4(sv, vh, vl);
         *reinterpret_cast<f16x4*>(Fs_hi + row * HLD + q * 4) = vh;
         *reinterpret_cast<f16x4*>(Fs_lo + row * HLD + q * 4) = vl;
       }
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, con
   } else {
     run(F_{}, F_{});
   }
+  sdy_flag_range(pk.flags, amax);
 
   gemm_epilogue<WM, WN>(acc, p, z, m0, n0, M_valid, out_scale);
 }
@@ -364,6 +371,7 @@ __global__ __launch_bounds__(512) void gemm_h3_wide_kernel(const GemmParams p, c
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float amax = 0.0f;   // largest |scaled activation| this thread split into fp16 (range guard)
 
   f32x4 rp_hi[4], rp_lo[4];
   f32x4 rb[4];
@@ -415,6 +423,7 @@ __global__ __launch_bounds__(512) void gemm_h3_wide_kernel(const GemmParams p, c
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) {
         const float v = fmaf(rb[kk][pp], a, d);
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
         const _Float16 hv = (_Float16)v;
         hi[kk][pp] = hv;
         lo[kk][pp] = (_Float16)(v - (float)hv);
@@ -465,6 +474,7 @@ __global__ __launch_bounds__(512) void gemm_h3_wide_kernel(const GemmParams p, c
     }
     __syncthreads();
   }
+  sdy_flag_range(pk.flags, amax);
   if (!wave_dead) gemm_epilogue_at<WM, WN>(acc, p, z, m0 + wr * 64, n0 + wc * 64, p.M_store, out_scale);
 }
 
@@ -501,6 +511,7 @@ int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, in
   pk.rows_pad = rows_pad;
   pk.Kpad = Kpad;
   pk.bstride = bstride;
+  SDY_TRY(sdy_flags_ptr(&pk.flags));
   const float sx = 16.0f;                       // keeps the lo parts of O(1) activations out of the fp16 subnormals
   const float out_scale = 1.0f / (w_scale * sx);
   if (rows_mode) {

@@ -36,6 +36,7 @@ struct LegParams {
   int M_store, K, N;
   int tri;                       // SDY_TRI_LEG_FWD / SDY_TRI_LEG_INV
   float out_scale;
+  unsigned* flags;               // sticky status word (sdy_status_flags)
 };
 
 // 384-byte rows: the 16-byte slot of (px, chunk c) in the 256-byte bank row is (8 * (px & 1) + c) mod 16.  XOR-ing the low
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(192, 3) void leg_h3_kernel(const LegParams p) {
 
   // ---- phase 0: activation tile -> LDS (fp16 hi / lo, [n][k]); thread = (column quad q, octets o and o + 12)
   {
+    float amax = 0.0f;   // range guard of the fp16 split
     const int q = tid & 15, o = tid >> 4;
     const bool ok = full || (n0 + 4 * q < p.N);
     const float* __restrict__ xg = p.X + (long)z * p.sX + (ok ? n0 + 4 * q : 0);
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(192, 3) void leg_h3_kernel(const LegParams p) {
         for (int e = 0; e < 8; ++e) {
           const int k = 8 * c + e;
           const float v = (ok && k < p.K && k >= k_lo) ? xr[oc][e][pp] * LSX : 0.0f;
+          amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
           const _Float16 hv = (_Float16)v;
           vh[e] = hv;
           vl[e] = (_Float16)(v - (float)hv);
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(192, 3) void leg_h3_kernel(const LegParams p) {
         *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
       }
     }
+    sdy_flag_range(p.flags, amax);
   }
   __syncthreads();
 
@@ -231,6 +235,7 @@ int sdy_leg_h3_launch(const void* table, float scale, int nz, const float* X, lo
   p.C = C; p.ldc = ldc; p.sC = sC;
   p.M_store = M_store; p.K = K; p.N = N; p.tri = tri;
   p.out_scale = 1.0f / (scale * LSX);
+  SDY_TRY(sdy_flags_ptr(&p.flags));
   dim3 grid((N + LTN - 1) / LTN, nz);
   hipLaunchKernelGGL(leg_h3_kernel, grid, dim3(192), 0, stream, p);
   return sdy_launch_status();

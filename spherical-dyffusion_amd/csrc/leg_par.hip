@@ -43,6 +43,7 @@ struct ParParams {
   int fwd;                       // 1 analysis, 0 synthesis
   const int* kdead;              // polar cut-off per order (rows k' < kdead[m] and their mirrors are skipped) or nullptr
   float out_scale;
+  unsigned* flags;               // sticky status word (sdy_status_flags)
 };
 
 // same swizzle as leg_h3.hip: 16-byte chunk c (0..23) of column px
@@ -78,6 +79,8 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
   }
 
   // ---- phase 0: input rows -> LDS halves; thread = (column quad q, octet o of the half: positions 8 o .. 8 o + 7)
+  // (No fp16 range guard here: at 168 registers for three workgroups per CU the tracker spills.  The inputs are the FFT of a
+  //  normalised field / the output of the guarded dhconv; an overflow would still surface as non-finite statistics.)
   {
     const int q = tid & 15, o = tid >> 4;
     const bool ok = full || (n0 + 4 * q < p.N);
@@ -273,6 +276,7 @@ int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, l
   p.C = C; p.ldc = ldc; p.sC = sC;
   p.rows_out = rows_out; p.K = K; p.N = N; p.fwd = fwd; p.kdead = kdead;
   p.out_scale = 1.0f / (scale * PSX);
+  SDY_TRY(sdy_flags_ptr(&p.flags));
   dim3 grid((N + PTN - 1) / PTN, nz);
   hipLaunchKernelGGL(leg_par_kernel, grid, dim3(192), 0, stream, p);
   return sdy_launch_status();

@@ -66,6 +66,7 @@ struct MlpParams {
   uint32_t seed_lo, seed_hi, stream1, stream2, call, batch_offset;
   const float* batch_scale;
   double* stats;                           // optional [B][ME][2]: sum and sum of squares of the stored output rows
+  unsigned* flags;                         // sticky status word (sdy_status_flags)
   unsigned long long* stamps;              // timing experiments only (SDY_MLP_STAMPS): per-phase s_memtime of one wave
 };
 
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 
   // ---- phase 0: x tile (already in registers) -> LDS (fp16 hi / lo, [px][k])
   {
+    float amax = 0.0f;   // range guard of the fp16 split (flagged per tile: no register lives across the tile loop)
     const bool ok = full || (n0 + 4 * q0 < p.HW);
 #pragma unroll
     for (int oc = 0; oc < 2; ++oc) {
@@ -181,12 +183,13 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = ok ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
-        sdy_split8(v, vh, vl);
+        sdy_split8(v, vh, vl, amax);
         const int off = xs_off(px, o0 + 16 * oc);
         *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
         *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
       }
     }
+    sdy_flag_range(p.flags, amax);
   }
   __syncthreads();
 
@@ -660,6 +663,7 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   p.stream1 = a->stream_fc1; p.stream2 = a->stream_fc2; p.call = a->call; p.batch_offset = a->batch_offset;
   p.batch_scale = a->batch_scale;
   p.stats = a->stats;
+  SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;
   if (std::getenv("SDY_MLP_STAMPS")) {
     if (!g_stamps) SDY_HIP_TRY(hipMalloc(&g_stamps, 64 * sizeof(unsigned long long)));

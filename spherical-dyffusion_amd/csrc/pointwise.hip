@@ -1,4 +1,5 @@
 // HBM-bound pointwise / reduction kernels of the SFNO block and the DYffusion sampler, gfx950.
+#include <mutex>
 #include "common.h"
 #include "pointwise.h"
 
@@ -12,7 +13,8 @@ __global__ __launch_bounds__(256) void instnorm_coeffs_kernel(const float* __res
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ ss, long ss_stride, float eps,
-                                                               float* __restrict__ a_out, float* __restrict__ d_out) {
+                                                               float* __restrict__ a_out, float* __restrict__ d_out,
+                                                               unsigned* __restrict__ flags) {
   const int c = blockIdx.x, b = blockIdx.y;
   const float* px = x + ((long)b * C + c) * HW;
   double s = 0.0, s2 = 0.0;
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(256) void instnorm_coeffs_kernel(const float* __res
   if (threadIdx.x == 0) {
     const double S = sh[0] + sh[1] + sh[2] + sh[3];
     const double S2 = sh[4] + sh[5] + sh[6] + sh[7];
+    if (flags && !(fabs(S) <= 1.7e308 && S2 <= 1.7e308)) atomicOr(flags, (unsigned)SDY_FLAG_NONFINITE);   // inf or NaN
     const double mean = S / HW;
     double var = S2 / HW - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -65,13 +68,15 @@ __global__ __launch_bounds__(256) void instnorm_from_stats_kernel(double* __rest
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
                                                                    const float* __restrict__ ss, long ss_stride, float eps,
-                                                                   float* __restrict__ a_out, float* __restrict__ d_out) {
+                                                                   float* __restrict__ a_out, float* __restrict__ d_out,
+                                                                   unsigned* __restrict__ flags) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= BC) return;
   const int b = i / C, c = i - b * C;
   const double S = stats[2 * (long)i], S2 = stats[2 * (long)i + 1];
   stats[2 * (long)i] = 0.0;
   stats[2 * (long)i + 1] = 0.0;
+  if (flags && !(fabs(S) <= 1.7e308 && S2 <= 1.7e308)) atomicOr(flags, (unsigned)SDY_FLAG_NONFINITE);   // inf or NaN
   const double mean = S / HW;
   double var = S2 / HW - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -492,12 +497,38 @@ extern "C" int sdy_lp_rel_terms(const float* gen, const sdy_var_table* targets, 
   return sdy_launch_status();
 }
 
+// ---- sticky status word (include/sdy_amd.h) ------------------------------------------------------------------------
+int sdy_flags_ptr(unsigned** flags) {
+  static unsigned* words[SDY_MAX_DEVICES] = {};
+  static std::mutex mu;
+  int dev = 0;
+  SDY_TRY(sdy_current_device(&dev));
+  std::lock_guard<std::mutex> g(mu);
+  if (!words[dev]) {
+    SDY_HIP_TRY(hipMalloc(&words[dev], 64));
+    SDY_HIP_TRY(hipMemset(words[dev], 0, 64));
+  }
+  *flags = words[dev];
+  return SDY_OK;
+}
+extern "C" int sdy_status_flags(unsigned* flags, int reset, void* stream) {
+  if (!flags) return SDY_ERR_ARG;
+  unsigned* d = nullptr;
+  SDY_TRY(sdy_flags_ptr(&d));
+  SDY_HIP_TRY(hipMemcpyAsync(flags, d, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (reset) SDY_HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned), (hipStream_t)stream));
+  SDY_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return SDY_OK;
+}
+
 int sdy_instnorm_coeffs_launch(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
                                const float* ss, long ss_stride, float eps, float* a, float* d, hipStream_t stream) {
   if (!x || !gamma || !beta || !a || !d || B <= 0 || C <= 0 || HW <= 0) return SDY_ERR_ARG;
   if (HW & 3) return SDY_ERR_ALIGN;
+  unsigned* flags = nullptr;
+  SDY_TRY(sdy_flags_ptr(&flags));
   hipLaunchKernelGGL(instnorm_coeffs_kernel, dim3(C, B), dim3(256), 0, stream, x, C, HW, gamma, beta, ss, ss_stride,
-                     eps, a, d);
+                     eps, a, d, flags);
   return sdy_launch_status();
 }
 
@@ -505,8 +536,10 @@ extern "C" int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, cons
                                        const float* ss, long ss_stride, float eps, float* a, float* d, void* stream) {
   if (!stats || !gamma || !beta || !a || !d || B <= 0 || C <= 0 || HW <= 0) return SDY_ERR_ARG;
   const int BC = B * C;
+  unsigned* flags = nullptr;
+  SDY_TRY(sdy_flags_ptr(&flags));
   hipLaunchKernelGGL(instnorm_from_stats_kernel, dim3((BC + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, BC, C, HW,
-                     gamma, beta, ss, ss_stride, eps, a, d);
+                     gamma, beta, ss, ss_stride, eps, a, d, flags);
   return sdy_launch_status();
 }
 

@@ -176,7 +176,8 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
         ic_rows = torch.tensor(ic_list, dtype=torch.long, device=dev)
         # IC-major batch: row r is global trajectory start + r = (IC ic_rows[r], member (start + r) % members)
         batch = {k: v.index_select(0, ic_rows) for k, v in win.items()}
-        stitcher.apply_initial_condition(batch, ic_rows)
+        # the stitcher carries targets for the initial conditions this process touches (all of them unless ragged)
+        stitcher.apply_initial_condition(batch, ic_rows if rect else ic_rows - ic_list[0])
         if hasattr(module, "set_batch_offset"):
             module.set_batch_offset(start)
         stepped = stepper.run_on_batch(batch, None, n_forward_steps=forward_steps_in_memory)

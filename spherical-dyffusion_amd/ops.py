@@ -284,6 +284,33 @@ def concat_channels(tensors) -> torch.Tensor:
     return out
 
 
+FLAG_NONFINITE, FLAG_F16_RANGE = 1, 2
+
+
+def status_flags(reset: bool = True, device=None) -> int:
+    """Sticky status word of a device (`sdy_status_flags`): FLAG_NONFINITE | FLAG_F16_RANGE bits set by kernels since the last
+    reset.  Synchronises the current stream of that device."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = C.c_uint(0)
+    with torch.cuda.device(dev):
+        check(lib.sdy_status_flags(C.byref(out), 1 if reset else 0, current_stream()), "sdy_status_flags")
+    return int(out.value)
+
+
+def raise_on_status_flags(flags: int, where: str) -> None:
+    if not flags:
+        return
+    why = []
+    if flags & FLAG_F16_RANGE:
+        why.append("an activation exceeded the fp16 range of the split-precision kernels (|value| * 16 >= 65504, i.e. "
+                   "|value| >= 4094 after normalisation)")
+    if flags & FLAG_NONFINITE:
+        why.append("an InstanceNorm statistic came out inf / NaN (a tensor inside the network holds non-finite values)")
+    from ._lib import SdyError
+    raise SdyError(f"{where}: " + "; ".join(why) + ".  Inputs are expected standardised; if the data really need the range, "
+                   "run the fp32-MFMA path: SDY_GEMM_MODE=f32 (or gemm_mode='f32').")
+
+
 class stage_timer:
     """Context manager around `sdy_profile_*`: per-stage HIP-event timing of every SFNO forward issued inside the block
     (events on the launch stream).  `.stages` afterwards: {stage name: (launches, total_ms)}.  Measurement only."""

@@ -60,6 +60,8 @@ class MultiStepStepper:
             raise ValueError("Variables which are being prescribed in masked regions must be in in_names and out_names, "
                              f"but {prescriber.prescribed_name} is not.")     # prescriber.py:39-43
         self.prescriber = prescriber
+        # once per window: raise if a kernel flagged an fp16-range overflow / non-finite statistics (include/sdy_amd.h)
+        self.check_status = True
         if max(len(self.in_names), len(self.out_names), len(self.forcing_names)) > SDY_MAX_VARS:
             raise ValueError(f"more than {SDY_MAX_VARS} variables")
         # one entry per distinct variable of (in packer) U (out packer)
@@ -158,6 +160,9 @@ class MultiStepStepper:
 
         # metrics (LpLoss.rel, darcy_loss.py:214-228): one device->host read for the whole window
         terms = loss_terms.cpu()
+        if self.check_status:     # the stream is drained by the read above: the sticky status word costs one 4-byte copy
+            from . import ops
+            ops.raise_on_status_flags(ops.status_flags(reset=True, device=dev), "MultiStepStepper.run_on_batch")
         per_step = (terms[..., 0].sqrt() / terms[..., 1].sqrt()).mean(dim=1)
         metrics = {f"loss_step_{i}": per_step[i].to(torch.float32) for i in range(n_forward_steps)}
         metrics["loss"] = per_step.sum().to(torch.float32)

@@ -292,3 +292,33 @@ def test_sharding_invariance_of_trajectories():
     with pytest.raises(ValueError):      # a shard that needs an IC the window does not hold
         _run_sharded(exp, stepper, [{k: v[:1] for k, v in w.items()} for w in wins], n_total, n_mem, members,
                      unit_range=(1, 3))
+
+
+@pytest.mark.parametrize("mode", ["h3", "f32"])
+def test_stepper_raises_on_fp16_range_overflow(mode, monkeypatch):
+    """|x| = 1e4 after normalisation: the split-precision path cannot represent it (x16 -> fp16 overflow) and the window
+    must fail loudly, naming the fp32 mode; the fp32-MFMA path runs the same data."""
+    import sdy_amd
+    from sdy_amd._lib import SdyError
+
+    monkeypatch.setenv("SDY_GEMM_MODE", mode)
+    exp, _, cs, n_forc = _build(hack=True, dropout=False)
+    assert exp.model.model.gemm_mode == mode
+    in_names = ["HGTsfc"] + [f"v{i}" for i in range(1, cs)]
+    out_names, forcing_names = in_names[1:], ["f0", "f1"]
+    names = in_names + forcing_names
+    stepper = sdy_amd.MultiStepStepper(exp, names, out_names, forcing_names, {n: 0.0 for n in names},
+                                       {n: 1.0 for n in names}, None)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    data = {n: torch.randn(1, 7, 32, 64, generator=g).cuda() for n in names}
+    sdy_amd.ops.status_flags(reset=True)
+    out = stepper.run_on_batch(data, None, n_forward_steps=6)            # ordinary data: fine in both modes
+    assert all(torch.isfinite(v).all() for v in out.gen_data.values())
+    data["v1"][0, 0, 4, 9] = 1.0e4
+    if mode == "h3":
+        with pytest.raises(SdyError, match="SDY_GEMM_MODE=f32"):
+            stepper.run_on_batch(data, None, n_forward_steps=6)
+        assert sdy_amd.ops.status_flags(reset=True) == 0                 # the check consumed the flags
+    else:
+        out = stepper.run_on_batch(data, None, n_forward_steps=6)
+        assert all(torch.isfinite(v).all() for v in out.gen_data.values())

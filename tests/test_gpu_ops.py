@@ -409,3 +409,39 @@ def test_sht_shapes_both_directions(sdy, nlat, nlon, L, M, C, B, grid):
     refi = OInv(nlat, nlon, lmax=L, mmax=M, grid=grid).float()(c)
     goti = sdy.InverseRealSHT(nlat, nlon, lmax=L, mmax=M, grid=grid, gemm_mode="h3").float()(c.cuda())
     assert rel_l2(goti, refi) < TOL_OP, f"InverseRealSHT {nlat}x{nlon} L={L} M={M} {grid}"
+
+
+def test_fp16_range_guard_sets_the_sticky_flag(sdy):
+    """The split-precision kernels scale activations by 16 into fp16: |x| >= 4094 overflows to inf.  That must not be silent:
+    the kernel sets SDY_FLAG_F16_RANGE in the device's sticky status word; the fp32-MFMA mode has no such limit."""
+    ops = sdy.ops
+    g = _gen(21)
+    F = torch.nn.functional
+    ops.status_flags(reset=True)
+    x = torch.randn(1, 256, 32, 64, generator=g)
+    w = torch.randn(256, 256, 1, 1, generator=g) / 16.0
+    got = ops.conv1x1(x.cuda(), w, None, h3=True)                       # conv_h3 (256 -> 256 fragment-stream kernel)
+    assert ops.status_flags(reset=True) == 0 and torch.isfinite(got).all()
+    big = x.clone()
+    big[0, 17, 3, 5] = 1.0e4                                              # 1e4 * 16 > 65504
+    got = ops.conv1x1(big.cuda(), w, None, h3=True)
+    assert ops.status_flags(reset=False) & ops.FLAG_F16_RANGE
+    assert not torch.isfinite(got).all()                                  # ... which is what the flag warns about
+    assert ops.status_flags(reset=True) & ops.FLAG_F16_RANGE              # sticky until reset
+    assert ops.status_flags(reset=True) == 0
+    ref = F.conv2d(big.double(), w.double())
+    got32 = ops.conv1x1(big.cuda(), w, None)                              # fp32-MFMA path: exact range
+    assert ops.status_flags(reset=True) == 0 and rel_l2(got32, ref) < TOL_OP
+    # tile GEMM (other channel counts: encoder / decoder layers)
+    xs = torch.randn(1, 36, 32, 64, generator=g)
+    ws = torch.randn(130, 36, 1, 1, generator=g) / 6.0
+    ops.conv1x1(xs.cuda(), ws, None, h3=True)
+    assert ops.status_flags(reset=True) == 0
+    xs[0, 5, 1, 1] = -7.0e3
+    ops.conv1x1(xs.cuda(), ws, None, h3=True)
+    assert ops.status_flags(reset=True) & ops.FLAG_F16_RANGE
+    # just inside the range is fine: 4000 * 16 = 64000 < 65504
+    xs[0, 5, 1, 1] = 4000.0
+    got = ops.conv1x1(xs.cuda(), ws, None, h3=True)
+    assert ops.status_flags(reset=True) == 0
+    assert rel_l2(got, F.conv2d(xs.double(), ws.double())) < 5e-6
