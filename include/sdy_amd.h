@@ -154,6 +154,10 @@ typedef struct sdy_conv_args {
   float drop_p;                      /* 0 = no dropout */
   const float* keep_mask;            /* dev (B,Cout,HW) 0/1 injected mask (tests) or NULL = Philox stream */
   uint64_t seed; uint32_t call; uint32_t stream_id; uint32_t batch_offset;
+  int rows_per_call;                   /* 0: every batch row belongs to `call`.  n > 0: the batch stacks several calls of n
+                                          rows each: row b draws the stream of (call + b / n, trajectory batch_offset + b % n)
+                                          -- bit-identical to issuing those calls one after the other (the two interpolator
+                                          calls of a DYffusion sampling step share their inputs: dyffusion.py:497,515) */
   const float* batch_scale;          /* dev [B] or NULL (drop-path scale) */
   int kernel_tag;                    /* 0 generic; 1 = MLP fc1, 2 = MLP fc2, 3 = inner skip: identical code under a
                                         distinct symbol name so profilers attribute time per use */
@@ -198,6 +202,7 @@ typedef struct sdy_mlp_args {
   int B, E, hidden, HW;
   float drop_p;                        /* 0 = no dropout */
   uint64_t seed; uint32_t call; uint32_t stream_fc1; uint32_t stream_fc2; uint32_t batch_offset;
+  int rows_per_call;                   /* as in sdy_conv_args */
   const float* batch_scale;            /* dev [B] or NULL (drop-path scale) */
   double* stats;                       /* dev [B*E*2] or NULL: (sum, sum of squares) over HW of every output plane are
                                           ADDED here (InstanceNorm statistics of the next block, sfnonet.py:292): zero
@@ -257,6 +262,8 @@ typedef struct sdy_sfno_fwd_args {
   int B;
   int enable_dropout;                    /* inference_dropout_scope (src/models/_base_model.py:273-286) */
   uint64_t seed; uint32_t call; uint32_t batch_offset;
+  int rows_per_call;       /* 0, or n: the B rows are B / n stacked calls (call, call + 1, ...) of n trajectories each, see
+                              sdy_conv_args; B must be a multiple of n */
   const float* const* keep_masks;        /* optional injected masks (tests): [num_layers*2] dev pointers
                                             (hidden, out) per layer, or NULL */
   const float* drop_path_keep;           /* optional injected drop-path keep flags, dev [num_layers][B], or NULL */

@@ -33,6 +33,7 @@ class SdyConvArgs(C.Structure):
         ("drop_p", C.c_float),
         ("keep_mask", C.c_void_p),
         ("seed", C.c_uint64), ("call", C.c_uint32), ("stream_id", C.c_uint32), ("batch_offset", C.c_uint32),
+        ("rows_per_call", C.c_int),
         ("batch_scale", C.c_void_p),
         ("kernel_tag", C.c_int),
         ("w_h3", C.c_void_p),
@@ -56,6 +57,7 @@ class SdyMlpArgs(C.Structure):
         ("drop_p", C.c_float),
         ("seed", C.c_uint64), ("call", C.c_uint32), ("stream_fc1", C.c_uint32), ("stream_fc2", C.c_uint32),
         ("batch_offset", C.c_uint32),
+        ("rows_per_call", C.c_int),
         ("batch_scale", C.c_void_p),
         ("stats", C.c_void_p),
     ]
@@ -106,6 +108,7 @@ class SdySfnoFwdArgs(C.Structure):
         ("B", C.c_int),
         ("enable_dropout", C.c_int),
         ("seed", C.c_uint64), ("call", C.c_uint32), ("batch_offset", C.c_uint32),
+        ("rows_per_call", C.c_int),
         ("keep_masks", C.POINTER(C.c_void_p)),
         ("drop_path_keep", C.c_void_p),
         ("ws", C.c_void_p), ("ws_floats", C.c_size_t),

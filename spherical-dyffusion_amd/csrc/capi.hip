@@ -509,6 +509,8 @@ extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
   }
   g.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFu); g.seed_hi = (uint32_t)(a->seed >> 32);
   g.stream_id = a->stream_id; g.call = a->call; g.batch_offset = a->batch_offset;
+  if (a->rows_per_call < 0 || (a->rows_per_call > 0 && a->B % a->rows_per_call)) return SDY_ERR_ARG;
+  g.rows_per_call = a->rows_per_call > 0 ? a->rows_per_call : a->B;
   g.batch_scale = a->batch_scale;
   if (a->w_h3) {
     const int Mp = h3_mpad(a->Cout), Kp = h3_kpad(a->Cin);
@@ -885,7 +887,7 @@ extern "C" int sdy_sfno_time_embed(sdy_sfno* n, const float* time, int B, float*
   SDY_TRY(sdy_sfno_ready(n));
   if (!n->cfg.with_time_emb) return SDY_ERR_UNSUPPORTED;
   if (!ss) return SDY_ERR_ARG;
-  return sdy_time_mlp_launch(n->tm, time, B, t_repr, ss, nullptr, nullptr, 0, 0, 0, 0, (hipStream_t)stream);
+  return sdy_time_mlp_launch(n->tm, time, B, t_repr, ss, nullptr, nullptr, 0, 0, 0, 0, 0, (hipStream_t)stream);
 }
 
 // ---- stage timing of the forward (measurement only; off by default) ------------------------------------------------
@@ -987,8 +989,10 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
 
   // ---- time embedding + per-layer (scale|shift) + drop-path scales
   const bool drop = a->enable_dropout != 0;
+  if (a->rows_per_call < 0 || (a->rows_per_call > 0 && B % a->rows_per_call)) return SDY_ERR_ARG;
+  const int rpc = a->rows_per_call > 0 ? a->rows_per_call : B;   // stacked calls (sdy_sfno_fwd_args.rows_per_call)
   SDY_STAGE(ST_TIME_MLP, sdy_time_mlp_launch(n->tm, a->time, B, trep, ss, dp, a->drop_path_keep, drop ? 1 : 0, a->seed,
-                                             a->call, a->batch_offset, stream));
+                                             a->call, a->batch_offset, rpc, stream));
 
   sdy_conv_args cv;
   static const bool no_frag = std::getenv("SDY_NO_CONV_FRAG") != nullptr;
@@ -1001,7 +1005,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   };
   auto conv_reset = [&]() {
     std::memset(&cv, 0, sizeof(cv));
-    cv.B = B; cv.HW = HW; cv.seed = a->seed; cv.call = a->call; cv.batch_offset = a->batch_offset;
+    cv.B = B; cv.HW = HW; cv.seed = a->seed; cv.call = a->call; cv.batch_offset = a->batch_offset; cv.rows_per_call = rpc;
   };
 
   // ---- encoder (sfnonet.py:609-618,810,824): conv+bias -> GELU -> conv (no bias) -> + pos_embed
@@ -1091,7 +1095,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       else { ma.add = xn; ma.add_bstride = (long)E * HW; }
       ma.B = B; ma.E = E; ma.hidden = Hd; ma.HW = HW;
       ma.drop_p = pm; ma.seed = a->seed; ma.call = a->call; ma.stream_fc1 = 2u * i; ma.stream_fc2 = 2u * i + 1u;
-      ma.batch_offset = a->batch_offset;
+      ma.batch_offset = a->batch_offset; ma.rows_per_call = rpc;
       if (drop && n->tm.dp_rate[i] > 0.f) ma.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
       static const bool no_stats = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
       if (i < L - 1 && !no_stats) { ma.stats = st0; have_st0 = true; }   // the next block's norm0 statistics

@@ -190,6 +190,7 @@ struct GemmParams {
   int act;
   uint32_t drop_thr; float drop_scale; const float* keep_mask;
   uint32_t seed_lo, seed_hi, stream_id, call, batch_offset;
+  int rows_per_call;   // >= 1: batch row z draws the stream of (call + z / rows_per_call, trajectory batch_offset + z % rows_per_call)
   const float* batch_scale;
 };
 int sdy_gemm_launch(const GemmParams& p, hipStream_t stream);

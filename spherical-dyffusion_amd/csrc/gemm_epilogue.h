@@ -16,7 +16,11 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[WM][WN], const 
   const float* __restrict__ maskg = p.keep_mask ? p.keep_mask + (long)z * p.M_store * p.N : nullptr;
   const float bscale = p.batch_scale ? p.batch_scale[z] : 1.0f;
   const bool do_drop = p.drop_thr != 0u;
-  const uint32_t c1_base = (uint32_t)(((uint64_t)(z + p.batch_offset) * (uint64_t)(p.M_store >> 2)) & 0xFFFFFFFFu);
+  // stacked calls (sdy_conv_args.rows_per_call): which call, which trajectory (0 = launchers without a dropout stream)
+  const int rpc = p.rows_per_call > 0 ? p.rows_per_call : 0x7FFFFFFF;
+  const int zq = z / rpc;
+  const uint32_t call_z = p.call + (uint32_t)zq;
+  const uint32_t c1_base = (uint32_t)(((uint64_t)((z - zq * rpc) + p.batch_offset) * (uint64_t)(p.M_store >> 2)) & 0xFFFFFFFFu);
 
   // Two-phase per 32x32 tile: first every bias / addend load of the tile (16 independent loads in flight), then the
   // arithmetic and the stores.  (Interleaving them lets the possible add == C aliasing serialise each element behind a
@@ -51,7 +55,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[WM][WN], const 
         const int row_base = row0 + 8 * rg;
         uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (do_drop && !maskg && (FULL || (col_ok && row_base < M_store))) {
-          const philox4 w = philox4x32_10((uint32_t)gn & ~32u, c1_base + (uint32_t)(row_base >> 2), p.stream_id, p.call,
+          const philox4 w = philox4x32_10((uint32_t)gn & ~32u, c1_base + (uint32_t)(row_base >> 2), p.stream_id, call_z,
                                           p.seed_lo, p.seed_hi);
           words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
         }

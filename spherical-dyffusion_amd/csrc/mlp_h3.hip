@@ -64,6 +64,7 @@ struct MlpParams {
   float s1, s2;                            // accumulator scales: 1 / (w_scale * SX)
   uint32_t drop_thr; float drop_scale;
   uint32_t seed_lo, seed_hi, stream1, stream2, call, batch_offset;
+  int rows_per_call;                       // >= 1 (sdy_mlp_args.rows_per_call; 0 there = B)
   const float* batch_scale;
   double* stats;                           // optional [B][ME][2]: sum and sum of squares of the stored output rows
   unsigned* flags;                         // sticky status word (sdy_status_flags)
@@ -200,7 +201,10 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   const long e_off = e_ok ? e_col : 0;
 
   constexpr bool do_drop = DROP;
-  const uint32_t c1_base = (uint32_t)(((uint64_t)(z + p.batch_offset) * (uint64_t)(MH >> 2)) & 0xFFFFFFFFu);
+  // stacked calls: image z is trajectory z % rows_per_call of call + z / rows_per_call
+  const int zq = z / p.rows_per_call, zt = z - zq * p.rows_per_call;
+  const uint32_t call_z = p.call + (uint32_t)zq;
+  const uint32_t c1_base = (uint32_t)(((uint64_t)(zt + p.batch_offset) * (uint64_t)(MH >> 2)) & 0xFFFFFFFFu);
 
   // The chunk pipeline (MFMA work of one chunk overlaps the VALU work of the next):
   //     fc1(0) | chain(0) | B | fc1(1) | { chain(1) || fc2(0) } | B | fc1(2) | { chain(2) || fc2(1) } | B | fc1(3) |
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     const int px = 32 * j + l31;
     if (do_drop && st < 10 && j == 0) {
       if (st == 0) {
-        s.c0 = (uint32_t)(n0 + l31); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = p.call;
+        s.c0 = (uint32_t)(n0 + l31); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = call_z;
         s.k0 = p.seed_lo; s.k1 = p.seed_hi;
       }
       const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0, p1 = (uint64_t)0xCD9E8D57u * s.c2;   // one Philox4x32 round
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   //      every wave passed the last chunk's barrier after its final x read), then residual add + 16-byte row stores
   {
     const float bscale = p.batch_scale ? p.batch_scale[z] : 1.0f;
-    const uint32_t c1_base2 = (uint32_t)(((uint64_t)(z + p.batch_offset) * (uint64_t)(ME >> 2)) & 0xFFFFFFFFu);
+    const uint32_t c1_base2 = (uint32_t)(((uint64_t)(zt + p.batch_offset) * (uint64_t)(ME >> 2)) & 0xFFFFFFFFu);
     float* Os = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (do_drop) {   // one call per 4 rows x the pixel pair (l31, l31 + 32)
           const philox4 w = philox4x32_10((uint32_t)(n0 + l31), c1_base2 + (uint32_t)((row0 + 8 * g4) >> 2), p.stream2,
-                                          p.call, p.seed_lo, p.seed_hi);
+                                          call_z, p.seed_lo, p.seed_hi);
           words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
         }
 #pragma unroll
@@ -661,6 +665,8 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   }
   p.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFu); p.seed_hi = (uint32_t)(a->seed >> 32);
   p.stream1 = a->stream_fc1; p.stream2 = a->stream_fc2; p.call = a->call; p.batch_offset = a->batch_offset;
+  if (a->rows_per_call < 0 || (a->rows_per_call > 0 && a->B % a->rows_per_call)) return SDY_ERR_ARG;
+  p.rows_per_call = a->rows_per_call > 0 ? a->rows_per_call : a->B;
   p.batch_scale = a->batch_scale;
   p.stats = a->stats;
   SDY_TRY(sdy_flags_ptr(&p.flags));

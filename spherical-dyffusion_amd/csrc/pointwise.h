@@ -25,6 +25,6 @@ int sdy_concat_launch(const float* const* src, const int* chans, int nsrc, float
 int sdy_cold_update_launch(const float* xs, const float* xn, const float* xi, float* out, size_t n, hipStream_t stream);
 int sdy_time_mlp_launch(const SdyTimeMlp& t, const float* time, int B, float* trep, float* ss, float* dp,
                         const float* dp_keep_in, int enable_dropout, uint64_t seed, uint32_t call,
-                        uint32_t batch_offset, hipStream_t stream);
+                        uint32_t batch_offset, int rows_per_call, hipStream_t stream);
 int sdy_spec_to_torch_launch(const float* Cs, float* out, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);
 int sdy_torch_to_spec_launch(const float* in, float* Cs, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const SdyTimeMlp t, const
                                                         float* __restrict__ trep_out, float* __restrict__ ss_out,
                                                         float* __restrict__ dp_out, const float* __restrict__ dp_keep_in,
                                                         int enable_dropout, uint32_t seed_lo, uint32_t seed_hi,
-                                                        uint32_t call, uint32_t batch_offset) {
+                                                        uint32_t call, uint32_t batch_offset, int rows_per_call) {
   extern __shared__ float sm[];
   const int E = t.E, T = t.T, L = t.num_layers;
   float* emb = sm;         // [E]
@@ -197,8 +197,9 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const SdyTimeMlp t, const
       if (dp_keep_in) {
         keep = dp_keep_in[layer * gridDim.y + b] != 0.0f;
       } else {
-        const philox4 w = philox4x32_10((uint32_t)(b + batch_offset), 0xFFFFFFFFu, 0x1000u + (uint32_t)layer, call,
-                                        seed_lo, seed_hi);
+        const int bq = b / rows_per_call;   // stacked calls: trajectory b % rows_per_call of call + b / rows_per_call
+        const philox4 w = philox4x32_10((uint32_t)((b - bq * rows_per_call) + batch_offset), 0xFFFFFFFFu,
+                                        0x1000u + (uint32_t)layer, call + (uint32_t)bq, seed_lo, seed_hi);
         keep = w.x >= t.dp_thr[layer];
       }
       scale = keep ? 1.0f / (1.0f - p) : 0.0f;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const SdyTimeMlp t, const
 // drop-path scales only (network without time embedding)
 __global__ void droppath_kernel(const SdyTimeMlp t, float* __restrict__ dp_out, const float* __restrict__ dp_keep_in,
                                 int B, int enable_dropout, uint32_t seed_lo, uint32_t seed_hi, uint32_t call,
-                                uint32_t batch_offset) {
+                                uint32_t batch_offset, int rows_per_call) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int L = t.num_layers;
   if (i >= B * L) return;
@@ -222,8 +223,9 @@ __global__ void droppath_kernel(const SdyTimeMlp t, float* __restrict__ dp_out, 
     if (dp_keep_in) {
       keep = dp_keep_in[layer * B + b] != 0.0f;
     } else {
-      const philox4 w = philox4x32_10((uint32_t)(b + batch_offset), 0xFFFFFFFFu, 0x1000u + (uint32_t)layer, call,
-                                      seed_lo, seed_hi);
+      const int bq = b / rows_per_call;
+      const philox4 w = philox4x32_10((uint32_t)((b - bq * rows_per_call) + batch_offset), 0xFFFFFFFFu,
+                                      0x1000u + (uint32_t)layer, call + (uint32_t)bq, seed_lo, seed_hi);
       keep = w.x >= t.dp_thr[layer];
     }
     scale = keep ? 1.0f / (1.0f - p) : 0.0f;
@@ -575,17 +577,18 @@ int sdy_cold_update_launch(const float* xs, const float* xn, const float* xi, fl
 
 int sdy_time_mlp_launch(const SdyTimeMlp& t, const float* time, int B, float* trep, float* ss, float* dp,
                         const float* dp_keep_in, int enable_dropout, uint64_t seed, uint32_t call,
-                        uint32_t batch_offset, hipStream_t stream) {
+                        uint32_t batch_offset, int rows_per_call, hipStream_t stream) {
+  if (rows_per_call < 1) rows_per_call = B > 0 ? B : 1;
   const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
   if (t.E > 0) {
     if (!time) return SDY_ERR_ARG;
     const size_t smem = (size_t)(t.E + 2 * t.T) * sizeof(float);
     hipLaunchKernelGGL(time_mlp_kernel, dim3(t.num_layers + 1, B), dim3(256), smem, stream, t, time, trep, ss, dp,
-                       dp_keep_in, enable_dropout, slo, shi, call, batch_offset);
+                       dp_keep_in, enable_dropout, slo, shi, call, batch_offset, rows_per_call);
   } else if (dp) {
     const int n = B * t.num_layers;
     hipLaunchKernelGGL(droppath_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, t, dp, dp_keep_in, B, enable_dropout,
-                       slo, shi, call, batch_offset);
+                       slo, shi, call, batch_offset, rows_per_call);
   }
   return sdy_launch_status();
 }

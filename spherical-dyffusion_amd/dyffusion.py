@@ -46,6 +46,7 @@ class DYffusion(torch.nn.Module):
         interpolator_use_ema: bool = False,
         log_every_t: Union[str, int, None] = None,
         hack_for_imprecise_interpolation: bool = False,
+        fuse_interpolator_pair_max_batch: int = 8,
         **unused,
     ):
         super().__init__()
@@ -88,6 +89,10 @@ class DYffusion(torch.nn.Module):
         self.i_to_diffusion_step = {i: d for d, i in d_to_i.items()}
         self.artificial_interpolation_steps = {d: i for d, i in d_to_i.items() if not float(i).is_integer()}
         self.enable_interpolator_dropout = enable_interpolator_dropout
+        # A cold-sampling step interpolates the same (x_0, forecast) pair to two times (s' and s).  Up to this batch size the
+        # two calls run as ONE forward of 2B rows (per-row time, per-row dropout call number: identical results); larger
+        # batches already fill the GPU and would only pay for the stacked copy of the inputs.
+        self.fuse_interpolator_pair_max_batch = int(fuse_interpolator_pair_max_batch)
         self.full_sampling_schedule = list(range(0, self.num_timesteps))
         self.sampling_schedule = sampling_schedule or self.full_sampling_schedule
         # DYffusion.__init__ consistency check (dyffusion.py:632-640)
@@ -177,6 +182,34 @@ class DYffusion(torch.nn.Module):
             out = ops.concat_channels([initial_condition[:, :1], out])
         return out
 
+    def q_sample_pair(self, x0, x_end, t_first, t_second, is_artificial_step: bool = True, **kwargs):
+        """`(q_sample(t=t_first), q_sample(t=t_second))` for the same (x0, x_end) as ONE interpolator forward of 2B rows
+        (reference call sites dyffusion.py:497 and :515): rows 0..B-1 carry `t_first` and the dropout stream of the first
+        call, rows B..2B-1 `t_second` and that of the second call, so the results equal the two separate calls."""
+        B = x0.shape[0]
+        i_a, i_b = (self.diffusion_step_to_interpolation_step(t) for t in (t_first, t_second))
+        for i_n in (i_a, i_b):
+            assert 0 < i_n < self.interpolator_horizon, f"interpolate time must be in (0, {self.interpolator_horizon}), got {i_n}"
+        kwargs.pop("num_predictions", None)
+        dyn = kwargs.pop("dynamical_condition", None)
+        two = lambda v: torch.cat([v, v], dim=0)  # noqa: E731
+        kwargs = {k: (two(v) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in kwargs.items()}
+        if dyn is not None:   # the condition at each call's own time
+            kwargs["condition"] = torch.cat([self.interpolator.get_dynamical_condition(dyn, i_a),
+                                             self.interpolator.get_dynamical_condition(dyn, i_b)], dim=0)
+        time = torch.cat([self._time_tensor(i_a, x0), self._time_tensor(i_b, x0)])
+        hack = self.hparams.hack_for_imprecise_interpolation
+        inputs = ops.concat_channels([x_end] + ([x_end[:, :1]] if hack else []) + [x0])
+        do_enable = bool(
+            self.enable_interpolator_dropout in [True, "always"]
+            or (self.enable_interpolator_dropout == "except_dynamical_steps" and is_artificial_step)
+        )
+        with self.interpolator.inference_dropout_scope(condition=do_enable):
+            out = self.interpolator.predict_packed(two(inputs), time=time, rows_per_call=B, **kwargs)["preds"]
+        if hack:
+            out = ops.concat_channels([two(x_end[:, :1]), out])
+        return out[:B], out[B:]
+
     def predict_x_last(self, initial_condition: Tensor, x_t: Tensor, t, **kwargs) -> Tensor:
         """Forecaster call (dyffusion.py:286-355); `t` is a host scalar diffusion step."""
         assert 0 <= t <= self.num_timesteps - 1, f"Invalid timestep: {t}. {self.num_timesteps=}"
@@ -222,6 +255,7 @@ class DYffusion(torch.nn.Module):
             s_next = sched[pos + 1] if pos + 1 < len(sched) else sched[-1] + 1
             final = s == last                      # the forecast itself is the last state: no interpolation to s_next
             x_hat = self.predict_x_last(initial_condition=initial_condition, x_t=x_s, t=s, **dict(kwargs))
+            x_at_s = None          # I(x_0, x_hat, s), when it came out of a fused pair
             i_next = self.diffusion_step_to_interpolation_step(s_next) if not final else None
             lands_on_data = final or float(i_next).is_integer()
             ipol = dict(x0=x_hat, x_end=initial_condition, is_artificial_step=not lands_on_data)
@@ -231,7 +265,12 @@ class DYffusion(torch.nn.Module):
                     else x_hat
             else:
                 assert s_next <= last, f"Invalid s_next: {s_next} (should be <= {last})"
-                x_next = self.q_sample(**ipol, t=s_next, **dict(kwargs))
+                if cold and s > 0 and x_s.shape[0] <= self.fuse_interpolator_pair_max_batch:
+                    # the step's two interpolations (to s_next, then to s: the reference's call order) as one 2B forward
+                    x_next, x_at_s = self.q_sample_pair(x_hat, initial_condition, s_next, s,
+                                                        is_artificial_step=not lands_on_data, **dict(kwargs))
+                else:
+                    x_next = self.q_sample(**ipol, t=s_next, **dict(kwargs))
             if not cold:
                 x_s = x_next
             elif final and not hp.use_cold_sampling_for_last_step:
@@ -241,7 +280,9 @@ class DYffusion(torch.nn.Module):
                 x_s = x_hat
             else:
                 # x_s + (x_next - I(x_0, x_hat, s)); at s = 0 the interpolation "at time 0" is x_s itself
-                x_s = ops.cold_update(x_s, x_next, self.q_sample(**ipol, t=s, **dict(kwargs)) if s > 0 else None)
+                if s > 0 and x_at_s is None:
+                    x_at_s = self.q_sample(**ipol, t=s, **dict(kwargs))
+                x_s = ops.cold_update(x_s, x_next, x_at_s)
             k = int(i_next) if not final else k + 1
             if lands_on_data:
                 emit = x_s if (hp.use_cold_sampling_for_intermediate_steps or final) else x_next

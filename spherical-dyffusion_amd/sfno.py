@@ -322,7 +322,11 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def forward(self, inputs, time=None, condition=None, static_condition=None, return_time_emb: bool = False,
-                keep_masks=None, drop_path_keep=None, **kwargs):
+                keep_masks=None, drop_path_keep=None, rows_per_call: Optional[int] = None, **kwargs):
+        """`rows_per_call=n` (n divides the batch): the batch stacks B / n CALLS of n trajectories each -- row b draws the
+        dropout stream of call number `_call + b // n`, trajectory `batch_offset + b % n`, exactly as if the calls had
+        been issued one after the other, and the call counter advances by B / n.  (The two interpolator calls of a DYffusion
+        sampling step share their inputs, reference dyffusion.py:497,515.)"""
         if return_time_emb:
             raise NotImplementedError("return_time_emb is a training-path feature")
         if not inputs.is_cuda:
@@ -370,6 +374,13 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         a.time, a.out, a.B = ptr(tt), ptr(out), B
         a.enable_dropout = int(self.inference_dropout)
         a.seed, a.call, a.batch_offset = self.seed, self._call & 0xFFFFFFFF, self.batch_offset
+        n_calls = 1
+        if rows_per_call is not None:
+            assert rows_per_call >= 1 and B % rows_per_call == 0, f"rows_per_call={rows_per_call} must divide the batch {B}"
+            assert keep_masks is None and drop_path_keep is None and self.mask_injector is None, \
+                "injected masks address one call per forward"
+            a.rows_per_call = int(rows_per_call)
+            n_calls = B // int(rows_per_call)
         keep = []
         if keep_masks is None and drop_path_keep is None and self.mask_injector is not None and self.inference_dropout:
             keep_masks, drop_path_keep = self.mask_injector(self._call)
@@ -390,7 +401,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         a.ws, a.ws_floats = ptr(ws), ws.numel()
         with torch.cuda.device(dev):
             check(lib.sdy_sfno_forward(h, C.byref(a), current_stream()), "sdy_sfno_forward")
-        self._call += 1
+        self._call += n_calls
         return out
 
     def predict_forward(self, *inputs, metadata=None, **kwargs):      # _base_model.py:265-270

@@ -322,3 +322,36 @@ def test_stepper_raises_on_fp16_range_overflow(mode, monkeypatch):
     else:
         out = stepper.run_on_batch(data, None, n_forward_steps=6)
         assert all(torch.isfinite(v).all() for v in out.gen_data.values())
+
+
+@pytest.mark.parametrize("hack", [False, True])
+def test_fused_interpolator_pair_equals_two_calls(hack):
+    """A cold-sampling step interpolates the same (x_0, forecast) pair to two times (reference dyffusion.py:497 and :515).
+    Small batches run both as ONE forward of 2B rows with per-row time and per-row dropout call number
+    (`rows_per_call`): the samples must equal the two-call path bit for bit, dropout ON."""
+    exp, oracle, cs, n_forc = _build(hack=hack, dropout=True)
+    sampler, fnet, inet = exp.model, exp.model.model, exp.model.interpolator.model
+    g = torch.Generator(device="cpu").manual_seed(77)
+    B = 3
+    x0 = torch.randn(B, cs, 32, 64, generator=g).cuda()
+    kw = ({"static_condition": torch.randn(B, n_forc, 32, 64, generator=g).cuda()} if hack else
+          {"dynamical_condition": torch.randn(B, 7, n_forc, 32, 64, generator=g).cuda()})
+    exp.set_batch_offset(5)
+    outs = []
+    for limit in (0, 8):            # 0: never fuse; 8: fuse (B = 3)
+        sampler.fuse_interpolator_pair_max_batch = limit
+        fnet._call = inet._call = 0
+        outs.append(sampler.sample(x0, **kw))
+        assert (fnet._call, inet._call) == (6, 10)          # the fused forwards advance the call counter by two
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), f"{k}: fused pair differs from two calls"
+    # and the per-row stream really is per call: rows B.. of a stacked forward differ from rows 0..B-1
+    inet.enable_inference_dropout()
+    inp = torch.randn(B, inet.num_input_channels, 32, 64, generator=g).cuda()
+    c = torch.randn(B, n_forc, 32, 64, generator=g).cuda()
+    t = torch.full((2 * B,), 2.0).cuda()
+    y = inet(torch.cat([inp, inp]), time=t, static_condition=torch.cat([c, c]), rows_per_call=B)
+    assert not torch.equal(y[:B], y[B:])
+    inet.disable_inference_dropout()
+    with pytest.raises(AssertionError):
+        inet(torch.cat([inp, inp]), time=t, static_condition=torch.cat([c, c]), rows_per_call=4)
