@@ -92,10 +92,23 @@ def test_call_trace_is_16_forwards():
     f_net.forward = lambda *a, **k: (trace.append(("F", float(k["time"][0]))), f_orig(*a, **k))[1]
     i_net.forward = lambda *a, **k: (trace.append(("I", float(k["time"][0]))), i_orig(*a, **k))[1]
     x0 = torch.randn(1, cs, 32, 64).cuda()
-    exp.model.sample(x0, dynamical_condition=torch.randn(1, 7, n_forc, 32, 64).cuda())
+    dyn = torch.randn(1, 7, n_forc, 32, 64).cuda()
+    exp.model.fuse_interpolator_pair_max_batch = 0       # the reference's own sequence: one forward per call
+    exp.model.sample(x0, dynamical_condition=dyn)
     expect = [("F", 0.0), ("I", 1.0), ("F", 1.0), ("I", 2.0), ("I", 1.0), ("F", 2.0), ("I", 3.0), ("I", 2.0),
               ("F", 3.0), ("I", 4.0), ("I", 3.0), ("F", 4.0), ("I", 5.0), ("I", 4.0), ("F", 5.0), ("I", 5.0)]
     assert trace == expect
+    # small batches stack the two interpolations of a step (times s + 1 and s) into one forward of 2B rows: 12 launches of
+    # the network for the same 16 calls, in the same call order (row blocks: [s + 1 | s])
+    del trace[:]
+    f_net.forward = lambda *a, **k: (trace.append(("F", [float(k["time"][0])])), f_orig(*a, **k))[1]
+    i_net.forward = lambda *a, **k: (trace.append(("I", [float(v) for v in k["time"]])), i_orig(*a, **k))[1]
+    exp.model.fuse_interpolator_pair_max_batch = 8
+    f_net._call = i_net._call = 0
+    exp.model.sample(x0, dynamical_condition=dyn)
+    assert trace == [("F", [0.0]), ("I", [1.0]), ("F", [1.0]), ("I", [2.0, 1.0]), ("F", [2.0]), ("I", [3.0, 2.0]), ("F", [3.0]),
+                     ("I", [4.0, 3.0]), ("F", [4.0]), ("I", [5.0, 4.0]), ("F", [5.0]), ("I", [5.0])]
+    assert (f_net._call, i_net._call) == (6, 10)
 
 
 def test_stepper_interpolating_prescriber_matches_oracle():
