@@ -314,6 +314,10 @@ typedef struct sdy_step_finish_args {
   const float* presc_target;          /* dev (B, T1, HW) denormalised data of the prescribed variable */
   const float* presc_mask;            /* dev (B, T1, HW) mask variable */
   int mask_value, interpolate;
+  const float* ar_init;               /* NULL, or dev (B, n_out, HW): a separate state to feed back into next_in instead of
+                                         `gen` (use_cold_sampling_for_last_step = False hands the cold-sampled state over as
+                                         "preds_autoregressive_init", stepper_multistep.py:412-418); prescribed like `gen`,
+                                         the timelines still receive `gen` */
 } sdy_step_finish_args;
 /* prescriber + unpack into the timelines + denormalise + autoregressive feedback into next_in */
 int sdy_step_finish(const sdy_step_finish_args* args, void* stream);
@@ -334,6 +338,14 @@ int sdy_lp_rel_terms(const float* gen, const sdy_var_table* targets, int t, int 
  * out: dev double [n_planes*4], zeroed by the caller. */
 int sdy_ensemble_metrics(const float* pred, const float* truth, const float* weights, int M, long member_stride,
                          int n_planes, int HW, double* out, void* stream);
+
+/* Time-mean accumulation of the inference aggregator (src/ace_inference/core/aggregator/inference/time_mean.py:97-117,
+ * _add_or_initialize_time_mean): acc[p] += scale * sum over rows (r0, r1) and times t0 <= t < T of
+ * x[r0*stride0 + r1*stride1 + t*HW + p].  x: dev, one variable of a window, (n0, n1, T, HW) with float strides for the
+ * two leading axes (members, samples; a transposed view needs no copy); acc: dev (HW) running map.  scale = 1 / (n0 * n1 *
+ * (T - t0)) gives the reference's mean over members, samples and time (t0 = 1 skips a window's initial condition). */
+int sdy_time_mean_accumulate(const float* x, int n0, long stride0, int n1, long stride1, int t0, int T, int HW, float scale,
+                             float* acc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Sticky status word of the CURRENT device.  Kernels only ever set bits; the host reads (and optionally clears) it once per

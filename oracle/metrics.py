@@ -24,3 +24,21 @@ def ensemble_metrics(truth: torch.Tensor, predicted: torch.Tensor, weights: torc
     crps = weighted_mean(skill - 0.5 * diff, weights)
     bias = weighted_mean(mean - truth, weights)
     return {"rmse": rmse, "spread": spread, "spread_skill_ratio": spread / rmse, "crps": crps, "bias": bias}
+
+
+def time_mean_maps(windows, is_ensemble: bool):
+    """Restatement of `TimeMeanAggregator.record_batch` + `_get_target_gen_pairs`
+    (`src/ace_inference/core/aggregator/inference/time_mean.py:97-160`) for one process: `windows` = [(i_time_start,
+    target {name: (S, T, H, W)}, gen {name: (S, T, H, W) or (E, S, T, H, W)})].  Returns ({name: gen map}, {name: target
+    map}).  Pinned by `tests/golden/fx_time_mean.npz` (produced by the reference's own aggregator)."""
+    tgt_acc, gen_acc, n = {}, {}, 0
+    for i_time_start, tgt, gen in windows:
+        sl = slice(1, None) if i_time_start == 0 else slice(0, None)
+        if is_ensemble:
+            gen = {k: v.mean(dim=0) for k, v in gen.items()}
+        for acc, d in ((tgt_acc, tgt), (gen_acc, gen)):
+            for k, v in d.items():
+                m = v[:, sl].mean(dim=1).mean(dim=0)
+                acc[k] = acc[k] + m if k in acc else m
+        n += 1
+    return {k: v / n for k, v in gen_acc.items()}, {k: v / n for k, v in tgt_acc.items()}

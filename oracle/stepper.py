@@ -58,6 +58,15 @@ def run_on_batch(data: Dict[str, torch.Tensor], module, in_names: List[str], out
                 gen[p] = torch.where(torch.round(mask).to(int) == prescriber["mask_value"], tn, gen[p])
         gen_steps.append(gen)
         ar = dict(gen)
+        if "preds_autoregressive_init_normed" in res:     # stepper_multistep.py:412-418: a separate state seeds the next window
+            a_t = res["preds_autoregressive_init_normed"]
+            ar = {n: a_t.select(-3, i) for i, n in enumerate(out_names)}
+            if prescriber is not None:
+                p = prescriber["prescribed_name"]
+                if prescriber.get("interpolate", False):
+                    ar[p] = mask * tn + (1 - mask) * ar[p]
+                else:
+                    ar[p] = torch.where(torch.round(mask).to(int) == prescriber["mask_value"], tn, ar[p])
         forc = {n: norm[n][:, th] for n in forcing_names}
         if hack:
             ar["HGTsfc"] = inp["HGTsfc"]

@@ -83,6 +83,7 @@ class SdyStepFinishArgs(C.Structure):
         ("presc_entry", C.c_int),
         ("presc_target", C.c_void_p), ("presc_mask", C.c_void_p),
         ("mask_value", C.c_int), ("interpolate", C.c_int),
+        ("ar_init", C.c_void_p),
     ]
 
 
@@ -176,6 +177,8 @@ SIGNATURES = {
     "sdy_cold_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdy_concat_channels": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p]),
+    "sdy_time_mean_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int,
+                                          C.c_float, C.c_void_p, C.c_void_p]),
     "sdy_status_flags": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
     "sdy_profile_enable": (C.c_int, [C.c_int]),
     "sdy_profile_stage_count": (C.c_int, []),

@@ -320,20 +320,27 @@ __global__ __launch_bounds__(256) void step_finish_kernel(const sdy_step_finish_
   if (oi >= 0) {
     g = reinterpret_cast<const f32x4*>(a.gen + ((long)b * a.n_out + oi) * a.HW)[i];
     const long toff = ((long)b * a.T1 + a.t) * a.HW;
-    if (e == a.presc_entry) {   // Prescriber.__call__ (prescriber.py:68-92)
+    f32x4 fb = g;   // what is fed back into the next step's input
+    if (a.ar_init) fb = reinterpret_cast<const f32x4*>(a.ar_init + ((long)b * a.n_out + oi) * a.HW)[i];
+    if (e == a.presc_entry) {   // Prescriber.__call__ (prescriber.py:68-92), on the prediction and on the fed-back state
       const f32x4 tv = reinterpret_cast<const f32x4*>(a.presc_target + toff)[i];
       const f32x4 mk = reinterpret_cast<const f32x4*>(a.presc_mask + toff)[i];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float tn = (tv[q] - a.mean[e]) / a.std[e];
-        if (a.interpolate)
+        if (a.interpolate) {
           g[q] = mk[q] * tn + (1.0f - mk[q]) * g[q];
-        else
-          g[q] = ((int)rintf(mk[q]) == a.mask_value) ? tn : g[q];   // torch.round = round half to even
+          fb[q] = mk[q] * tn + (1.0f - mk[q]) * fb[q];
+        } else {
+          const bool on = (int)rintf(mk[q]) == a.mask_value;   // torch.round = round half to even
+          g[q] = on ? tn : g[q];
+          fb[q] = on ? tn : fb[q];
+        }
       }
     }
     reinterpret_cast<f32x4*>(a.gen_norm_tl[e] + toff)[i] = g;
     reinterpret_cast<f32x4*>(a.gen_tl[e] + toff)[i] = g * a.std[e] + a.mean[e];
+    g = fb;
   } else {
     g = reinterpret_cast<const f32x4*>(a.prev_in + ((long)b * a.n_in + ii) * a.HW)[i];   // input-only: carried over
   }
@@ -432,6 +439,32 @@ __global__ __launch_bounds__(256) void ens_metrics_kernel(const float* __restric
 }
 
 }  // namespace
+
+// ---- time-mean accumulation (src/ace_inference/core/aggregator/inference/time_mean.py:97-117) ---------------------------
+// acc[p] += scale * sum_{r0 < n0} sum_{r1 < n1} sum_{t0 <= t < T} x[r0 * s0 + r1 * s1 + t * HW + p]: the mean over members,
+// samples and the window's time steps of one variable, added to the running (H, W) map.  One pass over the data, 16-byte
+// loads, fp32 sums per pixel (at most a few hundred terms), HBM-bound.
+__global__ __launch_bounds__(256) void time_mean_kernel(const float* __restrict__ x, int n0, long s0, int n1, long s1, int t0,
+                                                         int T, int HW4, float scale, float* __restrict__ acc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW4) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < n0; ++a)
+    for (int b = 0; b < n1; ++b) {
+      const f32x4* px = reinterpret_cast<const f32x4*>(x + (long)a * s0 + (long)b * s1) + i;
+      for (int t = t0; t < T; ++t) s += px[(long)t * HW4];
+    }
+  f32x4* pa = reinterpret_cast<f32x4*>(acc) + i;
+  *pa = *pa + s * scale;
+}
+extern "C" int sdy_time_mean_accumulate(const float* x, int n0, long stride0, int n1, long stride1, int t0, int T, int HW,
+                                        float scale, float* acc, void* stream) {
+  if (!x || !acc || n0 < 1 || n1 < 1 || T < 1 || t0 < 0 || t0 >= T || HW < 1) return SDY_ERR_ARG;
+  if ((HW & 3) || (stride0 & 3) || (stride1 & 3)) return SDY_ERR_ALIGN;
+  hipLaunchKernelGGL(time_mean_kernel, dim3((HW / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, n0, stride0, n1,
+                     stride1, t0, T, HW / 4, scale, acc);
+  return sdy_launch_status();
+}
 
 extern "C" int sdy_ensemble_metrics(const float* pred, const float* truth, const float* weights, int M, long member_stride,
                                     int n_planes, int HW, double* out, void* stream) {

@@ -50,3 +50,112 @@ def ensemble_metrics(truth: torch.Tensor, predicted: torch.Tensor, weights: torc
     spread = out[:, 1].sqrt().reshape(lead) * ((E + 1) / E) ** 0.5
     return {"rmse": rmse, "spread": spread, "spread_skill_ratio": spread / rmse, "crps": out[:, 2].reshape(lead),
             "bias": out[:, 3].reshape(lead)}
+
+
+class TorchDistributed:
+    """`reduce_mean` of the reference's `Distributed` singleton (`src/ace_inference/core/distributed.py`): mean over ranks
+    with `torch.distributed.all_reduce` (RCCL over xGMI on the GPU box; identity without a process group).  The reduce is
+    issued on a side stream: it belongs to `get_logs`, not to the sampling path, and never blocks the compute stream."""
+
+    def __init__(self):
+        import torch.distributed as dist
+
+        self._dist = dist if dist.is_available() and dist.is_initialized() else None
+        self._stream = None
+
+    @property
+    def world_size(self) -> int:
+        return self._dist.get_world_size() if self._dist is not None else 1
+
+    def reduce_mean(self, tensor: torch.Tensor) -> torch.Tensor:
+        if self._dist is None:
+            return tensor
+        if not tensor.is_cuda:
+            out = tensor.clone()
+            self._dist.all_reduce(out)
+            return out / self.world_size
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=tensor.device)
+        self._stream.wait_stream(torch.cuda.current_stream(tensor.device))
+        with torch.cuda.stream(self._stream):
+            out = tensor.clone()
+            self._dist.all_reduce(out)
+            out /= self.world_size
+        torch.cuda.current_stream(tensor.device).wait_stream(self._stream)
+        return out
+
+
+class TimeMeanAggregator:
+    """Statistics on the time-mean state: host mirror of `TimeMeanAggregator`
+    (`src/ace_inference/core/aggregator/inference/time_mean.py:45-173`) minus its plots.
+
+    Same constructor keywords that matter (`area_weights`, `dist`, `target`, `is_ensemble`), same `record_batch(loss,
+    target_data, gen_data, target_data_norm, gen_data_norm, i_time_start)` (what `run_inference` calls once per window) and
+    the same numbers from `get_logs(label)`: `rmse/<name>`, `bias/<name>`, `rmse/channel_mean` of the time-mean maps.  The
+    maps stay on the device (`time_mean_maps()`), one HIP launch per variable and window adds a window's mean over members,
+    samples and time (`sdy_time_mean_accumulate`, strided views welcome); `get_logs` reduces the maps over ranks
+    (`dist.reduce_mean`) and takes RMSE / bias with `sdy_ensemble_metrics`.  The matplotlib / wandb images of the reference
+    are out of scope."""
+
+    def __init__(self, area_weights: torch.Tensor, dist=None, target: str = "denorm", metadata=None,
+                 log_individual_channels: bool = True, is_ensemble: bool = False):
+        if target not in ("norm", "denorm"):
+            raise ValueError(f"target must be 'norm' or 'denorm', got {target!r}")
+        self._area_weights = area_weights
+        self._is_ensemble = is_ensemble
+        self._target = target
+        self._log_individual_channels = log_individual_channels
+        self._dist = TorchDistributed() if dist is None else dist
+        self._target_data: Dict[str, torch.Tensor] = {}
+        self._gen_data: Dict[str, torch.Tensor] = {}
+        self._n_batches = 0
+
+    @staticmethod
+    def _accumulate(maps: Dict[str, torch.Tensor], data, t0: int, ensemble: bool) -> None:
+        for name, v in data.items():
+            if not v.is_cuda:
+                raise RuntimeError("sdy_amd aggregators run on the GPU only (no CPU fallback)")
+            v = v.to(torch.float32)
+            if ensemble:
+                assert v.dim() == 5, "ensemble data are (members, samples, time, lat, lon)"
+                n0, n1, T, H, W = v.shape
+            else:
+                assert v.dim() == 4, "data are (samples, time, lat, lon)"
+                (n1, T, H, W), n0 = v.shape, 1
+            if v.stride(-1) != 1 or v.stride(-2) != W or v.stride(-3) != H * W:
+                v = v.contiguous()
+            s0, s1 = (v.stride(0), v.stride(1)) if ensemble else (0, v.stride(0))
+            if name not in maps:
+                maps[name] = torch.zeros(H, W, dtype=torch.float32, device=v.device)
+            with torch.cuda.device(v.device):
+                check(lib.sdy_time_mean_accumulate(ptr(v), n0, s0, n1, s1, t0, T, H * W, 1.0 / (n0 * n1 * (T - t0)),
+                                                   ptr(maps[name]), current_stream()), "sdy_time_mean_accumulate")
+
+    @torch.no_grad()
+    def record_batch(self, loss, target_data, gen_data, target_data_norm, gen_data_norm, i_time_start: int = 0):
+        if self._target == "norm":
+            target_data, gen_data = target_data_norm, gen_data_norm
+        t0 = 1 if i_time_start == 0 else 0          # the very first time of a run is the initial condition
+        self._accumulate(self._target_data, target_data, t0, ensemble=False)
+        self._accumulate(self._gen_data, gen_data, t0, ensemble=self._is_ensemble)
+        self._n_batches += 1
+
+    def time_mean_maps(self) -> Dict[str, Dict[str, torch.Tensor]]:
+        """{"gen": {name: (H, W)}, "target": {...}}: time means so far, reduced over ranks, on the device."""
+        if self._n_batches == 0:
+            raise ValueError("No data recorded.")
+        red = lambda d: {k: self._dist.reduce_mean(v / self._n_batches) for k, v in d.items()}  # noqa: E731
+        return {"gen": red(self._gen_data), "target": red(self._target_data)}
+
+    @torch.no_grad()
+    def get_logs(self, label: str) -> Dict[str, float]:
+        maps = self.time_mean_maps()
+        logs, rmse_all = {}, {}
+        for name, gen in maps["gen"].items():
+            m = ensemble_metrics(maps["target"][name], gen[None], self._area_weights)     # one "member": RMSE and bias of a map
+            rmse_all[name] = float(m["rmse"])
+            if self._log_individual_channels:
+                logs[f"rmse/{name}"] = rmse_all[name]
+                logs[f"bias/{name}"] = float(m["bias"])
+        logs["rmse/channel_mean"] = sum(rmse_all.values()) / len(rmse_all)
+        return {f"{label}/{k}": v for k, v in logs.items()} if len(label) != 0 else logs

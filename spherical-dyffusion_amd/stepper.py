@@ -147,11 +147,12 @@ class MultiStepStepper:
                 g = res[f"t{h}_preds_normed"].contiguous()
                 check(lib.sdy_lp_rel_terms(ptr(g), C.byref(out_tab), th, T1, B, HW, ptr(loss_terms[th - 1]), stream()),
                       "sdy_lp_rel_terms")
-                if "preds_autoregressive_init_normed" in res:
-                    raise NotImplementedError("use_cold_sampling_for_last_step=False (separate AR-init tensor, "
-                                              "stepper_multistep.py:412-418) is outside the shipped configuration")
+                ar = None
+                if "preds_autoregressive_init_normed" in res:   # the state handed to the next window differs from the
+                    ar = res["preds_autoregressive_init_normed"].contiguous()   # prediction (stepper_multistep.py:412-418)
                 nxt = torch.empty_like(state)
                 fa.t, fa.gen, fa.prev_in, fa.next_in = th, ptr(g), ptr(state), ptr(nxt)
+                fa.ar_init = ptr(ar)
                 check(lib.sdy_step_finish(C.byref(fa), stream()), "sdy_step_finish")
                 state = nxt
                 if n_f:

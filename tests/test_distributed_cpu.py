@@ -99,3 +99,31 @@ def test_two_rank_ragged_ic_member_split():
     from sdy_amd import ensemble
     s, c, rows, mem, rect = ensemble.plan_rows(n_ics, members)
     assert rect and [s + i for i in range(c)] == glob and list(zip(rows, mem)) == units
+
+
+def _reduce_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sdy_amd.metrics import TorchDistributed
+
+    d = TorchDistributed()
+    m = d.reduce_mean(torch.full((4, 8), float(rank + 1)))          # a rank's time-mean map
+    ret[rank] = (d.world_size, m)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_time_mean_maps_reduce_over_ranks():
+    """The aggregator's only collective (off the sampling path): `reduce_mean` of the (H, W) maps over ranks, as the
+    reference's Distributed.reduce_mean (time_mean.py:147-148)."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reduce_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in range(2):
+        assert ret[r][0] == 2 and torch.equal(ret[r][1], torch.full((4, 8), 1.5))
+    from sdy_amd.metrics import TorchDistributed
+    assert TorchDistributed().reduce_mean(torch.ones(2)).tolist() == [1.0, 1.0]     # no process group: identity
+

@@ -368,3 +368,88 @@ def test_fused_interpolator_pair_equals_two_calls(hack):
     inet.disable_inference_dropout()
     with pytest.raises(AssertionError):
         inet(torch.cat([inp, inp]), time=t, static_condition=torch.cat([c, c]), rows_per_call=4)
+
+
+def test_stepper_autoregressive_init_handoff():
+    """use_cold_sampling_for_last_step = False (dyffusion.py:503-510): the last prediction of a window is the plain forecast,
+    while the cold-sampled state is handed to the next window as `preds_autoregressive_init` (stepper_multistep.py:412-418),
+    prescribed like the prediction.  Two windows, so the handed-over state matters; vs the oracle stepper + sampler."""
+    import sdy_amd
+    from oracle.stepper import run_on_batch
+
+    C, n_forc, hz = 6, 2, 6
+    fcfg = SFNOConfig(in_chans=C + n_forc, out_chans=C, nlat=32, nlon=64, embed_dim=16, num_layers=2, with_time_emb=True,
+                      min_time=0.0, max_time=hz - 1.0)
+    icfg = SFNOConfig(in_chans=2 * C + n_forc, out_chans=C, nlat=32, nlon=64, embed_dim=16, num_layers=2, with_time_emb=True,
+                      min_time=1.0, max_time=hz - 1.0)
+    fnet, fora, _ = make_pair(fcfg, C, n_forc, seed=11)
+    inet, iora, _ = make_pair(icfg, 2 * C, n_forc, seed=22)
+    exp = sdy_amd.MultiHorizonForecastingDYffusion(
+        fnet, sdy_amd.InterpolationExperiment(inet, horizon=hz), horizon=hz,
+        diffusion_config=dict(use_cold_sampling_for_last_step=False, enable_interpolator_dropout=False))
+    oracle = OracleDYffusion(lambda x, time, condition=None, static_condition=None: fora(x, time=time, condition=condition,
+                                                                                          static_condition=static_condition),
+                             lambda x, time, condition=None, static_condition=None: iora(x, time=time, condition=condition,
+                                                                                          static_condition=static_condition),
+                             timesteps=hz, use_cold_sampling_for_last_step=False)
+    names = [f"v{i}" for i in range(C)]
+    forcing = ["f0", "f1"]
+    g = torch.Generator(device="cpu").manual_seed(8)
+    B, T1 = 2, 13
+    means = {n: 0.2 * i for i, n in enumerate(names + forcing)}
+    stds = {n: 1.0 + 0.1 * i for i, n in enumerate(names + forcing)}
+    data = {n: torch.randn(B, T1, 32, 64, generator=g) * stds[n] + means[n] for n in names + forcing}
+    data["frac"] = torch.rand(B, T1, 32, 64, generator=g)
+    pres = dict(prescribed_name="v2", mask_name="frac", mask_value=1, interpolate=True)
+
+    class OMod:   # the reference module's surface around the oracle sampler: forcings ride as the dynamical condition
+        true_horizon = hz
+        from contextlib import nullcontext
+        ema_scope = inference_dropout_scope = staticmethod(nullcontext)
+
+        def __init__(self):
+            self.cache = None
+
+        def get_preds_at_t_for_batch(self, batch, horizon, **kw):
+            if horizon == 1:
+                self.cache = oracle.sample(batch["dynamics"], static_condition=batch.get("static_condition"))
+            out = {f"t{horizon}_preds_normed": self.cache[f"t{horizon}_preds"]}
+            if horizon == hz:
+                out["preds_autoregressive_init_normed"] = self.cache["preds_autoregressive_init"]
+            return out
+
+    # without the input-only HGTsfc channel the stepper passes no forcings (stepper_multistep.py:383-384): a network without
+    # conditioning would be needed; keep the forcings by driving both sides through a thin wrapper that adds them
+    class WithForcing:
+        def __init__(self, inner):
+            self.inner, self.true_horizon = inner, inner.true_horizon
+            self.model = inner.model if hasattr(inner, "model") else None
+            self.ema_scope, self.inference_dropout_scope = inner.ema_scope, inner.inference_dropout_scope
+            self.forc = None
+
+        def get_preds_at_t_for_batch(self, batch, horizon, **kw):
+            batch = dict(batch, static_condition=self.forc.to(batch["dynamics"].device))
+            return self.inner.get_preds_at_t_for_batch(batch, horizon=horizon, **kw)
+
+    forc0 = torch.stack([(data[n][:, 0] - means[n]) / stds[n] for n in forcing], dim=1)
+    om, pm = WithForcing(OMod()), WithForcing(exp)
+    om.forc = pm.forc = forc0
+    tm = {k: torch.tensor(v) for k, v in means.items()}
+    ts = {k: torch.tensor(v) for k, v in stds.items()}
+    metrics, gen, _ = run_on_batch(data, om, names, names, [], tm, ts, T1 - 1, pres, hack=False)
+    stepper = sdy_amd.MultiStepStepper(pm, names, names, [], means, stds, sdy_amd.Prescriber(**pres))
+    out = stepper.run_on_batch({k: v.cuda() for k, v in data.items()}, None, n_forward_steps=T1 - 1)
+    for n in names:
+        assert rel_l2(out.gen_data[n], gen[n]) < TOL, n
+    # the handed-over state is not the prediction: feeding the prediction back instead gives another second window
+    class NoHandoff(WithForcing):
+        def get_preds_at_t_for_batch(self, batch, horizon, **kw):
+            r = super().get_preds_at_t_for_batch(batch, horizon, **kw)
+            r.pop("preds_autoregressive_init_normed", None)
+            return r
+    nh = NoHandoff(exp)
+    nh.forc = forc0
+    out2 = sdy_amd.MultiStepStepper(nh, names, names, [], means, stds, sdy_amd.Prescriber(**pres)).run_on_batch(
+        {k: v.cuda() for k, v in data.items()}, None, n_forward_steps=T1 - 1)
+    assert rel_l2(out2.gen_data["v0"][:, :7], gen["v0"][:, :7]) < TOL
+    assert rel_l2(out2.gen_data["v0"][:, 7:], gen["v0"][:, 7:]) > 1e-3

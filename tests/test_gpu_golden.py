@@ -292,3 +292,38 @@ def test_ensemble_metrics_vs_reference():
         assert torch.allclose(got[k].cpu(), ref[k], rtol=1e-5, atol=1e-7), k
     with pytest.raises(RuntimeError):
         sdy_amd.metrics.ensemble_metrics(truth, pred, w)     # CPU tensors: no fallback
+
+
+def test_time_mean_aggregator_vs_reference():
+    """sdy_amd.metrics.TimeMeanAggregator (device-resident maps, one HIP launch per variable and window, strided member
+    views) vs the reference's own TimeMeanAggregator fed the same two windows (fx_time_mean.npz)."""
+    import sdy_amd
+
+    z = gu.load("fx_time_mean")
+    names = json.loads(str(z["names"]))
+    W = z["ens::gen_map::a"].shape[-1]
+    w = sdy_amd.metrics.spherical_area_weights(torch.from_numpy(z["lats"]), W)
+    for key, ens in (("ens", True), ("det", False)):
+        agg = sdy_amd.metrics.TimeMeanAggregator(w, is_ensemble=ens)
+        for i in range(2):
+            tgt = {n: torch.from_numpy(z[f"{key}::tgt{i}::{n}"]).cuda() for n in names}
+            gen = {n: torch.from_numpy(z[f"{key}::gen{i}::{n}"]).cuda() for n in names}
+            if ens:   # the window driver hands over (members, samples, ...) as a TRANSPOSED view of its IC-major batch
+                gen = {n: v.transpose(0, 1).contiguous().transpose(0, 1) for n, v in gen.items()}
+                assert not gen[names[0]].is_contiguous()
+            agg.record_batch(0.0, tgt, gen, tgt, gen, i_time_start=int(z[f"{key}::i_time_start{i}"]))
+        maps = agg.time_mean_maps()
+        logs = agg.get_logs("inference")
+        for n in names:
+            assert rel_l2(maps["gen"][n], torch.from_numpy(z[f"{key}::gen_map::{n}"])) < 1e-6
+            assert rel_l2(maps["target"][n], torch.from_numpy(z[f"{key}::target_map::{n}"])) < 1e-6
+            assert abs(logs[f"inference/rmse/{n}"] - float(z[f"{key}::rmse::{n}"])) < 1e-5
+            assert abs(logs[f"inference/bias/{n}"] - float(z[f"{key}::bias::{n}"])) < 1e-5
+        want = sum(float(z[f"{key}::rmse::{n}"]) for n in names) / len(names)
+        assert abs(logs["inference/rmse/channel_mean"] - want) < 1e-5
+    with pytest.raises(ValueError):
+        sdy_amd.metrics.TimeMeanAggregator(w).get_logs("x")
+    with pytest.raises(RuntimeError):
+        sdy_amd.metrics.TimeMeanAggregator(w).record_batch(0.0, {"a": torch.zeros(1, 2, 16, 32)}, {"a": torch.zeros(1, 2, 16, 32)},
+                                                        {}, {})
+

@@ -206,3 +206,32 @@ def test_ensemble_metrics_match_reference():
         want = torch.from_numpy(z[k]).double()
         assert got[k].shape == want.shape
         assert torch.allclose(got[k], want, rtol=2e-5, atol=1e-6), k
+
+
+def test_oracle_time_mean_vs_reference_aggregator():
+    """oracle.metrics.time_mean_maps vs the reference's own TimeMeanAggregator (fx_time_mean.npz: two windows, ensemble and
+    deterministic), and the RMSE / bias the reference derives from the maps."""
+    import json
+
+    import numpy as np
+    import torch
+
+    from oracle.metrics import time_mean_maps, weighted_mean
+
+    z = gu.load("fx_time_mean")
+    names = json.loads(str(z["names"]))
+    lats = torch.from_numpy(z["lats"])
+    W = z["ens::gen_map::a"].shape[-1]
+    w = torch.cos(torch.deg2rad(lats)).repeat(W, 1).t()
+    w = w / w.sum()
+    for key, ens in (("ens", True), ("det", False)):
+        wins = [(int(z[f"{key}::i_time_start{i}"]), {n: torch.from_numpy(z[f"{key}::tgt{i}::{n}"]) for n in names},
+                 {n: torch.from_numpy(z[f"{key}::gen{i}::{n}"]) for n in names}) for i in range(2)]
+        gen, tgt = time_mean_maps(wins, ens)
+        for n in names:
+            assert np.allclose(gen[n].numpy(), z[f"{key}::gen_map::{n}"], rtol=1e-6, atol=1e-6)
+            assert np.allclose(tgt[n].numpy(), z[f"{key}::target_map::{n}"], rtol=1e-6, atol=1e-6)
+            rmse = float(weighted_mean((gen[n] - tgt[n]).double() ** 2, w.double()).sqrt())
+            bias = float(weighted_mean((gen[n] - tgt[n]).double(), w.double()))
+            assert abs(rmse - float(z[f"{key}::rmse::{n}"])) < 1e-6 and abs(bias - float(z[f"{key}::bias::{n}"])) < 1e-6
+

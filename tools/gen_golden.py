@@ -397,8 +397,50 @@ def gen_metrics(tag="fx_metrics"):
     print(f"{tag}: crps[0] {out['crps'][0]}, saved")
 
 
+def gen_time_mean(tag="fx_time_mean"):
+    """The reference's own TimeMeanAggregator (src/ace_inference/core/aggregator/inference/time_mean.py) fed two windows of
+    an ensemble run the way run_inference feeds it (loop.py:133-149): time-mean maps, their RMSE and bias."""
+    from src.ace_inference.core import metrics as M
+    from src.ace_inference.core.aggregator.inference.time_mean import TimeMeanAggregator
+
+    class NoDist:            # single process: reduce_mean is the identity (core/distributed.py)
+        def reduce_mean(self, t):
+            return t
+
+    g = torch.Generator(device="cpu").manual_seed(41)
+    E, S, T, H, W = 3, 2, 4, 16, 32
+    names = ["a", "b"]
+    lats = torch.linspace(-84.375, 84.375, H)
+    w = M.spherical_area_weights(lats, W)
+    out = dict(lats=lats.numpy(), names=json.dumps(names))
+    for is_ens in (True, False):
+        agg = TimeMeanAggregator(w, dist=NoDist(), is_ensemble=is_ens)
+        key = "ens" if is_ens else "det"
+        for win, (i_time_start, nt) in enumerate(((0, T + 1), (T + 1, T))):
+            tgt = {n: torch.randn(S, nt, H, W, generator=g) * 2.0 + 1.0 for n in names}
+            shp = (E, S, nt, H, W) if is_ens else (S, nt, H, W)
+            gen = {n: (tgt[n][None] if is_ens else tgt[n]) + torch.randn(*shp, generator=g) * 0.5 + 0.2 for n in names}
+            agg.record_batch(loss=0.0, target_data=tgt, gen_data=gen, target_data_norm=tgt, gen_data_norm=gen,
+                             i_time_start=i_time_start)
+            for n in names:
+                out[f"{key}::tgt{win}::{n}"] = tgt[n].numpy()
+                out[f"{key}::gen{win}::{n}"] = gen[n].numpy()
+            out[f"{key}::i_time_start{win}"] = i_time_start
+        for pr in agg._get_target_gen_pairs():
+            out[f"{key}::gen_map::{pr.name}"] = pr.gen.numpy()
+            out[f"{key}::target_map::{pr.name}"] = pr.target.numpy()
+            out[f"{key}::rmse::{pr.name}"] = pr.rmse(weights=w)
+            out[f"{key}::bias::{pr.name}"] = pr.weighted_mean_bias(weights=w)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"{tag}: ens rmse a {out['ens::rmse::a']}, saved")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:      # regenerate selected fixtures only: python tools/gen_golden.py gen_time_mean
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     # C1: one block, 32x64, 8 channels (BASELINE.json configs[0])
     gen_sfno("fx_block_c1", SFNOConfig(in_chans=8, out_chans=8, nlat=32, nlon=64, embed_dim=8, num_layers=1,
                                        with_time_emb=True, min_time=0.0, max_time=5.0), 8, 0, 2, [1.0, 4.0], 4321, False)
@@ -418,5 +460,6 @@ if __name__ == "__main__":
     gen_loop()
     gen_ckpt_layout()
     gen_metrics()
+    gen_time_mean()
     sizes = {n: os.path.getsize(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT))}
     print(sizes)
