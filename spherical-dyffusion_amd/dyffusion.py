@@ -182,6 +182,12 @@ class DYffusion(torch.nn.Module):
             out = ops.concat_channels([initial_condition[:, :1], out])
         return out
 
+    def _can_stack_calls(self) -> bool:
+        """Stacked calls need a network that numbers its dropout calls per row (`rows_per_call`); injected masks (tests that
+        replay the reference's recorded masks) address one call per forward."""
+        net = getattr(self.interpolator, "model", None)
+        return hasattr(net, "batch_offset") and getattr(net, "mask_injector", None) is None
+
     def q_sample_pair(self, x0, x_end, t_first, t_second, is_artificial_step: bool = True, **kwargs):
         """`(q_sample(t=t_first), q_sample(t=t_second))` for the same (x0, x_end) as ONE interpolator forward of 2B rows
         (reference call sites dyffusion.py:497 and :515): rows 0..B-1 carry `t_first` and the dropout stream of the first
@@ -265,7 +271,7 @@ class DYffusion(torch.nn.Module):
                     else x_hat
             else:
                 assert s_next <= last, f"Invalid s_next: {s_next} (should be <= {last})"
-                if cold and s > 0 and x_s.shape[0] <= self.fuse_interpolator_pair_max_batch:
+                if cold and s > 0 and x_s.shape[0] <= self.fuse_interpolator_pair_max_batch and self._can_stack_calls():
                     # the step's two interpolations (to s_next, then to s: the reference's call order) as one 2B forward
                     x_next, x_at_s = self.q_sample_pair(x_hat, initial_condition, s_next, s,
                                                         is_artificial_step=not lands_on_data, **dict(kwargs))

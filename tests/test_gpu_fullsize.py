@@ -91,3 +91,20 @@ def test_b25_full_depth_batch_rows_are_independent_trajectories():
             a, f = alone[f"t{k}_preds"][0], full[f"t{k}_preds"][b]
             e = rel_l2(a, f)
             assert e < 2e-6, f"row {b}, t{k}: batch row vs lone trajectory rel L2 {e:.3e} (bitwise: {torch.equal(a, f)})"
+
+
+def test_c4_rollout_25_members_through_the_window_driver():
+    """BASELINE.json configs[3] in short: 25 members of one initial condition, full grid / width / depth, two windows of 6
+    steps through run_inference -> stepper -> sampler -> SFNO with the device time-mean aggregator (tools/c4_rollout.py runs
+    the 100-step version).  No oracle at this size: finite, shapes, the driver's own throughput timer, members diverge."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import c4_rollout
+
+    r = c4_rollout.run(torch.device("cuda", 0), steps=12, members=25)
+    assert r["finite"] and r["windows"] == 2
+    assert r["prediction_shape"] == (25, 1, 6, NLAT, NLON)          # second window: initial time dropped, members stacked
+    assert r["member_forecast_steps_per_s"] > 10.0
+    assert r["time_mean_rmse_channel_mean"] > 0.0
