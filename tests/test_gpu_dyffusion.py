@@ -386,12 +386,13 @@ def test_stepper_autoregressive_init_handoff():
     inet, iora, _ = make_pair(icfg, 2 * C, n_forc, seed=22)
     exp = sdy_amd.MultiHorizonForecastingDYffusion(
         fnet, sdy_amd.InterpolationExperiment(inet, horizon=hz), horizon=hz,
-        diffusion_config=dict(use_cold_sampling_for_last_step=False, enable_interpolator_dropout=False))
+        diffusion_config=dict(use_cold_sampling_for_last_step=False, use_cold_sampling_for_init_of_ar_step=True,
+                              enable_interpolator_dropout=False))
     oracle = OracleDYffusion(lambda x, time, condition=None, static_condition=None: fora(x, time=time, condition=condition,
                                                                                           static_condition=static_condition),
                              lambda x, time, condition=None, static_condition=None: iora(x, time=time, condition=condition,
                                                                                           static_condition=static_condition),
-                             timesteps=hz, use_cold_sampling_for_last_step=False)
+                             timesteps=hz, use_cold_sampling_for_last_step=False, use_cold_sampling_for_init_of_ar_step=True)
     names = [f"v{i}" for i in range(C)]
     forcing = ["f0", "f1"]
     g = torch.Generator(device="cpu").manual_seed(8)
