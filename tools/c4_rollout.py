@@ -62,7 +62,7 @@ def windows(names, n_windows, window, nlat, nlon, seed=1234):
         yield types.SimpleNamespace(data=data, times=None)
 
 
-def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=360, aggregate=True):
+def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=360, aggregate=True, warmup=True):
     import torch
 
     import sdy_amd
@@ -81,6 +81,9 @@ def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=36
             finite["ok"] = finite["ok"] and bool(torch.isfinite(v).all())
             finite["shape"] = tuple(v.shape)
 
+    if warmup:   # one untimed window: native objects, weight upload and the workspace are created on first use (~8 s)
+        sdy_amd.run_inference(None, stepper, windows(names, 1, window, nlat, nlon, seed=7), window, window,
+                              n_ensemble_members=members, eval_device=device)
     t0 = time.perf_counter()
     timers = sdy_amd.run_inference(agg, stepper, windows(names, steps // window, window, nlat, nlon), steps, window,
                                    n_ensemble_members=members, eval_device=device, writer=Writer())
