@@ -241,8 +241,12 @@ def latency_b1(exp, device):
 
     c2 = timed(fwd, 10)
     c3 = timed(lambda: one_pass(exp, x, f), 3)
+    # how dense is the stream at B = 1?  kernel time of one pass (HIP events around every launch) against its wall time:
+    # a ratio near 1 means there are no launch gaps for a HIP graph to remove
+    _, kernel_ms = profile_pass(exp, x, f, 1)
     return {"c2_interpolator_forward_b1_ms": round(c2, 3), "c3_horizon6_pass_b1_ms": round(c3, 2),
-            "c3_forecast_steps_per_s_b1": round(HORIZON / (c3 * 1e-3), 2)}
+            "c3_forecast_steps_per_s_b1": round(HORIZON / (c3 * 1e-3), 2),
+            "c3_kernel_ms_b1": round(kernel_ms, 2), "c3_stream_density_b1": round(kernel_ms / c3, 3)}
 
 
 def cpu_baseline(oracles, threads):
