@@ -164,7 +164,7 @@ typedef struct sdy_conv_args {
   const void* w_h3;                  /* dev, optional: weight packed by sdy_h3_pack_weight -> the GEMM runs on the f16
                                         matrix cores in split precision (3 passes, fp32-class accuracy); wt may be NULL */
   float w_h3_scale;                  /* scale returned by sdy_h3_pack_weight */
-  const void* w_frag;                /* dev, optional, Cout == 256, Cin <= 256 (a pre-affine pa/pd needs Cin == 256): weight packed by sdy_conv256_h3_pack[_cin] -> the
+  const void* w_frag;                /* dev, optional, Cout == 256, Cin <= 384 (a pre-affine pa/pd needs Cin == 256): weight packed by sdy_conv256_h3_pack[_cin] -> the
                                         persistent fragment-stream kernel (no dropout / batch_scale / keep_mask) */
   float w_frag_scale;
   double* stats;                     /* dev [B*Cout*2] or NULL, w_frag path only: (sum, sum of squares) over HW of every
@@ -178,9 +178,10 @@ int sdy_conv1x1(const sdy_conv_args* args, void* stream);
  * (*scale) chosen so that max|w|*scale is in [2^12, 2^13). */
 /* 256 -> 256 weight (Cout, Cin) row-major -> per-wave MFMA fragment stream for sdy_conv_args.w_frag */
 int sdy_conv256_h3_supported(int Cin, int Cout);
-size_t sdy_conv256_h3_pack_bytes(void);
+size_t sdy_conv256_h3_pack_bytes(void);                                                    /* for Cin <= 256 */
+size_t sdy_conv256_h3_pack_bytes_cin(int Cin);                                             /* for any supported Cin */
 int sdy_conv256_h3_pack(const float* w_host, void* packed_dev, float* scale);             /* (256, 256) weight */
-int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* packed_dev, float* scale); /* (256, Cin), Cin <= 256 */
+int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* packed_dev, float* scale); /* (256, Cin), Cin <= 384 */
 size_t sdy_h3_pack_bytes(int Cout, int Cin);
 int sdy_h3_pack_weight(const float* w_host, int Cout, int Cin, void* packed_dev, float* scale);
 

@@ -156,6 +156,7 @@ SIGNATURES = {
     "sdy_mlp_h3": (C.c_int, [C.POINTER(SdyMlpArgs), C.c_void_p]),
     "sdy_conv256_h3_supported": (C.c_int, [C.c_int, C.c_int]),
     "sdy_conv256_h3_pack_bytes": (C.c_size_t, []),
+    "sdy_conv256_h3_pack_bytes_cin": (C.c_size_t, [C.c_int]),
     "sdy_conv256_h3_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "sdy_conv256_h3_pack_cin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "sdy_h3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -623,7 +623,9 @@ static int dev_upload_conv(DevBuf& b, const float* host, int out, int in, int ld
     SDY_TRY(sdy_h3_pack_weight(host, out, in, b.h3, &b.h3_scale));
     static const bool only256 = std::getenv("SDY_CONV_FRAG_256_ONLY") != nullptr;   // A/B: encoders on the tile GEMM
     if (sdy_conv256_h3_supported(in, out) && !(only256 && in != 256)) {
-      if (!b.frag) SDY_HIP_TRY(hipMalloc(&b.frag, sdy_conv256_h3_pack_bytes()));
+      if (b.frag) (void)hipFree(b.frag);
+      b.frag = nullptr;
+      SDY_HIP_TRY(hipMalloc(&b.frag, sdy_conv256_h3_pack_bytes_cin(in)));
       SDY_TRY(sdy_conv256_h3_pack_cin(host, in, b.frag, &b.frag_scale));
     }
   }

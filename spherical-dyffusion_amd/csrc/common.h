@@ -88,6 +88,29 @@ __device__ __forceinline__ void sdy_flag_range(unsigned* flags, float amax) {
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// 16-byte global access as (wave-uniform 64-bit base in SGPRs) + (32-bit byte offset per lane): the SADDR form of
+// global_load / global_store.  The persistent kernels address rows as image base + row * HW + lane part; written as plain
+// pointer arithmetic hipcc re-associates that into one 64-bit lane address PER ROW, hoists all of them out of the tile loop
+// and spills them.  The empty asm pins the base to SGPRs (so the row step is scalar arithmetic) and hides it from the
+// re-association; the explicit global address space keeps the access from degrading to FLAT.  `ubase` must be wave-uniform.
+typedef const char __attribute__((address_space(1)))* sdy_gcptr_t;
+typedef char __attribute__((address_space(1)))* sdy_gptr_t;
+typedef f32x4 __attribute__((address_space(1))) sdy_gf32x4;
+__device__ __forceinline__ f32x4 sdy_ld16s(const float* ubase, unsigned off_b) {
+  sdy_gcptr_t b = (sdy_gcptr_t)ubase;
+  asm volatile("" : "+s"(b), "+v"(off_b));   // (the offset too: its zero-extension must sit in the block of the access)
+  return *reinterpret_cast<const sdy_gf32x4*>(b + off_b);
+}
+__device__ __forceinline__ void sdy_st16s(float* ubase, unsigned off_b, f32x4 v) {
+  sdy_gptr_t b = (sdy_gptr_t)ubase;
+  asm volatile("" : "+s"(b), "+v"(off_b));
+#ifdef SDY_NT_STORE
+  __builtin_nontemporal_store(v, reinterpret_cast<sdy_gf32x4*>(b + off_b));
+#else
+  *reinterpret_cast<sdy_gf32x4*>(b + off_b) = v;
+#endif
+}
+
 // ---- exact-erf GELU (nn.GELU default, src/models/sfno/sfnonet.py:602-603) ------------------------------
 // erfc(z), z >= 0, by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7): one v_rcp_f32, one v_exp_f32 and a
 // 5-term Horner chain instead of ocml's branchy erff (~4x fewer VALU cycles in the GEMM epilogues).  Using the
@@ -201,7 +224,8 @@ int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, in
 
 // ---- persistent 256 -> 256 convolution (conv_h3.hip)
 int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream);
-extern "C" int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* dev, float* scale);   // (256, Cin) weight, Cin <= 256
+extern "C" int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* dev, float* scale);   // (256, Cin) weight, Cin <= 384
+extern "C" size_t sdy_conv256_h3_pack_bytes_cin(int Cin);
 // dh_h3.hip: fragment-stream pack of the dhconv weight; ilv = channel order of the 2C axis (fft.h)
 int sdy_dh_h3_pack(const float* w_host, int L, void* packed_dev, float* scale, int ilv);
 int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B, int ilv,

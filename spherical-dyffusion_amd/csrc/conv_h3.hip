@@ -1,17 +1,20 @@
-// Cin (<= 256) -> 256 channel 1x1 convolution (the block's inner skip, both encoder layers) as a persistent split-fp16
-// kernel in the style of mlp_h3.hip:
+// Cin (<= 384) -> 256 channel 1x1 convolution (the block's inner skip, both encoder layers, the decoder's first layer) as a
+// persistent split-fp16 kernel in the style of mlp_h3.hip:
 //   out[b] = act( W . (pa[b]*x[b] + pd[b]) + bias + add_pre[b] ) + add_post[b]        (+ InstanceNorm statistics of out)
 //   * one workgroup owns 64 pixels and all 256 output rows; the activation tile is fetched once, split hi/lo and
-//     parked in LDS ([px][k], XOR-swizzled); wave w computes rows 64w .. 64w+63 (2 x 2 MFMA tiles, K = 256);
+//     parked in LDS ([px][k], XOR-swizzled); wave w computes 256 / NW rows (1 or 2 x 2 MFMA tiles);
 //   * the weight never touches LDS: packed per wave as a linear stream of MFMA A-fragment pairs (hi, lo) in consumption
-//     order, L2 -> registers through an 8-group ring;
-//   * the epilogue goes through LDS so that the addend loads and the stores are 16-byte row segments, applies
-//     bias / addend / GELU there, and keeps per-thread (sum, sum of squares) of what it stores: the workgroup is
-//     persistent (a contiguous range of tiles), so the statistics cost one fp64 atomic pair per row and IMAGE
-//     instead of one per tile -- the next InstanceNorm (norm1) needs no pass of its own over the tensor.
-// One workgroup per CU, software-pipelined over its tiles (see the tile loop).
+//     order, L2 -> registers through a 4-group ring;
+//   * the accumulators start from the bias; the epilogue goes through LDS so that the addend loads and the stores are
+//     16-byte row segments, applies addend / GELU there, and sums what it stores per row: DPP over the 16 lanes that share
+//     a row, then one fp64 pair per row in LDS, flushed with one atomic pair per row and IMAGE (the workgroup is persistent
+//     over a contiguous range of tiles) -- the next InstanceNorm (norm1) needs no pass of its own over the tensor.
+// Cin <= 256: 4 waves, <= 256 registers, 69 KB of LDS -> TWO workgroups per CU.  They are independent (no barrier couples
+// them), drift apart, and one's MFMA phase / barriers / LDS passes run under the other's HBM traffic (+2..7 % over one
+// 8-wave workgroup per CU).  256 < Cin <= 384 (decoder: [block output | inputs]): 8 waves, one workgroup per CU, 96 KB tile.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -23,52 +26,75 @@ typedef const f16x8 __attribute__((address_space(1)))* wptr_t;
 
 namespace {
 
-constexpr int CE = 256;          // channels in = out
+constexpr int CE = 256;          // output channels
 constexpr int CTN = 64;          // pixels per tile
-constexpr int CKS = CE / 16;     // k-steps
-// Waves per workgroup.  8 = two per SIMD: the arbiter then fills one wave's LDS / memory waits and its VALU-only phases
-// (fp16 split of the tile, GELU + statistics of the store loop) with the other wave's instructions; with 4 waves every
-// phase of the tile ran alone on its SIMD (dh_h3.hip has the measurements that led here).
-#ifndef SDY_CONV_NW
-#define SDY_CONV_NW 8
-#endif
-constexpr int CNW = SDY_CONV_NW;
-static_assert(CNW == 4 || CNW == 8, "4 or 8 waves");
-constexpr int CNT = 64 * CNW;    // threads
-constexpr int CMT = 8 / CNW;     // 32-row output tiles per wave
-constexpr int COC = 8 / CNW;     // channel octets per thread in the staging role (octets o0 + 4 CNW * oc)
-constexpr int CRPT = 64 / CNW;   // output rows per thread in the store loop (rows o0 + 4 CNW * i)
-constexpr int CRS = 4 * CNW;     // = range of o0 = tid / 16
-constexpr int CRING = 4 * CMT;   // groups in flight (4 k-steps x CMT m-tiles)
-constexpr int CGPW = CMT * CKS;  // groups per wave
-constexpr int CGROUP = 2 * 64;   // f16x8 elements per group
+constexpr int CKMAX = 384;       // input channels supported
+constexpr int CRING = 4;         // weight groups in flight: one "window" of the stream
+constexpr int CGROUP = 2 * 64;   // f16x8 elements per group (hi | lo)
 constexpr float CSX = 16.0f;
+constexpr int CSTAT_BYTES = CE * 2 * 8;
+
+// Tiling for NW waves per workgroup and KBLK k-blocks of 64 input channels.
+template <int KBLK, int NW>
+struct ConvCfg {
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static constexpr int NT = 64 * NW;                    // threads
+  static constexpr int MT = 8 / NW;                     // 32-row output tiles per wave
+  static constexpr int RS = 4 * NW;                     // range of o0 = tid / 16: staging octets o0 + RS oc, rows o0 + RS i
+  static constexpr int OC = (8 * KBLK + RS - 1) / RS;   // channel octets per thread in the staging role
+  static constexpr int RPT = 64 / NW;                   // output rows per thread in the store loop
+  static constexpr int PPI = (8 * OC + RPT - 1) / RPT;  // x pieces prefetched per store-loop step
+  static constexpr int KROW = KBLK <= 4 ? 256 : 384;   // LDS row length in halfs (the swizzle permutes whole groups of 16 chunks)
+  static constexpr int KSW = KROW / 16;                 // k-steps per wave in the packed stream (zero-padded)
+  static constexpr int GPK = 4 * MT;                    // groups per k-block of 4 k-steps
+  static constexpr int GPW = MT * KSW;                  // groups per wave
+  static constexpr int WGS = NW == 4 ? 2 : 1;           // workgroups per CU
+  static constexpr int TILE_BYTES = 2 * CTN * KROW * 2; // hi + lo
+  static constexpr int LDS_BYTES = TILE_BYTES + CSTAT_BYTES + CE * 4;
+};
 
 struct ConvParams {
   const float* x; long x_bs;
   const float* pa; const float* pd;
-  const f16x8* w;                  // [CNW waves][CGPW groups][hi | lo][64 lanes]
+  const f16x8* w;                  // [NW waves][GPW groups][hi | lo][64 lanes]
   const float* bias;
   const float* add; long add_bs; int add_mode;   // 1: before the activation, 2: after it
   int act;
   float* out; long out_bs;
   double* stats;
   int HW, B;
-  int Cin;                         // input channels (<= 256; the weight stream is zero-padded to KBLK * 64)
+  int Cin;                         // input channels (the weight stream is zero-padded to KBLK * 64)
   float out_scale;
   unsigned* flags;                 // sticky status word (sdy_status_flags)
   unsigned long long* stamps;    // timing experiments only (SDY_CONV_STAMPS)
 };
 
 __device__ __forceinline__ int cv_swz(int px) { return (px & 15) ^ (((px >> 4) & 1) * 3); }
-__device__ __forceinline__ int cv_off(int px, int c) { return px * CE + (((c & 16) | ((c ^ cv_swz(px)) & 15)) << 3); }
+// 16-byte chunk c of pixel px in a row of KROW halfs
+template <int KROW>
+__device__ __forceinline__ int cv_off(int px, int c) { return px * KROW + (((c & ~15) | ((c ^ cv_swz(px)) & 15)) << 3); }
 
-// KBLK = ceil(Cin / 64): k-blocks of 4 k-steps actually streamed (4 for the block's 256 -> 256 convs, 2 / 3 for the encoders)
-template <int KBLK>
-__global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CTN * CE * 2];   // 64 KB
+// sum over the 16 lanes of a DPP row (all of them end up with the total)
+__device__ __forceinline__ float row16_sum(float x) {
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  x += dpp(x, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  x += dpp(x, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  x += dpp(x, std::integral_constant<int, 0x140>{});   // row_mirror
+  return x;
+}
+
+// KBLK = ceil(Cin / 64): k-blocks of 4 k-steps actually streamed (4 for the block's 256 -> 256 convs, 2 / 3 for the
+// encoders, 6 for the decoder)
+template <int KBLK, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const ConvParams p) {
+  using G = ConvCfg<KBLK, NW>;
+  constexpr int CMT = G::MT, CRS = G::RS, COC = G::OC, CRPT = G::RPT, KROW = G::KROW, CGPK = G::GPK, CGPW = G::GPW;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];   // x tile (64 / 96 KB) + 4 KB + 1 KB
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
-  _Float16* Xs_lo = Xs_hi + CTN * CE;
+  _Float16* Xs_lo = Xs_hi + CTN * KROW;
   float* Os = reinterpret_cast<float*>(smem);   // epilogue: [256 rows][64 px] fp32 (aliases the x tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -77,7 +103,7 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
   const int tpi = (p.HW + CTN - 1) / CTN;
   const int ntiles = tpi * p.B;
   // contiguous tile range per workgroup: a workgroup then crosses an image boundary at most ~once, so the per-image
-  // flush of the statistics (and the reload of per-image coefficients) is rare instead of every few tiles
+  // flush of the statistics is rare instead of every few tiles
   const int t_per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t_begin = (int)blockIdx.x * t_per;
   const int t_end = (t_begin + t_per < ntiles) ? t_begin + t_per : ntiles;
@@ -90,45 +116,46 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
     r_hi[s] = wp[s * CGROUP];
     r_lo[s] = wp[s * CGROUP + 64];
   }
-  wp += CRING * CGROUP;
+  constexpr int NWIN = KBLK * CMT;                     // windows of CRING groups per tile
+  wp = NWIN == 1 ? wbase : wbase + CRING * CGROUP;     // refill source while window 0 is consumed
 
-  float brow[CRPT];          // bias of the rows this thread stores (rows tid / 16 + CRS i): the same for every tile
-#pragma unroll
-  for (int i = 0; i < CRPT; ++i) brow[i] = p.bias ? p.bias[o0 + CRS * i] : 0.0f;
-  double psum[CRPT], psq[CRPT];   // statistics partials of those rows; fp64: sums of fp32 per-tile partials are then exact
-#pragma unroll
-  for (int i = 0; i < CRPT; ++i) { psum[i] = 0.0; psq[i] = 0.0; }
+  // bias: pre-divided by out_scale and parked in LDS once; the accumulators START from it (no registers across tiles, no
+  // add in the store loop).  Statistics: [256 rows][sum, sum of squares] fp64.
+  double* Ss = reinterpret_cast<double*>(smem + G::TILE_BYTES);
+  float* Bs = reinterpret_cast<float*>(smem + G::TILE_BYTES + CSTAT_BYTES);
+  if (tid < CE) {
+    Bs[tid] = p.bias ? p.bias[tid] / p.out_scale : 0.0f;
+    Ss[2 * tid] = 0.0; Ss[2 * tid + 1] = 0.0;
+  }
+  // (ordered before their first use by the barrier that ends the first tile's phase 0)
 
-  // Software pipeline over tiles (one workgroup per CU, full register budget).  Loads are issued ONE per step, never as
-  // a burst: a wave that issues more than the CU can keep in flight stalls at issue until HBM has delivered (a burst of
-  // 32 KB per wave measured 9-20k idle cycles).  Tile t+1's pixels (xr) and addend rows (addv, reloaded right after their
-  // use) both ride on tile t's store loop; the MFMA phase only streams the L2-resident weight ring.
+  // Software pipeline over tiles.  Loads are issued ONE per step where they ride on other work, never as a burst inside
+  // the MFMA phase: tile t+1's pixels (xr) ride on tile t's store loop; tile t's addend rows are requested when its MFMA
+  // loop has ended (their registers are the accumulators' until then) and travel during the accumulator pass through LDS;
+  // the MFMA phase only streams the L2-resident weight ring (vmcnt retires in order: an HBM load issued there makes the
+  // ring wait, measured 7.6k -> 12k cycles).
   f32x4 xr[COC][8], addv[CRPT];
-  auto x_ptr = [&](int t) {
-    const int zz = t / tpi, nn = (t - zz * tpi) * CTN;
-    return p.x + (long)zz * p.x_bs + ((nn + 4 * q0 < p.HW) ? nn + 4 * q0 : 0);   // ragged slice: clamped, zeroed later
+  // Addressing: every global access is (wave-uniform base of the image and row: SGPR arithmetic) + (ONE 32-bit byte offset per
+  // lane and tile), the SADDR form of global_load / global_store -- per-row 64-bit lane addresses (16 rows x 3 streams) would
+  // be hoisted out of the tile loop and spilled.  Lane offsets: x rows 8 o0 + e, addend / output rows o0 + CRS i.
+  auto img = [&](const float* base, long bs, int t) { return base + (long)(t / tpi) * bs; };   // uniform
+  auto lane_col = [&](int t) {   // first pixel of this lane's quad in tile t; a lane beyond the ragged edge re-reads column 0
+    const int nn = (t % tpi) * CTN + 4 * q0;
+    return nn < p.HW ? nn : 0;
   };
-  auto add_ptr = [&](int t) {
-    const int zz = t / tpi, nn = (t - zz * tpi) * CTN;
-    const int cc = nn + 4 * q0;
-    return (p.add ? p.add + (long)zz * p.add_bs : p.out + (long)zz * p.out_bs) + (long)o0 * p.HW + (cc < p.HW ? cc : 0);
-  };
+  const float* addsrc = p.add ? p.add : p.out;          // (p.out: never dereferenced without an addend, keeps it branch-free)
+  const long addsrc_bs = p.add ? p.add_bs : p.out_bs;
   if (t_begin < t_end) {
-    const float* xg = x_ptr(t_begin);
-    const float* ag = add_ptr(t_begin);
+    const float* xz = img(p.x, p.x_bs, t_begin);
+    const unsigned xo = (unsigned)(8 * o0 * p.HW + lane_col(t_begin)) * 4u;
 #pragma unroll
     for (int oc = 0; oc < COC; ++oc)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int ch = 8 * (o0 + CRS * oc) + e;
         xr[oc][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ch < p.Cin) xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)ch * p.HW);   // channels past Cin: no load
+        if (ch < p.Cin) xr[oc][e] = sdy_ld16s(xz + (long)(8 * CRS * oc + e) * p.HW, xo);   // channels past Cin: no load
       }
-#pragma unroll
-    for (int i = 0; i < CRPT; ++i) {
-      addv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.add) addv[i] = *reinterpret_cast<const f32x4*>(ag + (long)(CRS * i) * p.HW);
-    }
   }
 
   for (int tile = t_begin; tile < t_end; ++tile) {
@@ -151,6 +178,7 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
 #pragma unroll
       for (int oc = 0; oc < COC; ++oc) {
         const int c0 = 8 * (o0 + CRS * oc);
+        if (8 * CRS * oc + 8 * CRS > KROW && c0 >= KROW) continue;   // octets beyond the LDS row
         float av[8], dv[8];
         if (p.pa) {
           const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * CE + c0);
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (ok && c0 + e < p.Cin) ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
           sdy_split8(v, vh, vl, amax);
-          const int off = cv_off(4 * q0 + pp, o0 + CRS * oc);
+          const int off = cv_off<KROW>(4 * q0 + pp, o0 + CRS * oc);
           *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
           *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
         }
@@ -184,38 +212,41 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
     stamp(1);
     const int col = n0 + 4 * q0;
     const bool c_ok = full || col < p.HW;
-    const long roff = (long)o0 * p.HW + (c_ok ? col : 0);
+    const unsigned ro = (unsigned)(o0 * p.HW + (c_ok ? col : 0)) * 4u;   // this tile: addend / output rows o0 + CRS i
     const int tnext = (tile + 1 < t_end) ? tile + 1 : tile;   // past the end: a harmless re-read
-    const float* xnext = x_ptr(tnext);
-    const float* anext = add_ptr(tnext);
+    const float* xz_next = img(p.x, p.x_bs, tnext);
+    const unsigned xo_next = (unsigned)(8 * o0 * p.HW + lane_col(tnext)) * 4u;
     stamp(2);
     // ---- MFMA phase: rows 32 CMT wave .. + 32 CMT, all 64 px, K = 64 KBLK
     f32x16 acc[CMT][2];
 #pragma unroll
     for (int mi = 0; mi < CMT; ++mi)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int r4 = 0; r4 < 4; ++r4) {   // rows 32 (CMT wave + mi) + 8 r4 + 4 h .. + 3 of both pixel tiles
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bs + 32 * (CMT * wave + mi) + 8 * r4 + 4 * h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.0f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][j][4 * r4 + r] = b4[r];
+      }
+    // The stream is consumed in windows of CRING groups; while window c is consumed its slots are refilled with window
+    // c + 1, and the last window's refills fetch window 0 again, so the ring is ready for the next tile.
 #pragma unroll
     for (int kb = 0; kb < KBLK; ++kb) {
-      if (kb == KBLK - 1) {   // the refills of the last block fetch block 0 again: ring ready for the next tile
-        wp = wbase;
-        asm volatile("" : "+v"(wp));
-      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ks = 4 * kb + i;
         f16x8 bh[2], bl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int off = cv_off(32 * j + l31, 2 * ks + h);
+          const int off = cv_off<KROW>(32 * j + l31, 2 * ks + h);
           bh[j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
           bl[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
         }
 #pragma unroll
         for (int mi = 0; mi < CMT; ++mi) {
-          const int s = CMT * i + mi;
+          const int g = kb * CGPK + CMT * i + mi;   // group of the tile's stream
+          const int s = g % CRING;
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[mi][j], 0, 0, 0);
 #pragma unroll
@@ -225,13 +256,29 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
           r_hi[s] = wp[s * CGROUP];
           r_lo[s] = wp[s * CGROUP + 64];
           __builtin_amdgcn_sched_barrier(0);   // keep the loads here (the scheduler otherwise sinks them next to their use)
+          if (s == CRING - 1) {   // window c = g / CRING is done: point wp at the source of the next window's refills
+            const int c = g / CRING;
+            if (c == NWIN - 2) {
+              wp = wbase;                                             // the last window refills with window 0
+              asm volatile("" : "+v"(wp));   // (laundered: otherwise the refill addresses become loop invariants in VGPRs)
+            } else if (c == NWIN - 1) {
+              wp = NWIN == 1 ? wbase : wbase + CRING * CGROUP;       // next tile, window 0: source is window 1
+              asm volatile("" : "+v"(wp));
+            } else {
+              wp += CRING * CGROUP;
+            }
+          }
         }
       }
-      wp += CRING * CGROUP;
     }
 
     stamp(3);
-    // ---- epilogue: accumulators -> LDS [row][px]; bias / addend / GELU / statistics on 16-byte row segments
+    {   // this tile's addend rows (defined on both paths: not live across the MFMA loop)
+      const float* az = img(addsrc, addsrc_bs, tile);
+#pragma unroll
+      for (int i = 0; i < CRPT; ++i) addv[i] = p.add ? sdy_ld16s(az + (long)(CRS * i) * p.HW, ro) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- epilogue: accumulators -> LDS [row][px]; addend / GELU / statistics on 16-byte row segments
     __syncthreads();
     stamp(4);   // every wave is done reading the x tile
 #pragma unroll
@@ -246,56 +293,51 @@ __global__ __launch_bounds__(CNT, 1) void conv_h3_kernel(const ConvParams p) {
     __syncthreads();
     stamp(5);
     {
-      float* og = p.out + (long)z * p.out_bs + roff;
+      float* oz = p.out + (long)z * p.out_bs;   // uniform
 #pragma unroll
       for (int i = 0; i < CRPT; ++i) {
         f32x4 v = *reinterpret_cast<const f32x4*>(Os + (o0 + CRS * i) * CTN + 4 * q0);
-        v += brow[i];
         if (p.add_mode == 1) v += addv[i];
         if (p.act == 1) {
           const sdy_gf2 g0 = gelu_erf2(sdy_gf2{v.x, v.y}), g1 = gelu_erf2(sdy_gf2{v.z, v.w});
           v = f32x4{g0.x, g0.y, g1.x, g1.y};
         }
         if (p.add_mode == 2) v += addv[i];
-        if (c_ok) SDY_STREAM_STORE(og + (long)(CRS * i) * p.HW, v);
-        // next tile's addend row, one per step (every lane: a lane beyond a ragged tile's edge still owns pixels of the next)
-        if (p.add) addv[i] = *reinterpret_cast<const f32x4*>(anext + (long)(CRS * i) * p.HW);   // (workgroup-uniform)
-        // next tile's pixels, one piece per step as well: with them out of the MFMA phase the weight ring no longer queues
-        // behind HBM loads there (vmcnt retires in order): MFMA phase 12.0k -> 7.6k cycles, kernel -3 %
-        {
-          const int ch = 8 * (o0 + CRS * (i >> 3)) + (i & 7);
-          if (ch < p.Cin) xr[i >> 3][i & 7] = *reinterpret_cast<const f32x4*>(xnext + (long)ch * p.HW);
+        if (c_ok) sdy_st16s(oz + (long)(CRS * i) * p.HW, ro, v);
+        // next tile's pixels, a piece (or two) per step (every lane: a lane beyond a ragged tile's edge still owns pixels of
+        // the next tile)
+#pragma unroll
+        for (int k = 0; k < G::PPI; ++k) {
+          const int piece = G::PPI * i + k, oc = piece >> 3, e = piece & 7;
+          if (oc < COC) {
+            const int ch = 8 * (o0 + CRS * oc) + e;
+            if (ch < p.Cin) xr[oc][e] = sdy_ld16s(xz_next + (long)(8 * CRS * oc + e) * p.HW, xo_next);
+          }
         }
-        if (c_ok) {
-          psum[i] += (double)((v.x + v.y) + (v.z + v.w));
-          psq[i] += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+        if (p.stats) {   // (workgroup-uniform)
+          const float s1 = row16_sum(c_ok ? (v.x + v.y) + (v.z + v.w) : 0.0f);
+          const float s2 = row16_sum(c_ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.0f);
+          if (q0 == 0) {   // the one owner of this row in the workgroup
+            double* st = Ss + 2 * (o0 + CRS * i);
+            __hip_atomic_fetch_add(st, (double)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(st + 1, (double)s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
       }
     }
     stamp(6);
-    // statistics flush at this workgroup's last tile of the image (see mlp_h3.hip)
-    if (p.stats) {
+    // statistics flush at this workgroup's last tile of the image
+    {
       const int nt = tile + 1;
-      if (nt >= t_end || nt / tpi != z) {   // workgroup-uniform
-#pragma unroll
-        for (int i = 0; i < CRPT; ++i) {
-          double s1 = psum[i], s2 = psq[i];
-#pragma unroll
-          for (int m = 1; m < 16; m <<= 1) {
-            s1 += __shfl_xor(s1, m, 64);
-            s2 += __shfl_xor(s2, m, 64);
-          }
-          if (q0 == 0) {
-            double* st = p.stats + ((long)z * CE + o0 + CRS * i) * 2;
-            __hip_atomic_fetch_add(st, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(st + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          psum[i] = 0.0; psq[i] = 0.0;
+      if (p.stats && (nt >= t_end || nt / tpi != z)) {   // workgroup-uniform
+        __syncthreads();
+        if (tid < CE) {
+          double* st = p.stats + ((long)z * CE + tid) * 2;
+          __hip_atomic_fetch_add(st, Ss[2 * tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(st + 1, Ss[2 * tid + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          Ss[2 * tid] = 0.0; Ss[2 * tid + 1] = 0.0;
         }
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < CRPT; ++i) { psum[i] = 0.0; psq[i] = 0.0; }
     }
     stamp(7);
     __syncthreads();   // the store phase is done with the LDS tile
@@ -312,13 +354,26 @@ extern "C" int sdy_conv256_h3_debug_stamps(unsigned long long* host64) {
   return SDY_OK;
 }
 
-extern "C" int sdy_conv256_h3_supported(int Cin, int Cout) { return (Cin >= 1 && Cin <= CE && Cout == CE) ? 1 : 0; }
+extern "C" int sdy_conv256_h3_supported(int Cin, int Cout) { return (Cin >= 1 && Cin <= CKMAX && Cout == CE) ? 1 : 0; }
 
-extern "C" size_t sdy_conv256_h3_pack_bytes(void) { return (size_t)CNW * CGPW * CGROUP * sizeof(f16x8); }
+// layout of the packed stream for Cin input channels: waves, k-steps per wave (zero-padded), 32-row tiles per wave
+static void conv_layout(int Cin, int* nw, int* ksw, int* mt) {
+  const int kblk = (Cin + 63) / 64;
+  *nw = kblk <= 4 ? 4 : 8;
+  *ksw = kblk <= 4 ? 16 : 24;
+  *mt = 8 / *nw;
+}
 
-// w_host: (256, Cin) row-major (Cout, Cin), Cin <= 256 (zero-padded to 256 in the stream)
+extern "C" size_t sdy_conv256_h3_pack_bytes_cin(int Cin) {
+  int nw, ksw, mt;
+  conv_layout(Cin < 1 ? 1 : Cin, &nw, &ksw, &mt);
+  return (size_t)nw * mt * ksw * CGROUP * sizeof(f16x8);
+}
+extern "C" size_t sdy_conv256_h3_pack_bytes(void) { return sdy_conv256_h3_pack_bytes_cin(CE); }
+
+// w_host: (256, Cin) row-major (Cout, Cin), Cin <= 384 (zero-padded in the stream)
 extern "C" int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* dev, float* scale) {
-  if (!w_host || !dev || !scale || Cin < 1 || Cin > CE) return SDY_ERR_ARG;
+  if (!w_host || !dev || !scale || Cin < 1 || Cin > CKMAX) return SDY_ERR_ARG;
   float mx = 0.f;
   for (int i = 0; i < CE * Cin; ++i) mx = std::fmax(mx, std::fabs(w_host[i]));
   float s = 1.0f;
@@ -327,16 +382,18 @@ extern "C" int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* dev, 
     std::frexp(mx, &e);
     s = std::ldexp(1.0f, 13 - e);
   }
+  int nw, ksw, mt;
+  conv_layout(Cin, &nw, &ksw, &mt);
   const size_t gh = (size_t)CGROUP * 8;
-  std::vector<_Float16> buf((size_t)CNW * CGPW * gh);
+  std::vector<_Float16> buf((size_t)nw * mt * ksw * gh);
   _Float16* d = buf.data();
-  for (int w = 0; w < CNW; ++w)
-    for (int ks = 0; ks < CKS; ++ks)
-      for (int mi = 0; mi < CMT; ++mi, d += gh)
+  for (int w = 0; w < nw; ++w)
+    for (int ks = 0; ks < ksw; ++ks)
+      for (int mi = 0; mi < mt; ++mi, d += gh)
         for (int ln = 0; ln < 64; ++ln)
           for (int e = 0; e < 8; ++e) {
             const int kk = 16 * ks + 8 * (ln >> 5) + e;
-            const float v = kk < Cin ? w_host[(size_t)(32 * (CMT * w + mi) + (ln & 31)) * Cin + kk] * s : 0.0f;
+            const float v = kk < Cin ? w_host[(size_t)(32 * (mt * w + mi) + (ln & 31)) * Cin + kk] * s : 0.0f;
             const _Float16 hv = (_Float16)v;
             d[ln * 8 + e] = hv;
             d[64 * 8 + ln * 8 + e] = (_Float16)(v - (float)hv);
@@ -349,12 +406,21 @@ extern "C" int sdy_conv256_h3_pack(const float* w_host, void* dev, float* scale)
   return sdy_conv256_h3_pack_cin(w_host, CE, dev, scale);
 }
 
+template <int KBLK, int NW>
+static void conv_launch(const ConvParams& p, long ntiles, int n_cu, hipStream_t stream) {
+  using G = ConvCfg<KBLK, NW>;
+  const long want = (long)n_cu * G::WGS;   // persistent: WGS workgroups per CU
+  dim3 grid((unsigned)(ntiles < want ? ntiles : want));
+  hipLaunchKernelGGL((conv_h3_kernel<KBLK, NW>), grid, dim3(G::NT), 0, stream, p);
+}
+
 int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   if (!a || !a->x || !a->w_frag || !a->out || a->B <= 0 || a->HW <= 0) return SDY_ERR_ARG;
   if (!sdy_conv256_h3_supported(a->Cin, a->Cout)) return SDY_ERR_UNSUPPORTED;
   if (a->drop_p > 0.f || a->keep_mask || a->batch_scale) return SDY_ERR_UNSUPPORTED;
-  if (a->pa && a->Cin != CE) return SDY_ERR_UNSUPPORTED;   // the affine prologue reads 8-channel groups
+  if (a->pa && a->Cin != CE) return SDY_ERR_UNSUPPORTED;   // the affine prologue reads 8-channel groups of 256 channels
   if ((a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3) || (a->add_mode && (a->add_bstride & 3))) return SDY_ERR_ALIGN;
+  if ((long)a->HW * CKMAX * 4 >= (1L << 32)) return SDY_ERR_UNSUPPORTED;   // 32-bit lane offsets inside an image
   ConvParams p;
   p.x = a->x; p.x_bs = a->x_bstride; p.pa = a->pa; p.pd = a->pd;
   p.w = reinterpret_cast<const f16x8*>(a->w_frag);
@@ -374,13 +440,13 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   int n_cu = 0;
   SDY_TRY(sdy_cu_count(&n_cu));
   const long ntiles = (long)((a->HW + CTN - 1) / CTN) * a->B;
-  const long want = n_cu;   // persistent: one workgroup per CU
-  dim3 grid((unsigned)(ntiles < want ? ntiles : want));
   switch ((a->Cin + 63) / 64) {
-    case 1: hipLaunchKernelGGL(conv_h3_kernel<1>, grid, dim3(CNT), 0, stream, p); break;
-    case 2: hipLaunchKernelGGL(conv_h3_kernel<2>, grid, dim3(CNT), 0, stream, p); break;
-    case 3: hipLaunchKernelGGL(conv_h3_kernel<3>, grid, dim3(CNT), 0, stream, p); break;
-    default: hipLaunchKernelGGL(conv_h3_kernel<4>, grid, dim3(CNT), 0, stream, p); break;
+    case 1: conv_launch<1, 4>(p, ntiles, n_cu, stream); break;
+    case 2: conv_launch<2, 4>(p, ntiles, n_cu, stream); break;
+    case 3: conv_launch<3, 4>(p, ntiles, n_cu, stream); break;
+    case 4: conv_launch<4, 4>(p, ntiles, n_cu, stream); break;
+    case 5: conv_launch<5, 8>(p, ntiles, n_cu, stream); break;
+    default: conv_launch<6, 8>(p, ntiles, n_cu, stream); break;
   }
   return sdy_launch_status();
 }

@@ -155,11 +155,11 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
 
 
 def pack_conv256(weight: torch.Tensor, device):
-    """(256, Cin <= 256) fp32 weight -> (per-wave MFMA fragment stream, scale) for conv1x1(..., frag_prepared=...)."""
+    """(256, Cin <= 384) fp32 weight -> (per-wave MFMA fragment stream, scale) for conv1x1(..., frag_prepared=...)."""
     w = weight.detach().to("cpu", torch.float32).reshape(weight.shape[0], -1).contiguous()
     if not lib.sdy_conv256_h3_supported(w.shape[1], w.shape[0]):
-        raise NotImplementedError("the persistent conv kernel needs 256 output and at most 256 input channels")
-    buf = torch.empty(lib.sdy_conv256_h3_pack_bytes(), dtype=torch.uint8, device=device)
+        raise NotImplementedError("the persistent conv kernel needs 256 output and at most 384 input channels")
+    buf = torch.empty(lib.sdy_conv256_h3_pack_bytes_cin(w.shape[1]), dtype=torch.uint8, device=device)
     sc = C.c_float()
     with torch.cuda.device(device):
         check(lib.sdy_conv256_h3_pack_cin(ptr(w), w.shape[1], ptr(buf), C.byref(sc)), "sdy_conv256_h3_pack_cin")

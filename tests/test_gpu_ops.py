@@ -365,10 +365,12 @@ def test_conv256_persistent_kernel_and_statistics(sdy, B, H, W):
     assert rel_l2(out2, out3) < 5e-6
 
 
-@pytest.mark.parametrize("Cin", [65, 128, 130, 200, 4])
+@pytest.mark.parametrize("Cin", [65, 128, 130, 200, 4, 321, 384, 260])
 def test_conv_cin_to_256_persistent_kernel(sdy, Cin):
-    """The persistent kernel with fewer than 256 input channels (the encoders' first layers: 65 and 128 channels in
-    the benchmark configuration): bias + GELU epilogue, no addend, ragged image edge (3 x 20 x 36 = 12 tiles of 64 + ragged)."""
+    """The persistent kernel with other than 256 input channels (the encoders' first layers: 65 and 128 channels in the
+    benchmark configuration; the decoder's first layer reads [block output | inputs]: 321 and 384 channels, the 8-wave
+    variant with a 96 KB tile): bias + GELU epilogue, no addend, ragged image edge (3 x 20 x 36 = 12 tiles of 64 +
+    ragged)."""
     g = _gen(47)
     F = torch.nn.functional
     B, H, W = 3, 20, 37 * 4

@@ -1,11 +1,18 @@
 #!/bin/bash
-# End-to-end bench for conv_h3 build parameters on the GPU box: bash tools/micro/conv_sweep_e2e.sh "<defs1>" ...
+# Build-flag sweep of conv_h3 inside the network: bash tools/micro/conv_sweep_e2e.sh "<defs1>" "<defs2>" ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cd $R/spherical-dyffusion_amd/csrc
 for D in "$@"; do
+  cd $R/spherical-dyffusion_amd/csrc
   rm -f conv_h3.o
   make CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $D" conv_h3.o > /dev/null 2>&1
   make > /dev/null 2>&1
   echo "== $D"
-  (cd $R && for i in 1 2; do python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"])"; done)
+  cd $R
+  python bench.py --steps 4 --warmup 1 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('value', d['value'])
+for k in d['roofline']['kernels']:
+    if 'conv' in k['name']: print('  ', k['name'], k['ms'], k.get('frac_hbm'))
+"
 done
