@@ -123,14 +123,13 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     const int zz = t / tpi, nn = (t - zz * tpi) * TN;
     // ragged last slice of an image: clamp the address (branch-free loads keep exact vmcnt counts), zero at conversion
     const bool ok = nn + 4 * q0 < p.HW;
-    const float* __restrict__ xg = p.x + (long)zz * p.x_bs + (ok ? nn + 4 * q0 : 0);
+    // (wave-uniform row base in SGPRs) + (one 32-bit lane offset): see sdy_ld16s in common.h
+    const float* xz = p.x + (long)zz * p.x_bs;
+    const unsigned xo = (unsigned)(8 * o0 * p.HW + (ok ? nn + 4 * q0 : 0)) * 4u;
 #pragma unroll
     for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ch = 8 * (o0 + 16 * oc) + e;
-        xr[oc][e] = *reinterpret_cast<const f32x4*>(xg + (long)ch * p.HW);
-      }
+      for (int e = 0; e < 8; ++e) xr[oc][e] = sdy_ld16s(xz + (long)(8 * 16 * oc + e) * p.HW, xo);
   };
   // per-image coefficient table in LDS (norm affine of x, affine of the residual): rewritten only when the image changes
   auto load_coeffs = [&](int zz) {
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   f32x4 rres[16];
   const int e_col = n0 + 4 * (tid & 15);                    // store phase: first pixel of this thread's quad
   const bool e_ok = full || e_col < p.HW;
-  const long e_off = e_ok ? e_col : 0;
+  const unsigned e_ro = (unsigned)((tid >> 4) * p.HW + (e_ok ? e_col : 0)) * 4u;   // lane byte offset of rows tid / 16 + 16 i
 
   constexpr bool do_drop = DROP;
   // stacked calls: image z is trajectory z % rows_per_call of call + z / rows_per_call
@@ -472,9 +471,9 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   {
     // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested before
     // the epilogue arithmetic, which covers most of their latency
-    const float* ag = (p.add ? p.add + (long)z * p.add_bs : p.x + (long)z * p.x_bs) + (long)(tid >> 4) * p.HW + e_off;
+    const float* az = p.add ? p.add + (long)z * p.add_bs : p.x + (long)z * p.x_bs;   // uniform
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rres[i] = *reinterpret_cast<const f32x4*>(ag + (long)(16 * i) * p.HW);
+    for (int i = 0; i < 16; ++i) rres[i] = sdy_ld16s(az + (long)(16 * i) * p.HW, e_ro);
   }
 
   // ---- epilogue: bias, dropout, drop-path scale in accumulator layout -> LDS [256 rows][64 px] (the x tile's storage:
@@ -520,14 +519,14 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     __syncthreads();
     stamp(14);
     if (e_ok) {
-      float* og = p.out + (long)z * p.out_bs + (long)(tid >> 4) * p.HW + e_col;
+      float* oz = p.out + (long)z * p.out_bs;   // uniform
       const float* os = Os + (tid >> 4) * TN + 4 * (tid & 15);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (tid >> 4) + 16 * i;
         f32x4 v = *reinterpret_cast<const f32x4*>(os + 16 * i * TN);
         if (p.add) v += rres[i] * Cf[2 * ME + row] + Cf[3 * ME + row];
-        SDY_STREAM_STORE(og + (long)(16 * i) * p.HW, v);
+        sdy_st16s(oz + (long)(16 * i) * p.HW, e_ro, v);
         if (p.stats) {
           psum[i] += (double)((v.x + v.y) + (v.z + v.w));
           psq[i] += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
@@ -647,6 +646,7 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   if (!sdy_mlp_h3_supported(a->E, a->hidden)) return SDY_ERR_UNSUPPORTED;
   if ((a->pa == nullptr) != (a->pd == nullptr) || (a->add_a == nullptr) != (a->add_d == nullptr)) return SDY_ERR_ARG;
   if ((a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3) || (a->add && (a->add_bstride & 3))) return SDY_ERR_ALIGN;
+  if ((long)a->HW * ME * 4 >= (1L << 32)) return SDY_ERR_UNSUPPORTED;   // 32-bit lane offsets inside an image
   if (a->drop_p < 0.0f || a->drop_p >= 1.0f) return SDY_ERR_ARG;
   if (a->B > 65535) return SDY_ERR_UNSUPPORTED;
   MlpParams p{};
