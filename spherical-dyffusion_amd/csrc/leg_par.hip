@@ -40,42 +40,60 @@ struct ParParams {
   const float* X; long ldx, sX;  // input rows (latitudes / degrees) at X + z * sX + row * ldx, columns contiguous
   float* C; long ldc, sC;        // output rows at C + z * sC + row * ldc
   int rows_out, K, N;            // output rows stored, input rows, columns
-  int fwd;                       // 1 analysis, 0 synthesis
   const int* kdead;              // polar cut-off per order (rows k' < kdead[m] and their mirrors are skipped) or nullptr
   float out_scale;
-  unsigned* flags;               // sticky status word (sdy_status_flags)
+  unsigned long long* stamps;    // timing experiments only (SDY_LEG_STAMPS): [4 sampled workgroups][3 waves][8]
 };
 
 // same swizzle as leg_h3.hip: 16-byte chunk c (0..23) of column px
 __device__ __forceinline__ int pr_off(int px, int c) { return px * PKP + (((c & ~7) | ((c ^ (px >> 1)) & 7)) << 3); }
 
+// 4-byte global store as (wave-uniform base) + (32-bit lane byte offset), see sdy_st16s in common.h
+__device__ __forceinline__ void st4s(float* ubase, unsigned off_b, float v) {
+  sdy_gptr_t b = (sdy_gptr_t)ubase;
+  asm volatile("" : "+s"(b), "+v"(off_b));
+  *reinterpret_cast<float __attribute__((address_space(1)))*>(b + off_b) = v;
+}
+
+// The kernel is bound by instruction ISSUE, not by HBM latency (tools/leg_stamps.py: with three workgroups per CU every
+// phase of a workgroup takes 2-3x its instruction count; two workgroups per CU: 1.3x slower, one: 2.3x).  So: the direction
+// is a template parameter, every global access is (uniform row base) + (one lane offset) -- no 64-bit lane arithmetic, no
+// per-row clamps --, dead rows are masked by selects on lane masks computed once per thread, and the accumulators go
+// straight to global memory as 128-byte row segments (no LDS pass, no barrier after the MFMA loop).
+template <bool FWD, bool STAMPS>
 __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PTN * PKP * 2];   // 48 KB
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
   _Float16* Xs_lo = Xs_hi + PTN * PKP;
-  float* Os = reinterpret_cast<float*>(smem);   // epilogue: [192 rows][64 cols] fp32 (aliases the tile)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: row bases of the epilogue are scalar arithmetic
   const int h = lane >> 5, l31 = lane & 31;
   const int z = blockIdx.y;                     // zonal order m
   const int n0 = blockIdx.x * PTN;
   const bool full = n0 + PTN <= p.N;
-  const int Kh = p.K >> 1;                      // analysis: latitudes per hemisphere
+  const int Kh = (FWD ? p.K : p.rows_out) >> 1;   // latitudes per hemisphere
   const int cE = z & 1, cO = cE ^ 1;            // degree l = 2 r + cE is an "E" degree (l + m even), 2 r + cO an "O" degree
 
   const int kd = p.kdead ? p.kdead[z] : 0;                // polar rows of this order (table < 1e-12 of its maximum there)
-  const bool wave_dead = p.fwd ? (64 * wave + 63 < z)     // analysis: all degrees of this wave are below m
-                               : (32 * wave + 31 < kd);   // synthesis: all latitudes of this wave are polar
-  const int ks0 = p.fwd ? kd >> 4 : z >> 5;               // k-steps that contribute nothing: polar latitudes / degrees below m
-  const int row_lo = p.fwd ? z : 0;                       // analysis: degrees l < m are never read downstream
+  const bool wave_dead = FWD ? (64 * wave + 63 < z)       // analysis: all degrees of this wave are below m
+                             : (32 * wave + 31 < kd);     // synthesis: all latitudes of this wave are polar
+  const int ks0 = FWD ? kd >> 4 : z >> 5;                 // k-steps that contribute nothing: polar latitudes / degrees below m
+  auto stamp = [&](int i) {
+    if (STAMPS && lane == 0 && (blockIdx.x == 37 || blockIdx.x == 150) && (z == 20 || z == 90))
+      p.stamps[(((blockIdx.x == 150) * 2 + (z == 90)) * 3 + wave) * 8 + i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
 
   // ---- table ring (slot = 2 * (k-step % 4) + half)
   f16x8 r_hi[PRING], r_lo[PRING];
   const f16x8* __restrict__ wp = p.table + (size_t)(z * 3 + wave) * PGPW * PGROUP + lane;
+  if (!wave_dead) {
 #pragma unroll
-  for (int s = 0; s < PRING; ++s) {
-    r_hi[s] = wp[s * PGROUP];
-    r_lo[s] = wp[s * PGROUP + 64];
+    for (int s = 0; s < PRING; ++s) {
+      r_hi[s] = wp[s * PGROUP];
+      r_lo[s] = wp[s * PGROUP + 64];
+    }
   }
 
   // ---- phase 0: input rows -> LDS halves; thread = (column quad q, octet o of the half: positions 8 o .. 8 o + 7)
@@ -84,34 +102,57 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
   {
     const int q = tid & 15, o = tid >> 4;
     const bool ok = full || (n0 + 4 * q < p.N);
-    const float* __restrict__ xg = p.X + (long)z * p.sX + (ok ? n0 + 4 * q : 0);
-    f32x4 xr[2][8];
-    bool v_ok[2][8];
-    // synthesis: an octet whose 16 degrees are all below m is zero -- no loads at all (half of the octets on average)
-    const bool oct_live = p.fwd ? (8 * o + 7 >= kd) : (16 * o + 15 >= z);
+    const float* xz = p.X + (long)z * p.sX;   // uniform
+    f32x4 xa[8], xb[8];
+    bool va[8], vb[8];   // lane masks (one SGPR pair each), computed once and used for the four pixels of the quad
+    // analysis : xa = latitude 8 o + e, xb = its mirror K - 1 - (8 o + e) = (K - 8 - 8 o) + (7 - e)
+    // synthesis: xa / xb = the "E" / "O" degree of position 8 o + e: 16 o + 2 e + cE / cO
+    // Octets that contribute nothing are not loaded at all: polar latitudes (rows the producer never wrote), degrees below
+    // m, positions past the end.  Inside a live octet every row is in bounds (K >= 16), so the loads are unconditional and
+    // the dead ones (uninitialised memory) are masked by SELECTS, never by a multiplication.
+    const bool oct_live = FWD ? (8 * o + 7 >= kd && 8 * o < Kh) : (16 * o + 15 >= z && 16 * o < p.K);
+    const bool oct_full = FWD ? true : (16 * o + 15 < p.K);   // synthesis: the last octet may reach past lmax
+    const unsigned colc = ok ? n0 + 4 * q : 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      xr[0][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-      xr[1][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-      v_ok[0][e] = v_ok[1][e] = false;
-    }
-    if (oct_live)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
+      xa[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xb[e] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int r = 8 * o + e;
-      int rowA, rowB;
-      if (p.fwd) {   // latitude k' and its mirror
-        rowA = r; rowB = p.K - 1 - r;
-        v_ok[0][e] = v_ok[1][e] = r < Kh && r >= kd;
-      } else {       // the "E" and the "O" degree of position r
-        rowA = 2 * r + cE; rowB = 2 * r + cO;
-        v_ok[0][e] = rowA < p.K && rowA >= z;      // degrees below m were never written
-        v_ok[1][e] = rowB < p.K && rowB >= z;
+      if (FWD) {
+        va[e] = vb[e] = ok && r < Kh && r >= kd;
+      } else {
+        va[e] = ok && 2 * r + cE < p.K && 2 * r + cE >= z;   // degrees below m were never written
+        vb[e] = ok && 2 * r + cO < p.K && 2 * r + cO >= z;
       }
-      const int safe = p.fwd ? 0 : z;              // clamped: branch-free loads, zeroed below
-      xr[0][e] = *reinterpret_cast<const f32x4*>(xg + (long)(v_ok[0][e] ? rowA : safe) * p.ldx);
-      xr[1][e] = *reinterpret_cast<const f32x4*>(xg + (long)(v_ok[1][e] ? rowB : safe) * p.ldx);
     }
+    if (oct_live) {
+      if (FWD) {
+        const unsigned offA = (unsigned)((long)(8 * o) * p.ldx + colc) * 4u;
+        const unsigned offB = (unsigned)((long)(p.K - 8 - 8 * o) * p.ldx + colc) * 4u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xa[e] = sdy_ld16s(xz + (long)e * p.ldx, offA);
+          xb[e] = sdy_ld16s(xz + (long)(7 - e) * p.ldx, offB);
+        }
+      } else {
+        const unsigned off = (unsigned)((long)(16 * o) * p.ldx + colc) * 4u;
+        if (oct_full) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xa[e] = sdy_ld16s(xz + (long)(2 * e + cE) * p.ldx, off);
+            xb[e] = sdy_ld16s(xz + (long)(2 * e + cO) * p.ldx, off);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (16 * o + 2 * e + cE < p.K) xa[e] = sdy_ld16s(xz + (long)(2 * e + cE) * p.ldx, off);
+            if (16 * o + 2 * e + cO < p.K) xb[e] = sdy_ld16s(xz + (long)(2 * e + cO) * p.ldx, off);
+          }
+        }
+      }
+    }
+    stamp(1);   // loads issued
+    if (STAMPS) { asm volatile("s_waitcnt vmcnt(0)"); stamp(2); }   // loads arrived
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
@@ -120,11 +161,11 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          if (p.fwd) {
-            const float a = xr[0][e][pp], b = xr[1][e][pp];
-            v[e] = (ok && v_ok[0][e]) ? (hf == 0 ? a + b : a - b) * PSX : 0.0f;
+          if (FWD) {
+            const float a = xa[e][pp], b = xb[e][pp];
+            v[e] = va[e] ? (hf == 0 ? a + b : a - b) * PSX : 0.0f;
           } else {
-            v[e] = (ok && v_ok[hf][e]) ? xr[hf][e][pp] * PSX : 0.0f;
+            v[e] = (hf == 0 ? va[e] : vb[e]) ? (hf == 0 ? xa[e][pp] : xb[e][pp]) * PSX : 0.0f;
           }
         }
         sdy_split8(v, vh, vl);
@@ -135,6 +176,8 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
     }
   }
   __syncthreads();
+  stamp(3);   // tile in LDS
+  if (wave_dead) return;   // (after the only barrier)
 
   f32x16 acc[2][2];   // [half: E, O][column tile]
 #pragma unroll
@@ -146,7 +189,7 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
 
 #pragma unroll
   for (int ks = 0; ks < PKS; ++ks) {
-    if (!wave_dead && ks >= ks0) {
+    if (ks >= ks0) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         f16x8 bh[2], bl[2];
@@ -175,47 +218,99 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  stamp(4);   // MFMA loop done
 
-  // ---- epilogue: accumulators -> LDS [output row][col] -> 16-byte row stores of the live rows
-  __syncthreads();   // every wave is done reading the tile
-  if (!wave_dead) {
+  // ---- epilogue: accumulators -> global.  Register r of a tile is row 8 (r >> 2) + 4 h + (r & 3) of the wave's 32, lanes
+  // l31 are 32 consecutive columns: one store instruction writes two 128-byte row segments.  Row = uniform part (SGPR
+  // arithmetic on the wave index, running pointers) + a lane part that depends on h only.  Groups of four registers
+  // (r >> 2) that lie inside the stored range take plain stores; a group that touches the edge (rows below m, the last
+  // degrees / latitudes, a ragged column tile) is predicated with lane masks built from scalar compares.
+  float* cz = p.C + (long)z * p.sC + n0;   // uniform
+  constexpr unsigned long long MH0 = 0x00000000FFFFFFFFull, MH1 = 0xFFFFFFFF00000000ull;   // lanes with h = 0 / h = 1
+  unsigned long long colm[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 2; ++j) colm[j] = __builtin_amdgcn_ballot_w64(n0 + 32 * j + l31 < p.N);
+  if (FWD) {
+    // degree l = 2 rt + c = [64 wave + 16 r4 + 2 r2 + c] + 8 h, c = cE for the E tile, cO for the O tile
+    const unsigned offl = (unsigned)((long)(8 * h) * p.ldc + l31) * 4u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rt = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;   // row inside the wave's tile pair
-        const int col = 32 * j + l31;
-        if (p.fwd) {          // degrees 2 rt + cE ("E" tile) and 2 rt + cO ("O" tile)
-          Os[(2 * rt + cE) * PTN + col] = acc[0][j][r] * p.out_scale;
-          Os[(2 * rt + cO) * PTN + col] = acc[1][j][r] * p.out_scale;
-        } else if (rt < (p.rows_out >> 1)) {   // latitude rt and its mirror
-          Os[rt * PTN + col] = (acc[0][j][r] + acc[1][j][r]) * p.out_scale;
-          Os[(p.rows_out - 1 - rt) * PTN + col] = (acc[0][j][r] - acc[1][j][r]) * p.out_scale;
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int base = 64 * wave + 16 * r4 + (hf == 0 ? cE : cO);   // uniform; the group holds degrees base .. base + 14
+        if (base + 14 < z || base >= p.rows_out) continue;            // uniform: all below m / past lmax
+        float* rowp = cz + (long)base * p.ldc;
+        if (full && base >= z && base + 14 < p.rows_out) {
+#pragma unroll
+          for (int r2 = 0; r2 < 4; ++r2, rowp += 2 * p.ldc)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) st4s(rowp + 32 * j, offl, acc[hf][j][4 * r4 + r2] * p.out_scale);
+        } else {
+#pragma unroll
+          for (int r2 = 0; r2 < 4; ++r2, rowp += 2 * p.ldc) {
+            const int lu = base + 2 * r2;
+            const unsigned long long m = ((lu >= z && lu < p.rows_out) ? MH0 : 0ull) | ((lu + 8 >= z && lu + 8 < p.rows_out) ? MH1 : 0ull);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (__builtin_amdgcn_inverse_ballot_w64(m & colm[j])) st4s(rowp + 32 * j, offl, acc[hf][j][4 * r4 + r2] * p.out_scale);
+          }
         }
       }
-  }
-  __syncthreads();
-  {
-    const int q = tid & 15, r0 = tid >> 4;
-    const int col = n0 + 4 * q;
-    if (full || col < p.N) {
-      float* cg = p.C + (long)z * p.sC + col;
+  } else {
+    // latitude rt = [32 wave + 8 r4 + r2] + 4 h and its mirror rows_out - 1 - rt = [rows_out - 5 - (32 wave + 8 r4 + r2)] + 4 (1 - h)
+    const unsigned off1 = (unsigned)((long)(4 * h) * p.ldc + l31) * 4u;
+    const unsigned off2 = (unsigned)((long)(4 * (1 - h)) * p.ldc + l31) * 4u;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = r0 + 12 * i;
-        if (row >= row_lo && row < p.rows_out && (p.fwd || (row >= kd && row < p.rows_out - kd)))
-          SDY_STREAM_STORE(cg + (long)row * p.ldc, *reinterpret_cast<const f32x4*>(Os + row * PTN + 4 * q));
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int base = 32 * wave + 8 * r4;                 // uniform; the group holds latitudes base .. base + 7
+      if (base + 7 < kd || base >= Kh) continue;           // uniform: polar rows / past the equator
+      float* row1 = cz + (long)base * p.ldc;
+      float* row2 = cz + (long)(p.rows_out - 5 - base) * p.ldc;
+      if (full && base >= kd && base + 7 < Kh) {
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2, row1 += p.ldc, row2 -= p.ldc)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float e = acc[0][j][4 * r4 + r2], od = acc[1][j][4 * r4 + r2];
+            st4s(row1 + 32 * j, off1, (e + od) * p.out_scale);
+            st4s(row2 + 32 * j, off2, (e - od) * p.out_scale);
+          }
+      } else {
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2, row1 += p.ldc, row2 -= p.ldc) {
+          const int ru = base + r2;
+          const unsigned long long m = ((ru >= kd && ru < Kh) ? MH0 : 0ull) | ((ru + 4 >= kd && ru + 4 < Kh) ? MH1 : 0ull);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (__builtin_amdgcn_inverse_ballot_w64(m & colm[j])) {
+              const float e = acc[0][j][4 * r4 + r2], od = acc[1][j][4 * r4 + r2];
+              st4s(row1 + 32 * j, off1, (e + od) * p.out_scale);
+              st4s(row2 + 32 * j, off2, (e - od) * p.out_scale);
+            }
+        }
       }
     }
   }
+  stamp(5);
 }
 
 }  // namespace
 
+static unsigned long long* g_lstamps = nullptr;
+extern "C" int sdy_leg_par_debug_stamps(unsigned long long* host96) {
+  if (!g_lstamps || !host96) return SDY_ERR_STATE;
+  SDY_HIP_TRY(hipDeviceSynchronize());
+  SDY_HIP_TRY(hipMemcpy(host96, g_lstamps, 96 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return SDY_OK;
+}
+
 size_t sdy_leg_par_table_bytes(int nz) { return ((size_t)nz * 3 * PGPW + PRING) * PGROUP * sizeof(f16x8); }
 
 // rows_out x K problem of leg_h3 (analysis: lmax x nlat, synthesis: nlat x lmax); the folded axis (nlat) must be even
-int sdy_leg_par_supported(int nlat, int lmax) { return (nlat <= PM && lmax <= PM && (nlat & 1) == 0 && nlat >= 2) ? 1 : 0; }
+// (nlat, lmax >= 16: inside a live octet of the load phase every row is then in bounds, see the kernel)
+int sdy_leg_par_supported(int nlat, int lmax) {
+  return (nlat <= PM && lmax <= PM && (nlat & 1) == 0 && nlat >= 16 && lmax >= 16) ? 1 : 0;
+}
 
 // value(ctx, z, row, k): the UNFOLDED table of leg_h3 (analysis: row = l, k = latitude; synthesis: row = latitude, k = l).
 // Only latitudes of the first hemisphere are read.
@@ -274,10 +369,22 @@ int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, l
   p.table = reinterpret_cast<const f16x8*>(table);
   p.X = X; p.ldx = ldx; p.sX = sX;
   p.C = C; p.ldc = ldc; p.sC = sC;
-  p.rows_out = rows_out; p.K = K; p.N = N; p.fwd = fwd; p.kdead = kdead;
+  // 32-bit lane offsets: 96 input rows / 8 output rows of lane-dependent distance
+  if ((long)PM * ldx * 4 + (long)N * 4 >= (1L << 32) || (long)8 * ldc * 4 + (long)N * 4 >= (1L << 32)) return SDY_ERR_UNSUPPORTED;
+  p.rows_out = rows_out; p.K = K; p.N = N; p.kdead = kdead;
   p.out_scale = 1.0f / (scale * PSX);
-  SDY_TRY(sdy_flags_ptr(&p.flags));
+  p.stamps = nullptr;
+  if (std::getenv("SDY_LEG_STAMPS")) {
+    if (!g_lstamps) SDY_HIP_TRY(hipMalloc(&g_lstamps, 96 * sizeof(unsigned long long)));
+    p.stamps = g_lstamps;
+  }
   dim3 grid((N + PTN - 1) / PTN, nz);
-  hipLaunchKernelGGL(leg_par_kernel, grid, dim3(192), 0, stream, p);
+  if (p.stamps) {
+    if (fwd) hipLaunchKernelGGL((leg_par_kernel<true, true>), grid, dim3(192), 0, stream, p);
+    else hipLaunchKernelGGL((leg_par_kernel<false, true>), grid, dim3(192), 0, stream, p);
+  } else {
+    if (fwd) hipLaunchKernelGGL((leg_par_kernel<true, false>), grid, dim3(192), 0, stream, p);
+    else hipLaunchKernelGGL((leg_par_kernel<false, false>), grid, dim3(192), 0, stream, p);
+  }
   return sdy_launch_status();
 }
