@@ -33,6 +33,9 @@ constexpr int CRING = 4;         // weight groups in flight: one "window" of the
 constexpr int CGROUP = 2 * 64;   // f16x8 elements per group (hi | lo)
 constexpr float CSX = 16.0f;
 constexpr int CSTAT_BYTES = CE * 2 * 8;
+#ifndef SDY_CONV_STAMP_T0
+#define SDY_CONV_STAMP_T0 2      // first of the four tiles of workgroup 3 that SDY_CONV_STAMPS samples
+#endif
 
 // Tiling for NW waves per workgroup and KBLK k-blocks of 64 input channels.
 template <int KBLK, int NW>
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
     asm volatile("" : "+v"(l31), "+v"(h), "+v"(q0), "+v"(o0));
     const int tile_it = tile - t_begin;
     auto stamp = [&](int i) {
-      if (p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= 2 && tile_it < 6)
-        p.stamps[(tile_it - 2) * 8 + i] = __builtin_amdgcn_s_memtime();
+      if (p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= SDY_CONV_STAMP_T0 && tile_it < SDY_CONV_STAMP_T0 + 4)
+        p.stamps[(tile_it - SDY_CONV_STAMP_T0) * 8 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     const int z = tile / tpi;
