@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   // The weight stream is packed in exactly this block order, 16 groups per block, so ring slot = index in the block.
   f32x16 acc[2];
   f32x4 bv[4];
-  auto load_bias = [&](int hc) {   // requested before the block's ring refills (see fc1)
-    const int row0 = HC * hc + 32 * wave + 4 * h;
+  auto load_bias = [&](int hc) {   // requested before the block's ring refills (see fc1); an LDS copy read inside the chain
+    const int row0 = HC * hc + 32 * wave + 4 * h;   // was slower: the wait for it lands in front of the stage that uses it
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) bv[g4] = *reinterpret_cast<const f32x4*>(p.b1 + row0 + 8 * g4);
   };
@@ -286,13 +286,15 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     switch (st) {
       // (the arithmetic stages work on value PAIRS: v_pk_fma_f32 / v_pk_mul_f32 do two values per instruction at the scalar
       // rate -- the chain is what bounds the interleaved fc2, see the timeline in DESIGN.md; rcp / exp2 stay scalar)
-      case 0:
+      case 0: {
+        const f32x4 b4 = bv[g4];
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
-          const sdy_gf2 v2 = sdy_gf2{acc[j][4 * g4 + r], acc[j][4 * g4 + r + 1]} * p.s1 + sdy_gf2{bv[g4][r], bv[g4][r + 1]};
+          const sdy_gf2 v2 = sdy_gf2{acc[j][4 * g4 + r], acc[j][4 * g4 + r + 1]} * p.s1 + sdy_gf2{b4[r], b4[r + 1]};
           s.v[r] = v2.x; s.v[r + 1] = v2.y;
         }
         break;
+      }
       // exact-erf GELU times SX: with z = |v| / sqrt(2), t = 1 / (1 + p z) and
       // Q = SX * erfc(z) / 2 = t * poly(t) * exp(-z^2) (A&S 7.1.26, coefficients pre-multiplied by SX / 2),
       //   SX * gelu(v) = (SX/2) v + |v| (SX/2 - Q)          (both signs of v, no compare / select)
@@ -380,6 +382,118 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       }
     }
   };
+  // The same piece for the slots BESIDE fc2's MFMAs.  tools/micro/mfma_valu_overlap.hip: one wave hides up to ~5 plain VALU
+  // instructions (fp32 FMA / MUL, conversions, v_fma_mix) under each of its own MFMAs (MFMA + 5 x v_fma_f32 = 34 cycles, MFMA
+  // alone 32; every further one +4.7), v_rcp / v_exp mostly (+2.6 each), but NOT packed fp32: v_pk_fma_f32 waits for the
+  // matrix pipe (MFMA + 2 x v_pk_fma_f32 = 56 cycles).  So this version is scalar throughout (the file is built with
+  // -fno-slp-vectorize) and cut into 12 slots of <= 6 instructions; the stand-alone chain(0) above keeps the packed form,
+  // which halves the instruction count where there is no MFMA to hide under.
+  auto chain_slot = [&](Piece& s, int st, int hc, int j, int g4) {
+    const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
+    const int px = 32 * j + l31;
+    if (do_drop && st < 10 && j == 0) {
+      if (st == 0) {
+        s.c0 = (uint32_t)(n0 + l31); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = call_z;
+        s.k0 = p.seed_lo; s.k1 = p.seed_hi;
+      }
+      const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0, p1 = (uint64_t)0xCD9E8D57u * s.c2;   // one Philox4x32 round
+      const uint32_t m0 = (uint32_t)(p1 >> 32) ^ s.c1 ^ s.k0, m2 = (uint32_t)(p0 >> 32) ^ s.c3 ^ s.k1;
+      s.c0 = m0; s.c1 = (uint32_t)p1; s.c2 = m2; s.c3 = (uint32_t)p0;
+      s.k0 += 0x9E3779B9u; s.k1 += 0xBB67AE85u;
+    }
+    constexpr float CT = 0.3275911f * 0.70710678118654752440f, KAP = -0.5f * 1.44269504088896340736f, HS = 0.5f * SX;
+    constexpr float A5 = 1.061405429f * HS, A4 = -1.453152027f * HS, A3 = 1.421413741f * HS, A2 = -0.284496736f * HS,
+                    A1 = 0.254829592f * HS;
+    // SX * gelu(v) = HS v + |v| (HS - Q),  Q = t poly(t) exp(-v^2 / 2),  t = 1 / (1 + CT |v|)   (as chain_stage)
+    switch (st) {
+      case 0: {
+        const f32x4 b4 = bv[g4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.v[r] = fmaf(acc[j][4 * g4 + r], p.s1, b4[r]);
+        break;
+      }
+      case 1:
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.t[r] = fmaf(__builtin_fabsf(s.v[r]), CT, 1.0f);
+        s.e[0] = s.v[0] * KAP; s.e[1] = s.v[1] * KAP;
+        break;
+      case 2:
+        s.t[0] = __builtin_amdgcn_rcpf(s.t[0]); s.t[1] = __builtin_amdgcn_rcpf(s.t[1]);
+        s.e[2] = s.v[2] * KAP; s.e[3] = s.v[3] * KAP;
+        s.e[0] *= s.v[0]; s.e[1] *= s.v[1];
+        break;
+      case 3:
+        s.t[2] = __builtin_amdgcn_rcpf(s.t[2]); s.t[3] = __builtin_amdgcn_rcpf(s.t[3]);
+        s.e[2] *= s.v[2]; s.e[3] *= s.v[3];
+        s.q[0] = fmaf(s.t[0], A5, A4); s.q[1] = fmaf(s.t[1], A5, A4);
+        break;
+      case 4:
+        s.e[0] = __builtin_amdgcn_exp2f(s.e[0]); s.e[1] = __builtin_amdgcn_exp2f(s.e[1]);
+        s.q[2] = fmaf(s.t[2], A5, A4); s.q[3] = fmaf(s.t[3], A5, A4);
+        s.q[0] = fmaf(s.q[0], s.t[0], A3); s.q[1] = fmaf(s.q[1], s.t[1], A3);
+        break;
+      case 5:
+        s.e[2] = __builtin_amdgcn_exp2f(s.e[2]); s.e[3] = __builtin_amdgcn_exp2f(s.e[3]);
+        s.q[2] = fmaf(s.q[2], s.t[2], A3); s.q[3] = fmaf(s.q[3], s.t[3], A3);
+        s.q[0] = fmaf(s.q[0], s.t[0], A2); s.q[1] = fmaf(s.q[1], s.t[1], A2);
+        break;
+      case 6:
+        s.q[2] = fmaf(s.q[2], s.t[2], A2); s.q[3] = fmaf(s.q[3], s.t[3], A2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.q[r] = fmaf(s.q[r], s.t[r], A1);
+        break;
+      case 7:
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.q[r] *= s.t[r];
+        s.q[0] = fmaf(-s.q[0], s.e[0], HS); s.q[1] = fmaf(-s.q[1], s.e[1], HS);   // HS - Q
+        break;
+      case 8:
+        s.q[2] = fmaf(-s.q[2], s.e[2], HS); s.q[3] = fmaf(-s.q[3], s.e[3], HS);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.q[r] *= __builtin_fabsf(s.v[r]);
+        break;
+      case 9:
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.v[r] = fmaf(s.v[r], HS, s.q[r]);
+        if (do_drop) {
+          if (j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s.v[r] = sdy_keep16(pw[r], j, p.drop_thr) ? s.v[r] * p.drop_scale : 0.0f;
+        }
+        break;
+      case 10: {   // fp16 hi and the fp32 residual (kept in e / t for the last slot; an inline-asm v_fma_mix_f32 here costs
+                   // the register allocator more than the instruction it saves: 124 bytes of scratch)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const sdy_f16x2 h2 = __builtin_convertvector(sdy_f32x2{s.v[r], s.v[r + 1]}, sdy_f16x2);
+          s.e[r >> 1] = __builtin_bit_cast(float, h2);
+          s.t[r] = s.v[r] - (float)h2[0]; s.t[r + 1] = s.v[r + 1] - (float)h2[1];
+        }
+        break;
+      }
+      default: {
+        _Float16* Hh = Hs + (hc & 1) * (2 * TN * HC);
+        _Float16* Hl = Hh + TN * HC;
+        f16x4 vh, vl;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const sdy_f16x2 h2 = __builtin_bit_cast(sdy_f16x2, s.e[r >> 1]);
+          const sdy_f16x2 l2 = __builtin_convertvector(sdy_f32x2{s.t[r], s.t[r + 1]}, sdy_f16x2);
+          vh[r] = h2[0]; vh[r + 1] = h2[1];
+          vl[r] = l2[0]; vl[r + 1] = l2[1];
+        }
+        const int off = hs_off(px, 4 * wave + g4) + 4 * h;
+        *reinterpret_cast<f16x4*>(Hh + off) = vh;
+        *reinterpret_cast<f16x4*>(Hl + off) = vl;
+      }
+    }
+  };
+#ifndef SDY_MLP_SCALAR_CHAIN
+#define SDY_MLP_SCALAR_CHAIN 1
+#endif
+#ifndef SDY_MLP_ABL
+#define SDY_MLP_ABL 0   // timing ablation only: bit s set = slot s of the interleaved chain is skipped (wrong results)
+#endif
   auto chain_piece = [&](int hc, int j, int g4) {
     Piece s;
 #pragma unroll
@@ -417,7 +531,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
           const f16x8 b = (k >= 2 && k < 4) ? bl[c][j] : bh[c][j];
           oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, oacc[mi][j], 0, 0, 0);
           if constexpr (CHAIN) {
-            chain_stage(ps, 6 * mi + k, hc2 + 1, t & 1, t >> 1);
+            if (SDY_MLP_SCALAR_CHAIN) { if (!((SDY_MLP_ABL >> (6 * mi + k)) & 1)) chain_slot(ps, 6 * mi + k, hc2 + 1, t & 1, t >> 1); }
+            else chain_stage(ps, 6 * mi + k, hc2 + 1, t & 1, t >> 1);
             __builtin_amdgcn_sched_barrier(0);
           }
         }

@@ -1,0 +1,147 @@
+// Does ONE wave overlap its own MFMA with independent VALU work?  Loop of { v_mfma_f32_32x32x16_f16 ; N x VALU } with N = 0..8,
+// for plain VGPR VALU, for VALU that reads accumulator registers of a DIFFERENT accumulator (v_accvgpr_read), and with the
+// MFMA accumulators in VGPRs or AGPRs.  One wave per SIMD (256 threads per CU) and two (512).
+//   make -C tools/micro mfma_valu_overlap && tools/micro/mfma_valu_overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VALU1(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[(i) & 7]) : "v"(w));
+#define REPV_0
+#define REPV_1 VALU1(0)
+#define REPV_2 REPV_1 VALU1(1)
+#define REPV_3 REPV_2 VALU1(2)
+#define REPV_4 REPV_3 VALU1(3)
+#define REPV_5 REPV_4 VALU1(4)
+#define REPV_6 REPV_5 VALU1(5)
+#define REPV_8 REPV_6 VALU1(6) VALU1(7)
+// four instructions of another kind in the shadow of each MFMA
+#define PK1(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(d[(i) & 3]) : "v"(d[((i) + 1) & 3]));
+#define REP_PK4 PK1(0) PK1(1) PK1(2) PK1(3)
+#define REP_PK2 PK1(0) PK1(1)
+#define RCP1(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[(i) & 7]));
+#define REP_RCP2 RCP1(0) RCP1(1)
+#define REP_RCP4 RCP1(0) RCP1(1) RCP1(2) RCP1(3)
+#define CVT1(i) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[(i) & 7]) : "v"(w));
+#define REP_CVT4 CVT1(0) CVT1(1) CVT1(2) CVT1(3)
+#define ACCRD1(i) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[(i) & 7]) : "a"(spare));
+#define REP_ACC4 ACCRD1(0) ACCRD1(1) ACCRD1(2) ACCRD1(3)
+#define SNOP1(i) asm volatile("s_nop 0");
+#define REP_NOP4 SNOP1(0) SNOP1(1) SNOP1(2) SNOP1(3)
+#define SALU1(i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc) : : "scc");
+#define REP_SALU4 SALU1(0) SALU1(1) SALU1(2) SALU1(3)
+#define REP_SALU8 REP_SALU4 REP_SALU4
+#define WAIT1(i) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+#define REP_WAIT4 WAIT1(0) WAIT1(1) WAIT1(2) WAIT1(3)
+#define LDS1(i) asm volatile("ds_read_b128 %0, %1" : "=v"(q4[(i) & 1]) : "v"(ldsaddr));
+#define REP_LDS2 LDS1(0) LDS1(1)
+#define REP_LDS4 LDS1(0) LDS1(1) LDS1(0) LDS1(1)
+#define REP_MIX REPV_2 PK1(0) CVT1(3) SALU1(0) WAIT1(0)
+
+// accumulators pinned to AGPRs ("a") or VGPRs ("v") through the asm constraint of the MFMA itself
+#define MFMA_A(k) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(a), "v"(b));
+#define MFMA_V(k) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b));
+
+#define KERNEL(NAME, MF, REPV)                                                              \
+  __global__ void NAME(float* out, unsigned long long* ticks, int iters) {                  \
+    f16x8 a, b;                                                                             \
+    for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(threadIdx.x * 0.001f + e); b[e] = (_Float16)(e * 0.01f); } \
+    f32x16 acc[2];                                                                          \
+    for (int k = 0; k < 2; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;               \
+    float v[8], w = 1.0001f;                                                                \
+    for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 0.5f + i;                              \
+    double d[4]; for (int i = 0; i < 4; ++i) d[i] = v[i];                                   \
+    float spare = v[3]; asm volatile("" : "+a"(spare));                                     \
+    unsigned sc = 0; typedef float f4 __attribute__((ext_vector_type(4))); f4 q4[2] = {{0,0,0,0},{0,0,0,0}}; \
+    __shared__ float lds[1024]; lds[threadIdx.x & 1023] = v[0]; __syncthreads();            \
+    unsigned ldsaddr = (threadIdx.x & 63) * 16;                                             \
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();                                   \
+    for (int it = 0; it < iters; ++it) {                                                    \
+      MF(0) REPV MF(1) REPV MF(0) REPV MF(1) REPV MF(0) REPV MF(1) REPV MF(0) REPV MF(1) REPV \
+    }                                                                                       \
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();                                   \
+    float s = 0.f;                                                                          \
+    for (int k = 0; k < 2; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r];                \
+    for (int i = 0; i < 8; ++i) s += v[i];                                                  \
+    for (int i = 0; i < 4; ++i) s += (float)d[i];                                           \
+    s += spare + (float)sc + q4[0][0] + q4[1][1];                                           \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                         \
+    if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;                            \
+  }
+
+KERNEL(ka0, MFMA_A, REPV_0) KERNEL(ka1, MFMA_A, REPV_1) KERNEL(ka2, MFMA_A, REPV_2) KERNEL(ka3, MFMA_A, REPV_3)
+KERNEL(ka4, MFMA_A, REPV_4) KERNEL(ka5, MFMA_A, REPV_5) KERNEL(ka6, MFMA_A, REPV_6) KERNEL(ka8, MFMA_A, REPV_8)
+KERNEL(kpk2, MFMA_A, REP_PK2) KERNEL(kpk4, MFMA_A, REP_PK4) KERNEL(krcp2, MFMA_A, REP_RCP2) KERNEL(krcp4, MFMA_A, REP_RCP4)
+KERNEL(kcvt4, MFMA_A, REP_CVT4) KERNEL(kacc4, MFMA_A, REP_ACC4) KERNEL(knop4, MFMA_A, REP_NOP4) KERNEL(ksalu4, MFMA_A, REP_SALU4)
+KERNEL(ksalu8, MFMA_A, REP_SALU8) KERNEL(kwait4, MFMA_A, REP_WAIT4) KERNEL(klds2, MFMA_A, REP_LDS2) KERNEL(klds4, MFMA_A, REP_LDS4)
+KERNEL(kmix, MFMA_A, REP_MIX)
+KERNEL(kv0, MFMA_V, REPV_0) KERNEL(kv2, MFMA_V, REPV_2) KERNEL(kv4, MFMA_V, REPV_4) KERNEL(kv6, MFMA_V, REPV_6) KERNEL(kv8, MFMA_V, REPV_8)
+
+
+// ---- { 8 x MFMA ; L x global_load_dwordx4 (1 KB per wave, L2 hits) } : what a weight-ring refill costs the issuing wave
+typedef float f4_t __attribute__((ext_vector_type(4)));
+#define GLD(i) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[(i) & 3]) : "v"(gp + 64 * ((i) & 7)) : "memory");
+template <int L>
+__global__ void kload(float* out, unsigned long long* ticks, int iters, const f4_t* src) {
+  f16x8 a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(threadIdx.x * 0.001f + e); b[e] = (_Float16)(e * 0.01f); }
+  f32x16 acc[2];
+  for (int k = 0; k < 2; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  f4_t ld[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  const f4_t* gp = src + (blockIdx.x & 7) * 4096 + (threadIdx.x & 63);
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    MFMA_A(0) if (L >= 1) { GLD(0) } MFMA_A(1) if (L >= 5) { GLD(4) } MFMA_A(0) if (L >= 3) { GLD(2) } MFMA_A(1) if (L >= 7) { GLD(6) }
+    MFMA_A(0) if (L >= 2) { GLD(1) } MFMA_A(1) if (L >= 6) { GLD(5) } MFMA_A(0) if (L >= 4) { GLD(3) } MFMA_A(1) if (L >= 8) { GLD(7) }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int k = 0; k < 2; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r];
+  for (int i = 0; i < 4; ++i) s += ld[i][0] + ld[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+
+typedef void (*kern_t)(float*, unsigned long long*, int);
+int main() {
+  float* out; unsigned long long* ticks;
+  (void)hipMalloc(&out, 256 * 1024 * sizeof(float)); (void)hipMalloc(&ticks, 8);
+  const int iters = 4000;
+  struct { const char* name; kern_t k; int n; } list[] = {
+      {"acc in AGPRs", ka0, 0}, {"acc in AGPRs", ka1, 1}, {"acc in AGPRs", ka2, 2}, {"acc in AGPRs", ka3, 3}, {"acc in AGPRs", ka4, 4},
+      {"acc in AGPRs", ka5, 5}, {"acc in AGPRs", ka6, 6}, {"acc in AGPRs", ka8, 8},
+      {"2 x v_pk_fma_f32", kpk2, 2}, {"4 x v_pk_fma_f32", kpk4, 4}, {"2 x v_rcp_f32", krcp2, 2}, {"4 x v_rcp_f32", krcp4, 4},
+      {"4 x v_cvt_pk_f16_f32", kcvt4, 4}, {"4 x v_accvgpr_read", kacc4, 4}, {"4 x s_nop", knop4, 4}, {"4 x s_add_u32", ksalu4, 4},
+      {"8 x s_add_u32", ksalu8, 8}, {"4 x s_waitcnt (nothing pending)", kwait4, 4}, {"2 x ds_read_b128", klds2, 2}, {"4 x ds_read_b128", klds4, 4},
+      {"2 fma + pk_fma + cvt_pk + s_add + s_waitcnt", kmix, 6},
+      {"acc in VGPRs", kv0, 0}, {"acc in VGPRs", kv2, 2}, {"acc in VGPRs", kv4, 4}, {"acc in VGPRs", kv6, 6}, {"acc in VGPRs", kv8, 8}};
+  for (int threads : {256, 512}) {
+    printf("== %d threads per CU (%d wave(s) per SIMD): core cycles per (MFMA + N x v_fma_f32), per wave\n", threads, threads / 256);
+    for (auto& e : list) {
+      hipLaunchKernelGGL(e.k, dim3(256), dim3(threads), 0, 0, out, ticks, 10);
+      hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0);
+      hipLaunchKernelGGL(e.k, dim3(256), dim3(threads), 0, 0, out, ticks, iters);
+      (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+      unsigned long long t; (void)hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+      printf("  %s, N = %d: %6.1f ticks per group  (%.3f ms)\n", e.name, e.n, (double)t / (iters * 8.0), ms);
+    }
+  }
+  f4_t* src; (void)hipMalloc(&src, 8 * 4096 * sizeof(f4_t) + 65536); (void)hipMemset(src, 0, 8 * 4096 * sizeof(f4_t) + 65536);
+  for (int threads : {256, 512}) {
+    printf("== %d threads per CU: core cycles per MFMA with L 1-KB global loads (L2 hits) per 8 MFMAs\n", threads);
+    auto run = [&](auto kern, int L) {
+      hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, out, ticks, 10, src);
+      hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, out, ticks, iters, src);
+      (void)hipDeviceSynchronize();
+      unsigned long long t; (void)hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+      printf("  L = %d: %6.1f ticks per MFMA\n", L, (double)t / (iters * 8.0));
+    };
+    run(kload<0>, 0); run(kload<1>, 1); run(kload<2>, 2); run(kload<3>, 3); run(kload<4>, 4); run(kload<6>, 6); run(kload<8>, 8);
+  }
+  return 0;
+}

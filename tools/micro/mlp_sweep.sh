@@ -7,5 +7,5 @@ for D in "$@"; do
   make CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $D" mlp_h3.o > /dev/null 2>&1
   make > /dev/null 2>&1
   echo "== $D"
-  (cd $R && python tools/mlp_stamps.py 2>&1 | tail -19 | grep -E "fc1|chain|fc2|epilogue|total"; python tools/mlp_bench.py 2>&1 | tail -1)
+  (cd $R && python tools/mlp_stamps.py 2>&1 | grep -E "drop=|fc1|chain|fc2|epilogue|store|LDS|total" | awk '{printf "%s | ", $0} /total/{print ""}'; python tools/mlp_bench.py 25 2>&1 | tail -2 | cut -c1-60)
 done
