@@ -38,6 +38,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define REP_LDS2 LDS1(0) LDS1(1)
 #define REP_LDS4 LDS1(0) LDS1(1) LDS1(0) LDS1(1)
 #define REP_MIX REPV_2 PK1(0) CVT1(3) SALU1(0) WAIT1(0)
+// six DEPENDENT fp32 FMAs (one register), and the same as two chains of three / three chains of two
+#define DEP1(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[0]) : "v"(w));
+#define REP_DEP6 DEP1(0) DEP1(0) DEP1(0) DEP1(0) DEP1(0) DEP1(0)
+#define REP_DEP4 DEP1(0) DEP1(0) DEP1(0) DEP1(0)
+#define DEP2(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[(i) & 1]) : "v"(w));
+#define REP_DEP2x3 DEP2(0) DEP2(1) DEP2(0) DEP2(1) DEP2(0) DEP2(1)
+#define EXP1(i) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(i) & 7]));
+// a slot like those of the MLP chain: 2 transcendental + 4 FMAs that use their results
+#define REP_SLOT RCP1(0) RCP1(1) VALU1(2) VALU1(3) VALU1(4) VALU1(5)
+#define REP_SLOTDEP RCP1(0) RCP1(1) DEP2(0) DEP2(1) DEP2(0) DEP2(1)
 
 // accumulators pinned to AGPRs ("a") or VGPRs ("v") through the asm constraint of the MFMA itself
 #define MFMA_A(k) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(a), "v"(b));
@@ -76,6 +86,7 @@ KERNEL(kpk2, MFMA_A, REP_PK2) KERNEL(kpk4, MFMA_A, REP_PK4) KERNEL(krcp2, MFMA_A
 KERNEL(kcvt4, MFMA_A, REP_CVT4) KERNEL(kacc4, MFMA_A, REP_ACC4) KERNEL(knop4, MFMA_A, REP_NOP4) KERNEL(ksalu4, MFMA_A, REP_SALU4)
 KERNEL(ksalu8, MFMA_A, REP_SALU8) KERNEL(kwait4, MFMA_A, REP_WAIT4) KERNEL(klds2, MFMA_A, REP_LDS2) KERNEL(klds4, MFMA_A, REP_LDS4)
 KERNEL(kmix, MFMA_A, REP_MIX)
+KERNEL(kdep6, MFMA_A, REP_DEP6) KERNEL(kdep4, MFMA_A, REP_DEP4) KERNEL(kdep2x3, MFMA_A, REP_DEP2x3) KERNEL(kslot, MFMA_A, REP_SLOT) KERNEL(kslotdep, MFMA_A, REP_SLOTDEP)
 KERNEL(kv0, MFMA_V, REPV_0) KERNEL(kv2, MFMA_V, REPV_2) KERNEL(kv4, MFMA_V, REPV_4) KERNEL(kv6, MFMA_V, REPV_6) KERNEL(kv8, MFMA_V, REPV_8)
 
 
@@ -117,6 +128,8 @@ int main() {
       {"4 x v_cvt_pk_f16_f32", kcvt4, 4}, {"4 x v_accvgpr_read", kacc4, 4}, {"4 x s_nop", knop4, 4}, {"4 x s_add_u32", ksalu4, 4},
       {"8 x s_add_u32", ksalu8, 8}, {"4 x s_waitcnt (nothing pending)", kwait4, 4}, {"2 x ds_read_b128", klds2, 2}, {"4 x ds_read_b128", klds4, 4},
       {"2 fma + pk_fma + cvt_pk + s_add + s_waitcnt", kmix, 6},
+      {"6 dependent v_fma_f32 (one chain)", kdep6, 6}, {"4 dependent v_fma_f32", kdep4, 4}, {"2 chains x 3 dependent v_fma_f32", kdep2x3, 6},
+      {"2 v_rcp + 4 independent fma", kslot, 6}, {"2 v_rcp + 4 fma that read the rcp results", kslotdep, 6},
       {"acc in VGPRs", kv0, 0}, {"acc in VGPRs", kv2, 2}, {"acc in VGPRs", kv4, 4}, {"acc in VGPRs", kv6, 6}, {"acc in VGPRs", kv8, 8}};
   for (int threads : {256, 512}) {
     printf("== %d threads per CU (%d wave(s) per SIMD): core cycles per (MFMA + N x v_fma_f32), per wave\n", threads, threads / 256);
