@@ -218,25 +218,47 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   };
   // fc1 of chunk hc: hidden rows 128 hc + 32 wave .. +32 (1 x 2 tiles), K = 256 from the x tile.  The B fragments of
   // k-step ks + 1 are read from LDS while the MFMAs of k-step ks run (two register sets).
+#ifndef SDY_MLP_PINNED
+#define SDY_MLP_PINNED 1
+#endif
+  // Memory instructions of the MFMA loops are pinned ONE behind each MFMA (tools/micro/mfma_valu_overlap.hip, fc1-like
+  // loop): a k-step's four LDS fragment reads issued back to back hold up the next MFMA by ~34 cycles (37.8 cycles per MFMA),
+  // left to the scheduler they end up in front of the MFMA they feed behind an s_waitcnt lgkmcnt(0) (37-41 in this kernel),
+  // one per MFMA a whole k-step ahead of its use they are free (32.3).
   auto fc1 = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     f16x8 bh[2][2], bl[2][2];
-    auto ldb = [&](int set, int ks) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int off = xs_off(32 * j + l31, 2 * ks + h);
-        bh[set][j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
-        bl[set][j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
-      }
+    auto ldb1 = [&](int set, int ks, int part) {   // part: (hi j0, hi j1, lo j0, lo j1)
+      const int j = part & 1;
+      const int off = xs_off(32 * j + l31, 2 * ks + h);
+      if (part < 2) bh[set][j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
+      else bl[set][j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
     };
-    ldb(0, 0);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) ldb1(0, 0, part);
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
       const int c = ks & 1;
-      if (ks + 1 < KS1) ldb(c ^ 1, ks + 1);
+#if SDY_MLP_PINNED
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 a_lo = r_lo[ks], a_hi = r_hi[ks];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int j = k & 1;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? a_lo : a_hi, (k >= 2 && k < 4) ? bl[c][j] : bh[c][j], acc[j], 0, 0, 0);
+        if (k < 4) { if (ks + 1 < KS1) ldb1(c ^ 1, ks + 1, k); }
+        else if (k == 4) r_lo[ks] = wp[ks * GROUP_F8 + 64];
+        else r_hi[ks] = wp[ks * GROUP_F8];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
+      if (ks + 1 < KS1) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) ldb1(c ^ 1, ks + 1, part);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[ks], bh[c][j], acc[j], 0, 0, 0);
 #pragma unroll
@@ -257,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ring refill
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the refill here: the scheduler otherwise sinks it next to its use
+#endif
     }
     wp += RING * GROUP_F8;
   };
@@ -516,11 +539,17 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         bl[set][j] = *reinterpret_cast<const f16x8*>(Hl + off);
       }
     };
+    auto ldb1 = [&](int set, int t, int part) {   // one of a k-step's four fragment reads: (hi j0, hi j1, lo j0, lo j1)
+      const int j = part & 1;
+      const int off = hs_off(32 * j + l31, 2 * t + h);
+      if (part < 2) bh[set][j] = *reinterpret_cast<const f16x8*>(Hh + off);
+      else bl[set][j] = *reinterpret_cast<const f16x8*>(Hl + off);
+    };
     ldb(0, 0);
 #pragma unroll
     for (int t = 0; t < KSC; ++t) {
       const int c = t & 1;
-      if (t + 1 < KSC) ldb(c ^ 1, t + 1);
+      if (!SDY_MLP_PINNED && t + 1 < KSC) ldb(c ^ 1, t + 1);
       __builtin_amdgcn_sched_barrier(0);
       Piece ps;
 #pragma unroll
@@ -532,6 +561,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
           const f16x8 a = (k < 2) ? r_lo[s] : r_hi[s];
           const f16x8 b = (k >= 2 && k < 4) ? bl[c][j] : bh[c][j];
           oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, oacc[mi][j], 0, 0, 0);
+          if (SDY_MLP_PINNED && mi == 0 && k < 4 && t + 1 < KSC) ldb1(c ^ 1, t + 1, k);   // one LDS read behind each MFMA
+          if (SDY_MLP_PINNED && !CHAIN) __builtin_amdgcn_sched_barrier(0);
           if constexpr (CHAIN) {
             if (SDY_MLP_SCALAR_CHAIN) { if (!((SDY_MLP_ABL >> (6 * mi + k)) & 1)) chain_slot(ps, 6 * mi + k, hc2 + 1, t & 1, t >> 1); }
             else chain_stage(ps, 6 * mi + k, hc2 + 1, t & 1, t >> 1);

@@ -116,6 +116,70 @@ __global__ void kload(float* out, unsigned long long* ticks, int iters, const f4
   if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
 }
 
+// ---- the fc1 loop of mlp_h3 in isolation: per k-step 6 MFMAs whose B operands were read from LDS during the previous
+// k-step (two register sets, s_waitcnt before use) and whose A operands come from a ring refilled by two 1-KB global loads
+template <int LDSR, int GLD_>
+__global__ void kfc1(float* out, unsigned long long* ticks, int iters, const f4_t* src) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+  for (int i = threadIdx.x; i < 65536 / 16; i += blockDim.x) reinterpret_cast<f4_t*>(lds)[i] = f4_t{0.01f, 0.02f, 0.03f, 0.04f};
+  __syncthreads();
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 ring_hi[4], ring_lo[4], bh[2][2], bl[2][2];
+  for (int i = 0; i < 4; ++i) for (int e = 0; e < 8; ++e) { ring_hi[i][e] = (_Float16)(0.01f * e + i); ring_lo[i][e] = (_Float16)(0.001f * e); }
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int e = 0; e < 8; ++e) { bh[a][b][e] = (_Float16)0.5f; bl[a][b][e] = (_Float16)0.25f; }
+  f32x16 acc[2];
+  for (int k = 0; k < 2; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  const unsigned la = (threadIdx.x & 63) * 16;
+  const h8* gp = reinterpret_cast<const h8*>(src) + (blockIdx.x & 7) * 4096 + (threadIdx.x & 63);
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks & 1;
+      if (LDSR == 1 || LDSR == 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh[c ^ 1][j] = *reinterpret_cast<const h8*>(lds + ((la + 2048 * j + 4096 * ks) & 65535));
+          bl[c ^ 1][j] = *reinterpret_cast<const h8*>(lds + ((la + 2048 * j + 4096 * ks + 32768) & 65535));
+        }
+        if (LDSR == 2) __builtin_amdgcn_sched_barrier(0);   // keep them a k-step ahead of their use (two register sets)
+      }
+      if (LDSR == 3) {   // ONE memory instruction pinned behind each MFMA: 4 LDS reads of the next k-step, 2 ring loads
+        const h8 a_lo = ring_lo[ks], a_hi = ring_hi[ks];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int j = k & 1;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? a_lo : a_hi, (k >= 2 && k < 4) ? bl[c][j] : bh[c][j], acc[j], 0, 0, 0);
+          if (k == 0) bh[c ^ 1][0] = *reinterpret_cast<const h8*>(lds + ((la + 4096 * ks) & 65535));
+          if (k == 1) bh[c ^ 1][1] = *reinterpret_cast<const h8*>(lds + ((la + 2048 + 4096 * ks) & 65535));
+          if (k == 2) bl[c ^ 1][0] = *reinterpret_cast<const h8*>(lds + ((la + 4096 * ks + 32768) & 65535));
+          if (k == 3) bl[c ^ 1][1] = *reinterpret_cast<const h8*>(lds + ((la + 2048 + 4096 * ks + 32768) & 65535));
+          if (GLD_ && k == 4) ring_lo[ks] = gp[ks * 128 + 64];
+          if (GLD_ && k == 5) ring_hi[ks] = gp[ks * 128];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring_lo[ks], bh[c][j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring_hi[ks], bl[c][j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring_hi[ks], bh[c][j], acc[j], 0, 0, 0);
+      if (GLD_) {
+        ring_hi[ks] = gp[ks * 128];
+        ring_lo[ks] = gp[ks * 128 + 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int k = 0; k < 2; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+
 typedef void (*kern_t)(float*, unsigned long long*, int);
 int main() {
   float* out; unsigned long long* ticks;
@@ -154,6 +218,17 @@ int main() {
       unsigned long long t; (void)hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
       printf("  L = %d: %6.1f ticks per MFMA\n", L, (double)t / (iters * 8.0));
     };
+    auto run2 = [&](auto kern, const char* what) {
+      hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, out, ticks, 10, src);
+      hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, out, ticks, iters, src);
+      (void)hipDeviceSynchronize();
+      unsigned long long t; (void)hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+      printf("  fc1-like loop, %s: %6.1f ticks per MFMA\n", what, (double)t / (iters * 24.0));
+    };
+    run2(kfc1<0, 0>, "registers only"); run2(kfc1<1, 0>, "+ 4 ds_read_b128 per 6 MFMAs feeding the next k-step");
+    run2(kfc1<0, 1>, "+ 2 global loads per 6 MFMAs refilling the ring (4 k-steps ahead)"); run2(kfc1<1, 1>, "both");
+    run2(kfc1<2, 0>, "+ 4 ds_read_b128 FENCED a k-step ahead"); run2(kfc1<2, 1>, "fenced LDS reads + ring loads");
+    run2(kfc1<3, 0>, "one LDS read pinned behind each of 4 MFMAs"); run2(kfc1<3, 1>, "one LDS read / ring load pinned behind each MFMA");
     run(kload<0>, 0); run(kload<1>, 1); run(kload<2>, 2); run(kload<3>, 3); run(kload<4>, 4); run(kload<6>, 6); run(kload<8>, 8);
   }
   return 0;
