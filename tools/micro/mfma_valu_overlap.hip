@@ -38,6 +38,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define REP_LDS2 LDS1(0) LDS1(1)
 #define REP_LDS4 LDS1(0) LDS1(1) LDS1(0) LDS1(1)
 #define REP_MIX REPV_2 PK1(0) CVT1(3) SALU1(0) WAIT1(0)
+// integer multiplies of a Philox round
+#define MAD64(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d[(i) & 3]) : "v"(v[(i) & 7]), "v"(w) : "vcc");
+#define REP_MAD2 MAD64(0) MAD64(1)
+#define REP_MAD4 MAD64(0) MAD64(1) MAD64(2) MAD64(3)
+#define MULHI(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(v[(i) & 7]) : "v"(w));
+#define MULLO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(v[(i) & 7]) : "v"(w));
+#define REP_MULHL4 MULHI(0) MULLO(1) MULHI(2) MULLO(3)
+#define XOR3(i) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(v[(i) & 7]) : "v"(w));
+#define REP_XOR4 XOR3(0) XOR3(1) XOR3(2) XOR3(3)
+#define CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v[(i) & 7]) : "v"(w), "s"(msk));
+#define REP_CND4 CND(0) CND(1) CND(2) CND(3)
+#define CMP(i) asm volatile("v_cmp_ge_u32 %0, %1, %2" : "=s"(msk) : "v"(v[(i) & 7]), "v"(w));
+#define REP_CMPCND CMP(0) CND(1) CMP(2) CND(3)
 // six DEPENDENT fp32 FMAs (one register), and the same as two chains of three / three chains of two
 #define DEP1(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[0]) : "v"(w));
 #define REP_DEP6 DEP1(0) DEP1(0) DEP1(0) DEP1(0) DEP1(0) DEP1(0)
@@ -63,6 +76,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 0.5f + i;                              \
     double d[4]; for (int i = 0; i < 4; ++i) d[i] = v[i];                                   \
     float spare = v[3]; asm volatile("" : "+a"(spare));                                     \
+    unsigned long long msk = 0x5555555555555555ull;                                         \
     unsigned sc = 0; typedef float f4 __attribute__((ext_vector_type(4))); f4 q4[2] = {{0,0,0,0},{0,0,0,0}}; \
     __shared__ float lds[1024]; lds[threadIdx.x & 1023] = v[0]; __syncthreads();            \
     unsigned ldsaddr = (threadIdx.x & 63) * 16;                                             \
@@ -75,7 +89,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     for (int k = 0; k < 2; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r];                \
     for (int i = 0; i < 8; ++i) s += v[i];                                                  \
     for (int i = 0; i < 4; ++i) s += (float)d[i];                                           \
-    s += spare + (float)sc + q4[0][0] + q4[1][1];                                           \
+    s += spare + (float)sc + q4[0][0] + q4[1][1] + (float)(msk & 1);                                           \
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                         \
     if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;                            \
   }
@@ -86,6 +100,8 @@ KERNEL(kpk2, MFMA_A, REP_PK2) KERNEL(kpk4, MFMA_A, REP_PK4) KERNEL(krcp2, MFMA_A
 KERNEL(kcvt4, MFMA_A, REP_CVT4) KERNEL(kacc4, MFMA_A, REP_ACC4) KERNEL(knop4, MFMA_A, REP_NOP4) KERNEL(ksalu4, MFMA_A, REP_SALU4)
 KERNEL(ksalu8, MFMA_A, REP_SALU8) KERNEL(kwait4, MFMA_A, REP_WAIT4) KERNEL(klds2, MFMA_A, REP_LDS2) KERNEL(klds4, MFMA_A, REP_LDS4)
 KERNEL(kmix, MFMA_A, REP_MIX)
+KERNEL(kmad2, MFMA_A, REP_MAD2) KERNEL(kmad4, MFMA_A, REP_MAD4) KERNEL(kmulhl4, MFMA_A, REP_MULHL4) KERNEL(kxor4, MFMA_A, REP_XOR4)
+KERNEL(kcnd4, MFMA_A, REP_CND4) KERNEL(kcmpcnd, MFMA_A, REP_CMPCND)
 KERNEL(kdep6, MFMA_A, REP_DEP6) KERNEL(kdep4, MFMA_A, REP_DEP4) KERNEL(kdep2x3, MFMA_A, REP_DEP2x3) KERNEL(kslot, MFMA_A, REP_SLOT) KERNEL(kslotdep, MFMA_A, REP_SLOTDEP)
 KERNEL(kv0, MFMA_V, REPV_0) KERNEL(kv2, MFMA_V, REPV_2) KERNEL(kv4, MFMA_V, REPV_4) KERNEL(kv6, MFMA_V, REPV_6) KERNEL(kv8, MFMA_V, REPV_8)
 
@@ -192,6 +208,8 @@ int main() {
       {"4 x v_cvt_pk_f16_f32", kcvt4, 4}, {"4 x v_accvgpr_read", kacc4, 4}, {"4 x s_nop", knop4, 4}, {"4 x s_add_u32", ksalu4, 4},
       {"8 x s_add_u32", ksalu8, 8}, {"4 x s_waitcnt (nothing pending)", kwait4, 4}, {"2 x ds_read_b128", klds2, 2}, {"4 x ds_read_b128", klds4, 4},
       {"2 fma + pk_fma + cvt_pk + s_add + s_waitcnt", kmix, 6},
+      {"2 x v_mad_u64_u32", kmad2, 2}, {"4 x v_mad_u64_u32", kmad4, 4}, {"2 x (v_mul_hi_u32 + v_mul_lo_u32)", kmulhl4, 4},
+      {"4 x v_bitop3_b32 (xor3)", kxor4, 4}, {"4 x v_cndmask_b32 (SGPR mask)", kcnd4, 4}, {"2 x (v_cmp_ge_u32 -> SGPR + v_cndmask)", kcmpcnd, 4},
       {"6 dependent v_fma_f32 (one chain)", kdep6, 6}, {"4 dependent v_fma_f32", kdep4, 4}, {"2 chains x 3 dependent v_fma_f32", kdep2x3, 6},
       {"2 v_rcp + 4 independent fma", kslot, 6}, {"2 v_rcp + 4 fma that read the rcp results", kslotdep, 6},
       {"acc in VGPRs", kv0, 0}, {"acc in VGPRs", kv2, 2}, {"acc in VGPRs", kv4, 4}, {"acc in VGPRs", kv6, 6}, {"acc in VGPRs", kv8, 8}};
