@@ -237,7 +237,8 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
       const int scol = p.ilv ? 32 * (l31 >> 4) + (l31 & 15) : l31;   // + (ilv ? 16 : 32) * t
       const int tstep = p.ilv ? 16 : 32;
       const int gcol = p.ilv ? 64 * wave + 4 * sc4 : DE * (sc4 >> 3) + 32 * wave + 4 * (sc4 & 7);
-      float* og = p.out + (long)cur.l * p.sC + (long)row0 * DN + gcol;
+      float* og = p.out + (long)cur.l * p.sC + (long)row0 * DN;           // uniform: rows are added in SGPR arithmetic
+      const unsigned olane = (unsigned)(srow * DN + gcol) * 4u;             // the lane part of every store address
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
           for (int hh = 0; hh < 2; ++hh) {
             const int row = 32 * j + 8 * g + srow + 4 * hh;
             const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (srow + 4 * hh) * 64 + 4 * sc4);
-            if (row0 + row < M) SDY_STREAM_STORE(og + (long)row * DN, v);
+            if (row0 + row < M) sdy_st16s(og + (long)(32 * j + 8 * g + 4 * hh) * DN, olane, v);
           }
           __builtin_amdgcn_wave_barrier();
         }
