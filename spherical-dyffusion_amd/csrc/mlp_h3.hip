@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     Cf[2 * ME + tid] = p.add_a ? p.add_a[c] : 1.0f;
     Cf[3 * ME + tid] = p.add_a ? p.add_d[c] : 0.0f;
   };
-  Cb2[tid] = p.b2[tid];
+  Cb2[tid] = DROP ? p.b2[tid] * p.drop_scale : p.b2[tid];   // (see s2e in the epilogue)
   if (t_begin < t_end) load_coeffs(t_begin / tpi);
   __syncthreads();
   if (t_begin < t_end) prefetch_x(t_begin);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         if (do_drop) {
           if (j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s.v[r] = sdy_keep16(pw[r], j, p.drop_thr) ? s.v[r] * p.drop_scale : 0.0f;
+          for (int r = 0; r < 4; ++r) s.v[r] = sdy_keep16(pw[r], j, p.drop_thr) ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
         }
         break;
       }
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         if (do_drop) {
           if (j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s.v[r] = sdy_keep16(pw[r], j, p.drop_thr) ? s.v[r] * p.drop_scale : 0.0f;
+          for (int r = 0; r < 4; ++r) s.v[r] = sdy_keep16(pw[r], j, p.drop_thr) ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
         }
         break;
       case 10: {   // fp16 hi and the fp32 residual (kept in e / t for the last slot; an inline-asm v_fma_mix_f32 here costs
@@ -630,6 +630,10 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   //      every wave passed the last chunk's barrier after its final x read), then residual add + 16-byte row stores
   {
     const float bscale = p.batch_scale ? p.batch_scale[z] : 1.0f;
+    // Both dropouts scale what they keep by 1 / (1 - p): the hidden one is folded into the fc2 accumulator scale, the output
+    // one into that scale and the bias (Cb2 holds b2 / (1 - p)) -- no multiply per value, and the fp16 split of the hidden
+    // activation sees the unscaled values.
+    const float s2e = do_drop ? p.s2 * p.drop_scale * p.drop_scale : p.s2;
     const uint32_t c1_base2 = (uint32_t)(((uint64_t)(zt + p.batch_offset) * (uint64_t)(ME >> 2)) & 0xFFFFFFFFu);
     float* Os = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -651,12 +655,11 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
           const int px = 32 * j + l31;
 #pragma unroll
           for (int r4 = 0; r4 < 4; r4 += 2) {   // value pairs: packed fp32 FMA / MUL
-            sdy_gf2 o = sdy_gf2{oacc[mi][j][4 * g4 + r4], oacc[mi][j][4 * g4 + r4 + 1]} * p.s2 +
+            sdy_gf2 o = sdy_gf2{oacc[mi][j][4 * g4 + r4], oacc[mi][j][4 * g4 + r4 + 1]} * s2e +
                         sdy_gf2{bv[g4][r4], bv[g4][r4 + 1]};
             if (do_drop) {
-              const sdy_gf2 od = o * p.drop_scale;
-              o = sdy_gf2{sdy_keep16(words[r4], j, p.drop_thr) ? od.x : 0.0f,
-                          sdy_keep16(words[r4 + 1], j, p.drop_thr) ? od.y : 0.0f};
+              o = sdy_gf2{sdy_keep16(words[r4], j, p.drop_thr) ? o.x : 0.0f,
+                          sdy_keep16(words[r4 + 1], j, p.drop_thr) ? o.y : 0.0f};
             }
             o = o * bscale;
             Os[(row0 + 8 * g4 + r4) * TN + px] = o.x;
