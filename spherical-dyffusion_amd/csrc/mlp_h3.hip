@@ -518,9 +518,6 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 #ifndef SDY_MLP_SCALAR_CHAIN
 #define SDY_MLP_SCALAR_CHAIN (!DROP)
 #endif
-#ifndef SDY_MLP_ABL
-#define SDY_MLP_ABL 0   // timing ablation only: bit s set = slot s of the interleaved chain is skipped (wrong results)
-#endif
   auto chain_piece = [&](int hc, int j, int g4) {
     Piece s;
 #pragma unroll
@@ -566,7 +563,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
           if (SDY_MLP_PINNED && mi == 0 && k < 4 && t + 1 < KSC) ldb1(c ^ 1, t + 1, k);   // one LDS read behind each MFMA
           if (SDY_MLP_PINNED && !CHAIN) __builtin_amdgcn_sched_barrier(0);
           if constexpr (CHAIN) {
-            if (SDY_MLP_SCALAR_CHAIN) { if (!((SDY_MLP_ABL >> (6 * mi + k)) & 1)) chain_slot(ps, 6 * mi + k, hc2 + 1, t & 1, t >> 1); }
+            if (SDY_MLP_SCALAR_CHAIN) chain_slot(ps, 6 * mi + k, hc2 + 1, t & 1, t >> 1);
             else chain_stage(ps, 6 * mi + k, hc2 + 1, t & 1, t >> 1);
             __builtin_amdgcn_sched_barrier(0);
           }
