@@ -1,0 +1,91 @@
+"""Register budget of the shipped kernels, read from the built library (no GPU needed).
+
+The persistent kernels run at the edge of the register file (mlp_h3: 256 + 256 registers, conv_h3: 253, dh_h3 / leg_par sized
+for two / three workgroups per CU); when an edit pushes one over, hipcc spills to scratch silently and the kernel loses 5-10 %
+(DESIGN.md section 4).  This test parses the gfx950 code objects embedded in libsdy_amd.so (clang offload bundles -> ELF notes ->
+the AMDGPU msgpack metadata) and asserts that the hot kernels have no private segment and keep their occupancy."""
+import os
+import re
+import struct
+
+import pytest
+
+msgpack = pytest.importorskip("msgpack")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "spherical-dyffusion_amd", "libsdy_amd.so")
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects(blob):
+    for m in re.finditer(MAGIC, blob):
+        off = m.start()
+        (n,) = struct.unpack_from("<Q", blob, off + 24)
+        p = off + 32
+        for _ in range(n):
+            o, s, tl = struct.unpack_from("<QQQ", blob, p)
+            p += 24
+            triple = blob[p:p + tl].decode()
+            p += tl
+            if "gfx950" in triple and s:
+                yield blob[off + o:off + o + s]
+
+
+def _kernels(elf):
+    """AMDGPU metadata note of a 64-bit little-endian ELF -> list of kernel dicts."""
+    assert elf[:4] == b"\x7fELF" and elf[4] == 2
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+    out = []
+    for i in range(shnum):
+        sh = shoff + i * shentsize
+        sh_type, = struct.unpack_from("<I", elf, sh + 4)
+        if sh_type != 7:   # SHT_NOTE
+            continue
+        off, size = struct.unpack_from("<QQ", elf, sh + 0x18)
+        p, end = off, off + size
+        while p + 12 <= end:
+            namesz, descsz, ntype = struct.unpack_from("<III", elf, p)
+            p += 12
+            name = elf[p:p + namesz]
+            p += (namesz + 3) & ~3
+            desc = elf[p:p + descsz]
+            p += (descsz + 3) & ~3
+            if name.startswith(b"AMDGPU") and ntype == 32:   # NT_AMDGPU_METADATA
+                md = msgpack.unpackb(desc, raw=False, strict_map_key=False)
+                out.extend(md.get("amdhsa.kernels", []))
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(LIB):
+        pytest.skip("libsdy_amd.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    blob = open(LIB, "rb").read()
+    ks = {}
+    for co in _code_objects(blob):
+        for k in _kernels(co):
+            ks[k[".name"]] = k
+    assert ks, "no gfx950 code objects found in libsdy_amd.so"
+    return ks
+
+
+HOT = ("mlp_h3_kernel", "conv_h3_kernel", "leg_par_kernel", "dh_h3_kernel", "rfft360_kernel", "irfft360_kernel", "leg_h3_kernel")
+
+
+def test_hot_kernels_do_not_spill(kernels):
+    hot = {n: k for n, k in kernels.items() if any(h in n for h in HOT)}
+    assert len(hot) >= 12, sorted(hot)
+    spilled = {n: k[".private_segment_fixed_size"] for n, k in hot.items() if k[".private_segment_fixed_size"] != 0}
+    assert not spilled, f"kernels with scratch (register spills): {spilled}"
+
+
+def test_register_budgets_match_the_intended_occupancy(kernels):
+    for n, k in kernels.items():
+        total = k[".vgpr_count"]   # gfx90a+: unified count (VGPRs + AGPRs, allocation granule included)
+        if "mlp_h3_kernel" in n:
+            assert total <= 512, (n, total)
+        elif "conv_h3_kernel" in n or "dh_h3_kernel" in n:
+            assert total <= 256, (n, total)          # two waves per SIMD (two workgroups of 4 waves / one of 8)
+        elif "leg_par_kernel" in n:
+            assert total <= 168, (n, total)          # three workgroups of 3 waves per CU
