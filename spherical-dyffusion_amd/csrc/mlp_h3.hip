@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   float* Cf = reinterpret_cast<float*>(Hs + 4 * TN * HC);   // per-image coefficients: pa | pd | add_a | add_d, [4][ME]
   float* Cb2 = Cf + 4 * ME;                                 // fc2 bias [ME] (constant): the epilogue reads it at LDS latency
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: row / weight-stream bases become scalar arithmetic
   int h = lane >> 5, l31 = lane & 31;
   // Persistent workgroup (one per CU): a contiguous range of tiles; tile t = (image z, 64-pixel slice n0).
   // The NEXT tile's pixels (and its norm coefficients) are requested into registers while this tile computes, so no
@@ -107,8 +108,9 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 
   // ---- weight ring: slot s holds group s of the block being consumed; refilled for the next block right after its use
   f16x8 r_hi[RING], r_lo[RING];
-  const wptr_t wbase = (wptr_t)(p.w + (size_t)wave * (NGROUPS + RING) * GROUP_F8 + lane);
-  wptr_t wp = wbase;
+  // (recomputed where it is needed, from a laundered lane index: kept in a register pair across the tile it is spilled)
+  auto wbase_of = [&](int ln) { return (wptr_t)(p.w + (size_t)wave * (NGROUPS + RING) * GROUP_F8 + ln); };
+  wptr_t wp = wbase_of(lane);
 #pragma unroll
   for (int s = 0; s < RING; ++s) {
     r_hi[s] = wp[s * GROUP_F8];
@@ -218,16 +220,39 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   };
   // fc1 of chunk hc: hidden rows 128 hc + 32 wave .. +32 (1 x 2 tiles), K = 256 from the x tile.  The B fragments of
   // k-step ks + 1 are read from LDS while the MFMAs of k-step ks run (two register sets).
-// (In the network the dropout variant LOSES 4 % with the pinned loops -- 3.32 -> 3.46 ms, while the variant without dropout
-//  gains 1.3 % -- so, like the scalar chain, they are used without dropout only.)
+// (With the Philox rounds inside the chain the dropout variant LOST 4 % with the pinned loops; with the rounds moved under
+//  fc1's MFMAs -- SDY_MLP_PHILOX_AHEAD below -- both variants take them.)
 #ifndef SDY_MLP_PINNED
-#define SDY_MLP_PINNED (!DROP)
+#define SDY_MLP_PINNED 1
 #endif
   // Memory instructions of the MFMA loops are pinned ONE behind each MFMA (tools/micro/mfma_valu_overlap.hip, fc1-like
   // loop): a k-step's four LDS fragment reads issued back to back hold up the next MFMA by ~34 cycles (37.8 cycles per MFMA),
   // left to the scheduler they end up in front of the MFMA they feed behind an s_waitcnt lgkmcnt(0) (37-41 in this kernel),
   // one per MFMA a whole k-step ahead of its use they are free (32.3).
-  auto fc1 = [&]() {
+#ifndef SDY_MLP_PHILOX_AHEAD
+#define SDY_MLP_PHILOX_AHEAD 1
+#endif
+  // Dropout masks of a hidden chunk generated AHEAD, under the MFMAs of its fc1 (which leave issue slots free: a Philox
+  // round -- two v_mad_u64_u32 and two three-input XORs -- hides behind an MFMA), instead of inside the chain, whose slots
+  // beside fc2's MFMAs are full: 4 calls (row groups g4) x 10 rounds, one round behind every other MFMA; words kept in
+  // mw[g4][].  In the network: 3.39 -> 3.26 ms per launch (together with the scalar chain and the pinned loops, which the
+  // dropout variant could not use while the rounds sat in the chain).
+  uint32_t mw[4][4];
+  uint32_t ac0 = 0, ac1 = 0, ac2 = 0, ac3 = 0, ak0 = 0, ak1 = 0;
+  auto philox_ahead = [&](int hc, int idx) {   // idx = 10 g4 + round
+    const int g4 = idx / 10, rnd = idx % 10;
+    if (rnd == 0) {
+      const int row0 = HC * hc + 32 * wave + 4 * h;
+      ac0 = (uint32_t)(n0 + l31); ac1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); ac2 = p.stream1; ac3 = call_z;
+      ak0 = p.seed_lo; ak1 = p.seed_hi;
+    }
+    const uint64_t p0 = (uint64_t)0xD2511F53u * ac0, p1 = (uint64_t)0xCD9E8D57u * ac2;
+    const uint32_t m0 = (uint32_t)(p1 >> 32) ^ ac1 ^ ak0, m2 = (uint32_t)(p0 >> 32) ^ ac3 ^ ak1;
+    ac0 = m0; ac1 = (uint32_t)p1; ac2 = m2; ac3 = (uint32_t)p0;
+    ak0 += 0x9E3779B9u; ak1 += 0xBB67AE85u;
+    if (rnd == 9) { mw[g4][0] = ac0; mw[g4][1] = ac1; mw[g4][2] = ac2; mw[g4][3] = ac3; }
+  };
+  auto fc1 = [&](int hc_fc1) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -254,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         if (k < 4) { if (ks + 1 < KS1) ldb1(c ^ 1, ks + 1, k); }
         else if (k == 4) r_lo[ks] = wp[ks * GROUP_F8 + 64];
         else r_hi[ks] = wp[ks * GROUP_F8];
+        if (DROP && SDY_MLP_PHILOX_AHEAD && ((6 * ks + k) & 1) == 0 && (6 * ks + k) / 2 < 40) philox_ahead(hc_fc1, (6 * ks + k) / 2);
         __builtin_amdgcn_sched_barrier(0);
       }
       } else {
@@ -298,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   auto chain_stage = [&](Piece& s, int st, int hc, int j, int g4) {
     const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
     const int px = 32 * j + l31;
-    if (do_drop && st < 10 && j == 0) {
+    if (do_drop && !SDY_MLP_PHILOX_AHEAD && st < 10 && j == 0) {
       if (st == 0) {
         s.c0 = (uint32_t)(n0 + l31); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = call_z;
         s.k0 = p.seed_lo; s.k1 = p.seed_hi;
@@ -382,9 +408,10 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         break;
       case 10: {
         if (do_drop) {
-          if (j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
+          if (!SDY_MLP_PHILOX_AHEAD && j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s.v[r] = sdy_keep16(pw[r], j, p.drop_thr) ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
+          for (int r = 0; r < 4; ++r)
+            s.v[r] = sdy_keep16(SDY_MLP_PHILOX_AHEAD ? mw[g4][r] : pw[r], j, p.drop_thr) ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
         }
         break;
       }
@@ -416,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   auto chain_slot = [&](Piece& s, int st, int hc, int j, int g4) {
     const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
     const int px = 32 * j + l31;
-    if (do_drop && st < 10 && j == 0) {
+    if (do_drop && !SDY_MLP_PHILOX_AHEAD && st < 10 && j == 0) {
       if (st == 0) {
         s.c0 = (uint32_t)(n0 + l31); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = call_z;
         s.k0 = p.seed_lo; s.k1 = p.seed_hi;
@@ -481,9 +508,10 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s.v[r] = fmaf(s.v[r], HS, s.q[r]);
         if (do_drop) {
-          if (j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
+          if (!SDY_MLP_PHILOX_AHEAD && j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s.v[r] = sdy_keep16(pw[r], j, p.drop_thr) ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
+          for (int r = 0; r < 4; ++r)
+            s.v[r] = sdy_keep16(SDY_MLP_PHILOX_AHEAD ? mw[g4][r] : pw[r], j, p.drop_thr) ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
         }
         break;
       case 10: {   // fp16 hi and the fp32 residual (kept in e / t for the last slot; an inline-asm v_fma_mix_f32 here costs
@@ -513,10 +541,10 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       }
     }
   };
-  // Measured (B = 25): without dropout fc2 || chain 5.44k -> 4.89k cycles per phase, kernel 3.11 -> 3.08 ms; with dropout the
-  // Philox rounds already fill the slots and the longer scalar form loses (6.45k -> 7.19k, 3.23 -> 3.28 ms): packed there.
+  // Measured (B = 25): without dropout fc2 || chain 5.44k -> 4.89k cycles per phase, kernel 3.11 -> 3.08 ms; with dropout it
+  // only pays once the Philox rounds are out of the chain (SDY_MLP_PHILOX_AHEAD).
 #ifndef SDY_MLP_SCALAR_CHAIN
-#define SDY_MLP_SCALAR_CHAIN (!DROP)
+#define SDY_MLP_SCALAR_CHAIN 1
 #endif
   auto chain_piece = [&](int hc, int j, int g4) {
     Piece s;
@@ -580,7 +608,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 
   stamp(1);   // x tile in LDS
   load_bias(0);
-  fc1();
+  fc1(0);
   stamp(2);
 #pragma unroll
   for (int pc = 0; pc < 8; ++pc) chain_piece(0, pc & 1, pc >> 1);
@@ -588,7 +616,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   __syncthreads();
   stamp(4);
   load_bias(1);
-  fc1();
+  fc1(1);
   stamp(5);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -603,11 +631,15 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     __syncthreads();
     if (hc < NCH - 1) {
       load_bias(hc + 1);
-      fc1();
+      fc1(hc + 1);
     }
     stamp(5 + 2 * hc);
   }
-  wp = wbase;   // the refills of the last block fetch block 0 again: the ring is ready for the next tile
+  {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    wp = wbase_of(ln);   // the refills of the last block fetch block 0 again: the ring is ready for the next tile
+  }
   asm volatile("" : "+v"(wp));   // (laundered: otherwise the 16 refill addresses become loop invariants in VGPRs)
   {
     const int nt = tile + 1;
