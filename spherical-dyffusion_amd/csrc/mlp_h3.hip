@@ -135,11 +135,14 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   };
   // per-image coefficient table in LDS (norm affine of x, affine of the residual): rewritten only when the image changes
   auto load_coeffs = [&](int zz) {
-    const long c = (long)zz * ME + tid;
-    Cf[tid] = p.pa ? p.pa[c] * SX : SX;
-    Cf[ME + tid] = p.pa ? p.pd[c] * SX : 0.0f;
-    Cf[2 * ME + tid] = p.add_a ? p.add_a[c] : 1.0f;
-    Cf[3 * ME + tid] = p.add_a ? p.add_d[c] : 0.0f;
+    // the thread index is rebuilt from the SGPR wave index and the lane count of the exec mask: kept in a register across the
+    // tile loop for this rare use (image changes) it is the one value the dropout variant spills
+    const int t = 64 * wave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const long c = (long)zz * ME + t;
+    Cf[t] = p.pa ? p.pa[c] * SX : SX;
+    Cf[ME + t] = p.pa ? p.pd[c] * SX : 0.0f;
+    Cf[2 * ME + t] = p.add_a ? p.add_a[c] : 1.0f;
+    Cf[3 * ME + t] = p.add_a ? p.add_d[c] : 0.0f;
   };
   Cb2[tid] = DROP ? p.b2[tid] * p.drop_scale : p.b2[tid];   // (see s2e in the epilogue)
   if (t_begin < t_end) load_coeffs(t_begin / tpi);
