@@ -9,8 +9,9 @@
 //             XOR-swizzled so that the MFMA fragment reads (ds_read_b128) are bank-conflict free.
 //   chunk hc  (4 chunks of 128 hidden channels, a runtime loop):
 //     fc1     wave w: hidden rows 128 hc + 32 w .. +32, all 64 px (1 x 2 tiles of 32 x 32), K = 256.
-//     chain   bias + GELU + Philox dropout on the accumulators, x16, split hi/lo -> LDS H[px][128 k] (same swizzle),
-//             two alternating buffers: ONE barrier per chunk.
+//     chain   bias + GELU + dropout select on the accumulators, x16, split hi/lo -> LDS H[px][128 k] (same swizzle),
+//             two alternating buffers: ONE barrier per chunk.  chain(hc) runs in 12-instruction-slot pieces beside the
+//             MFMAs of fc2(hc - 1); the chunk's Philox masks are generated beside the MFMAs of its fc1.
 //     fc2     wave w: output rows 64 w .. +64 (2 x 2 tiles, accumulators live across all chunks), K = this chunk's
 //             128 hidden channels read from LDS.  No cross-wave reduction.
 //   epilogue  bias, Philox dropout, drop-path scale, residual add, store.
