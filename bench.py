@@ -38,7 +38,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MEMBERS = 25
 HORIZON = 6
@@ -95,23 +94,13 @@ def launch_children(n: int) -> int:
 
 # ---- models / one step -------------------------------------------------------------------------------------------------
 def build_models(device):
-    import torch
+    """Forecaster + interpolator + sampler with trained-like random weights (`sdy_amd.synthetic`: no checkpoint can be
+    fetched here).  Product code only: nothing under `oracle/` or `tests/` is imported for the timed path."""
+    from sdy_amd import synthetic
 
-    import sdy_amd
-    from helpers import make_pair
-    from oracle.sfno import SFNOConfig
-
-    fcfg = SFNOConfig(in_chans=STATE_CH + FORCING_CH, out_chans=STATE_CH, nlat=NLAT, nlon=NLON, embed_dim=EMBED,
-                      num_layers=LAYERS, with_time_emb=True, min_time=0.0, max_time=HORIZON - 1.0)
-    icfg = SFNOConfig(in_chans=2 * STATE_CH + FORCING_CH, out_chans=STATE_CH, nlat=NLAT, nlon=NLON, embed_dim=EMBED,
-                      num_layers=LAYERS, with_time_emb=True, dropout_mlp=0.1, drop_path_rate=0.1, min_time=1.0,
-                      max_time=HORIZON - 1.0)
-    with torch.cuda.device(device):
-        fnet, fora, _ = make_pair(fcfg, STATE_CH, FORCING_CH, seed=4321)
-        inet, iora, _ = make_pair(icfg, 2 * STATE_CH, FORCING_CH, seed=4322, net_seed=1000)
-    exp = sdy_amd.MultiHorizonForecastingDYffusion(fnet, sdy_amd.InterpolationExperiment(inet, horizon=HORIZON),
-                                                   horizon=HORIZON)
-    return exp, (fora, iora)
+    exp, _, _ = synthetic.build_sampler(device, state_chans=STATE_CH, forcing_chans=FORCING_CH, nlat=NLAT, nlon=NLON,
+                                        embed=EMBED, layers=LAYERS, horizon=HORIZON)
+    return exp
 
 
 def one_pass(exp, x0, forcings):
@@ -249,12 +238,21 @@ def latency_b1(exp, device):
             "c3_kernel_ms_b1": round(kernel_ms, 2), "c3_stream_density_b1": round(kernel_ms / c3, 3)}
 
 
-def cpu_baseline(oracles, threads):
+def cpu_baseline(threads):
     """CPU oracle (same torch op sequence as the reference's CPU PyTorch path) on the host cores: one forecaster and one
-    interpolator forward at B = 1 (about 20-30 s of CPU work), scaled to a horizon-6 pass = 6 + 10 forwards."""
+    interpolator forward at B = 1 (about 20-30 s of CPU work), scaled to a horizon-6 pass = 6 + 10 forwards.  The only
+    place `oracle/` is imported, on rank 0 at N = 1 only; the oracle's weight generator produces the benchmark networks'
+    weights (tests/test_host_logic.py holds the two generators together)."""
     import torch
 
-    fora, iora = oracles
+    from oracle.sfno import OracleSFNO, SFNOConfig, make_state_dict
+
+    fcfg = SFNOConfig(in_chans=STATE_CH + FORCING_CH, out_chans=STATE_CH, nlat=NLAT, nlon=NLON, embed_dim=EMBED,
+                      num_layers=LAYERS, with_time_emb=True, min_time=0.0, max_time=HORIZON - 1.0)
+    icfg = SFNOConfig(in_chans=2 * STATE_CH + FORCING_CH, out_chans=STATE_CH, nlat=NLAT, nlon=NLON, embed_dim=EMBED,
+                      num_layers=LAYERS, with_time_emb=True, dropout_mlp=0.1, drop_path_rate=0.1, min_time=1.0,
+                      max_time=HORIZON - 1.0)
+    fora, iora = OracleSFNO(fcfg, make_state_dict(fcfg, seed=4321)), OracleSFNO(icfg, make_state_dict(icfg, seed=4322))
     torch.set_num_threads(threads)
     g = torch.Generator(device="cpu").manual_seed(1234)
     x = torch.randn(1, STATE_CH, NLAT, NLON, generator=g)
@@ -319,7 +317,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
     red_dev = torch.device("cpu") if args.share_gpu else device
 
-    exp, oracles = build_models(device)
+    exp = build_models(device)
     h3 = sdy_amd._lib.default_gemm_mode() == "h3"
 
     def barrier():
@@ -412,7 +410,7 @@ def main():
             if world == 1:
                 res["latency"] = latency_b1(exp, device)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(oracles, args.cpu_threads or min(32, os.cpu_count() or 1))
+            res["cpu_baseline"] = cpu_baseline(args.cpu_threads or min(32, os.cpu_count() or 1))
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

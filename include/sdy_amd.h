@@ -340,6 +340,19 @@ int sdy_lp_rel_terms(const float* gen, const sdy_var_table* targets, int t, int 
 int sdy_ensemble_metrics(const float* pred, const float* truth, const float* weights, int M, long member_stride,
                          int n_planes, int HW, double* out, void* stream);
 
+/* Per-timestep series terms of the reduced inference aggregator (MeanAggregator / AreaWeightedReducedMetric,
+ * src/ace_inference/core/aggregator/inference/reduced.py:105-266; metrics src/ace_inference/core/metrics.py:32-208), one
+ * pass over the ensemble.  Plane p = (sample s, time t), p = s*T + t:
+ *   member m of plane p at pred + m*member_stride + s*sample_stride + t*HW (M <= 64; the strides let the window driver's
+ *   member-stacked (members, samples, time, HW) VIEW of its device batch be read without a copy);
+ *   truth plane p at truth + s*truth_sample_stride + t*HW; weights: dev (HW), any normalisation.
+ *   out[p][0..7] += sum_w (mean_m x - truth)^2 | sum_w var_m(x) (unbiased) | sum_w fair CRPS | sum_w (mean_m x - truth) |
+ *                   sum_w mean_m x | sum_w (mean_m x)^2 | sum_w truth | sum_w truth^2
+ * out: dev double [n_sample*T*8], zeroed by the caller. */
+int sdy_ensemble_series(const float* pred, int M, long member_stride, long sample_stride, const float* truth,
+                        long truth_sample_stride, const float* weights, int n_sample, int T, int HW, double* out,
+                        void* stream);
+
 /* Time-mean accumulation of the inference aggregator (src/ace_inference/core/aggregator/inference/time_mean.py:97-117,
  * _add_or_initialize_time_mean): acc[p] += scale * sum over rows (r0, r1) and times t0 <= t < T of
  * x[r0*stride0 + r1*stride1 + t*HW + p].  x: dev, one variable of a window, (n0, n1, T, HW) with float strides for the
@@ -360,6 +373,10 @@ int sdy_time_mean_accumulate(const float* x, int n0, long stride0, int n1, long 
 #define SDY_FLAG_NONFINITE 1u
 #define SDY_FLAG_F16_RANGE 2u
 int sdy_status_flags(unsigned* flags, int reset, void* stream);
+/* The same without the synchronisation: the word is copied to `flags_host` (pinned host memory) when `stream` reaches the
+ * call, and cleared behind the copy if `reset`; read it after an event recorded behind the call has completed (the window
+ * driver reads a window's word, together with its loss terms, while the next window computes). */
+int sdy_status_flags_async(unsigned* flags_host, int reset, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Measurement.  While enabled, every kernel launch of sdy_sfno_forward is bracketed by a pair of

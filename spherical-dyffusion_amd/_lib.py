@@ -181,6 +181,9 @@ SIGNATURES = {
     "sdy_time_mean_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int,
                                           C.c_float, C.c_void_p, C.c_void_p]),
     "sdy_status_flags": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
+    "sdy_status_flags_async": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "sdy_ensemble_series": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sdy_profile_enable": (C.c_int, [C.c_int]),
     "sdy_profile_stage_count": (C.c_int, []),
     "sdy_profile_stage_name": (C.c_char_p, [C.c_int]),

@@ -438,6 +438,67 @@ __global__ __launch_bounds__(256) void ens_metrics_kernel(const float* __restric
   }
 }
 
+// ---- per-timestep series of the reduced inference aggregator (src/ace_inference/core/aggregator/inference/reduced.py:144-266)
+// The same pass with the planes addressed as (sample, time) through strides -- the window driver's member-stacked view
+// (members, samples, time, H, W) is a transposed view of the device batch, no copy -- and four more sums per plane for the
+// area-weighted mean / standard deviation of the ensemble mean and of the target (metrics.py:32-82):
+//   out[p][0..7] += sum_w (mean - t)^2 | sum_w var_m | sum_w fair CRPS | sum_w (mean - t) | sum_w mean | sum_w mean^2 |
+//                   sum_w t | sum_w t^2
+__global__ __launch_bounds__(256) void ens_series_kernel(const float* __restrict__ pred, int M, long member_stride,
+                                                          long sample_stride, const float* __restrict__ truth,
+                                                          long truth_sample_stride, const float* __restrict__ w, int T, int HW,
+                                                          double* __restrict__ out) {
+  const int pl = blockIdx.y;
+  const int smp = pl / T, t_i = pl - smp * T;
+  const float* pp = pred + (long)smp * sample_stride + (long)t_i * HW;
+  const float* tp = truth + (long)smp * truth_sample_stride + (long)t_i * HW;
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float x[ENS_MAX];
+    float mean = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < M; ++m) {
+      x[m] = pp[(long)m * member_stride + i];
+      mean += x[m];
+    }
+    mean /= (float)M;
+    const float t = tp[i], wi = w[i];
+    float var = 0.f, skill = 0.f, pair = 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float d = x[m] - mean;
+      var += d * d;
+      skill += fabsf(x[m] - t);
+      for (int n = m + 1; n < M; ++n) pair += fabsf(x[m] - x[n]);
+    }
+    var = M > 1 ? var / (float)(M - 1) : 0.f;
+    const float crps = M > 1 ? skill / (float)M - pair / (float)(M * (M - 1)) : skill;
+    const float e = mean - t;
+    const double wd = (double)wi;
+    a[0] += wd * e * e;
+    a[1] += wd * var;
+    a[2] += wd * crps;
+    a[3] += wd * e;
+    a[4] += wd * mean;
+    a[5] += wd * ((double)mean * mean);
+    a[6] += wd * t;
+    a[7] += wd * ((double)t * t);
+  }
+  __shared__ double sh[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    double v = a[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) sh[4 * q + wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int q = threadIdx.x;
+    atomicAdd(&out[8 * pl + q], sh[4 * q] + sh[4 * q + 1] + sh[4 * q + 2] + sh[4 * q + 3]);
+  }
+}
+
 }  // namespace
 
 // ---- time-mean accumulation (src/ace_inference/core/aggregator/inference/time_mean.py:97-117) ---------------------------
@@ -474,6 +535,19 @@ extern "C" int sdy_ensemble_metrics(const float* pred, const float* truth, const
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(ens_metrics_kernel, dim3(gx, n_planes), dim3(256), 0, (hipStream_t)stream, pred, truth, weights, M,
                      member_stride, HW, out);
+  return sdy_launch_status();
+}
+
+extern "C" int sdy_ensemble_series(const float* pred, int M, long member_stride, long sample_stride, const float* truth,
+                                   long truth_sample_stride, const float* weights, int n_sample, int T, int HW, double* out,
+                                   void* stream) {
+  if (!pred || !truth || !weights || !out || M < 1 || n_sample < 1 || T < 1 || HW < 1) return SDY_ERR_ARG;
+  if (M > ENS_MAX) return SDY_ERR_UNSUPPORTED;
+  if ((long)n_sample * T > 65535) return SDY_ERR_UNSUPPORTED;
+  int gx = (HW + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(ens_series_kernel, dim3(gx, n_sample * T), dim3(256), 0, (hipStream_t)stream, pred, M, member_stride,
+                     sample_stride, truth, truth_sample_stride, weights, T, HW, out);
   return sdy_launch_status();
 }
 
@@ -553,6 +627,14 @@ extern "C" int sdy_status_flags(unsigned* flags, int reset, void* stream) {
   SDY_HIP_TRY(hipMemcpyAsync(flags, d, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
   if (reset) SDY_HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned), (hipStream_t)stream));
   SDY_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return SDY_OK;
+}
+extern "C" int sdy_status_flags_async(unsigned* flags_host, int reset, void* stream) {
+  if (!flags_host) return SDY_ERR_ARG;
+  unsigned* d = nullptr;
+  SDY_TRY(sdy_flags_ptr(&d));
+  SDY_HIP_TRY(hipMemcpyAsync(flags_host, d, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (reset) SDY_HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned), (hipStream_t)stream));
   return SDY_OK;
 }
 

@@ -61,11 +61,8 @@ class DYffusion(torch.nn.Module):
         assert additional_interpolation_steps_factor == 0, \
             "additional_interpolation_steps_factor must be 0 when using before_t1_only schedule"
         assert interpolate_before_t1, "interpolate_before_t1 must be True when using before_t1_only schedule"
-        if refine_intermediate_predictions:
-            raise NotImplementedError("refine_intermediate_predictions=True (a second interpolator sweep, dyffusion.py:551-563) "
-                                      "is outside the shipped configuration")
-        if log_every_t is not None:
-            raise NotImplementedError("log_every_t (intermediate-state logging) is not on the sampling path")
+        # `log_every_t` only adds diagnostic tensors to what `sample_loop` returns (dyffusion.py:535-547); `sample()` drops
+        # them again, so a checkpoint that sets it loads and samples the same: accepted, nothing is logged.
         assert timesteps > 1, f"horizon must be > 1, but got {timesteps}. Please use datamodule.horizon with > 1"
         self.model = model
         self.interpolator = interpolator
@@ -126,18 +123,49 @@ class DYffusion(torch.nn.Module):
     def sampling_schedule(self):
         return self._sampling_schedule
 
+    def _named_schedule(self, name: str) -> List[float]:
+        """The reference's schedule names (documented at dyffusion.py:369-382): every name visits step 0 and all steps that
+        land on a data time step; what differs is which of the ARTIFICIAL steps (additional_interpolation_steps > 0) join:
+        "only_dynamics" none; "only_dynamics_plus<N>[_discrete]" N + 1 points spaced evenly in [0, first data step) (floored
+        when discrete); "every<N>[th|nd|rd]" every N-th artificial step; "first<N>" the first N of them, "first<x>" with
+        0 < x < 1 the first ceil(x * count)."""
+        import math
+        import re
+
+        artificial = sorted(self.artificial_interpolation_steps)
+        first_data_step = min(self.dynamical_steps) if self.dynamical_steps else self.num_timesteps - 1
+        m = re.fullmatch(r"only_dynamics(?:_plus(_discrete)?(\d+)(_discrete)?)?", name)
+        if m:
+            extra: List[float] = []
+            if m.group(2) is not None:
+                n = int(m.group(2)) + 1
+                extra = [first_data_step * i / n for i in range(n)]
+                if m.group(1) or m.group(3):
+                    extra = [float(math.floor(v)) for v in extra]
+        elif (m := re.fullmatch(r"every(\d+)(?:th|nd|rd|st)?", name)):
+            stride = int(m.group(1))
+            assert 1 <= stride <= self.num_timesteps, f"Invalid sampling schedule: {name}"
+            extra = artificial[::stride]
+        elif (m := re.fullmatch(r"first(\d*\.?\d+)(?:v2)?", name)):
+            amount = float(m.group(1))
+            if amount < 1:
+                assert amount > 0, f"Invalid sampling schedule: {name}, must end with number/float > 0"
+                count = math.ceil(amount * len(artificial))
+            else:
+                assert amount.is_integer(), f"If first_n >= 1, it must be an integer, but got {amount}"
+                assert amount <= self.num_timesteps, f"Invalid sampling schedule: {name}"
+                count = int(amount)
+            extra = artificial[:count]
+        else:
+            raise ValueError(f"Invalid sampling schedule: ``{name}``. ")
+        return sorted({0, *self.dynamical_steps, *extra})
+
     @sampling_schedule.setter
     def sampling_schedule(self, schedule):
-        """Diffusion steps the sampler visits (reference setter: dyffusion.py:384-455).  Explicit lists and the named
-        schedule "only_dynamics" (= [0] + every step that lands on a data time step) are in scope; the reference's other
-        names pick subsets of ARTIFICIAL steps, which do not exist in the shipped configuration
-        (additional_interpolation_steps = 0), and raise here."""
+        """Diffusion steps the sampler visits (reference setter: dyffusion.py:384-455): an explicit list, or one of the
+        reference's schedule names (`_named_schedule`)."""
         if isinstance(schedule, str):
-            if schedule != "only_dynamics":
-                raise NotImplementedError(f"sampling_schedule={schedule!r}: named schedules other than 'only_dynamics' "
-                                          "select artificial interpolation steps (outside the shipped configuration); "
-                                          "pass the list of diffusion steps instead")
-            schedule = sorted({0, *self.dynamical_steps})
+            schedule = self._named_schedule(schedule)
         steps = [int(v) if float(v).is_integer() else float(v) for v in schedule]
         if not steps or steps[0] != 0:
             steps = [0] + steps
@@ -245,11 +273,9 @@ class DYffusion(torch.nn.Module):
     def sample_loop(self, initial_condition, log_every_t=None, num_predictions: int = None, verbose=True, **kwargs):
         """Cold sampling (Alg. 2 of the paper; reference dyffusion.py:457-567): per visited diffusion step s one forecaster
         call x_hat = F(x_s, s), then x_{s'} = x_s + I(x_0, x_hat, s') - I(x_0, x_hat, s) with the interpolator I drawing
-        fresh dropout masks on every call.  Returns (final state, {"t{k}_preds": ...}) like the reference; the
-        `log_every_t` diagnostics and `refine_intermediate_predictions` are refused by the constructor."""
+        fresh dropout masks on every call.  Returns (final state, {"t{k}_preds": ...}) like the reference, minus the
+        `log_every_t` diagnostics (which `sample()` discards anyway)."""
         hp = self.hparams
-        if log_every_t is not None:
-            raise NotImplementedError("log_every_t: intermediate-state logging is not on the sampling path")
         if hp.sampling_type not in ("cold", "naive"):
             raise ValueError(f"unknown sampling type {hp.sampling_type}")
         assert len(initial_condition.shape) == 4, f"condition.shape: {initial_condition.shape} (should be 4D)"
@@ -293,6 +319,16 @@ class DYffusion(torch.nn.Module):
             if lands_on_data:
                 emit = x_s if (hp.use_cold_sampling_for_intermediate_steps or final) else x_next
                 preds[f"t{k}_preds"] = self._drop_carried_channel(emit)
+        if hp.refine_intermediate_predictions:
+            # a second sweep (dyffusion.py:551-563): every intermediate data time is re-interpolated between x_0 and the LAST
+            # forecast; the final time keeps the forecast itself
+            times = hp.prediction_timesteps or list(self.dynamical_steps.values())
+            for i_n in (t for t in times if t < self.num_timesteps):
+                label = int(i_n) if float(i_n).is_integer() else i_n
+                assert not float(i_n).is_integer() or f"t{label}_preds" in preds, f"t{label}_preds not in intermediates"
+                again = self.q_sample(x0=x_hat, x_end=initial_condition, t=None, interpolation_time=i_n,
+                                      is_artificial_step=False, **dict(kwargs))
+                preds[f"t{label}_preds"] = self._drop_carried_channel(again)
         return (x_hat if sched[-1] + 1 >= self.num_timesteps else x_s), preds
 
     @torch.inference_mode()

@@ -15,14 +15,24 @@ MI355X-first differences:
   the C ABI), so its results do not depend on how initial conditions / members are grouped or sharded over GPUs;
 * the carried state never leaves the device (the reference moves it to the CPU and back every window, `loop.py:78-83,115`);
 * writer / aggregator receive device tensors; `host_outputs=True` hands the writer pinned host copies made on a side
-  stream while the next window computes.
+  stream while the next window computes;
+* the loop never drains the device between windows (`prefetch` > 0): window i + 1 is pulled from the loader on a
+  background thread, staged in pinned host memory and uploaded on a side stream while window i computes (the reference gets
+  the same overlap from DataLoader workers, `src/ace_inference/core/data_loading/getters.py:160-166`); a window's loss terms
+  and the device's status word come back asynchronously and are read -- by `aggregator.record_batch(loss=...)` -- one window
+  later, while the next one is already running;
+* `forecast_steps_per_second` is the reference's "Total steps per second" (`src/ace_inference/inference/inference.py:294-298`:
+  steps x trajectories over the WHOLE duration of the call, loading included); the rate over the device time of the windows
+  alone is reported beside it (`forecast_steps_per_second_run_on_batch`).
 Derived variables (`compute_derived_quantities`) are not on the sampling path: pass `derive=` to apply your own.
 """
 from __future__ import annotations
 
+import queue
+import threading
 import time
 from collections import defaultdict
-from typing import Callable, Dict, Mapping, Optional, Tuple
+from typing import Callable, Dict, List, Mapping, Optional, Tuple
 
 import torch
 
@@ -134,10 +144,109 @@ def _remove_ic(d: Mapping[str, torch.Tensor], ensemble: bool) -> Dict[str, torch
     return {k: (v[:, :, 1:] if ensemble else v[:, 1:]) for k, v in d.items()}
 
 
+class _WindowPrefetcher:
+    """Iterates `loader` on a background thread, up to `depth` windows ahead of the consumer: every tensor of a window is
+    staged in pinned host memory and uploaded on a side stream, so neither the loader's own work (file reads, decoding --
+    here: whatever `next(loader)` costs) nor the host-to-device copy sits between two windows of compute.  Yields
+    `(window, device tensors, ready event)`; the consumer makes its stream wait for the event.  The reference overlaps
+    loading through DataLoader worker processes (`src/ace_inference/core/data_loading/getters.py:160-166`)."""
+
+    _END = object()
+
+    def __init__(self, loader, dev: torch.device, depth: int):
+        self.dev = dev
+        self.stream = torch.cuda.Stream(device=dev)
+        self.q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._stop = False
+        self.thread = threading.Thread(target=self._run, args=(loader,), name="sdy-window-prefetch", daemon=True)
+        self.thread.start()
+
+    def _put(self, item) -> bool:
+        while not self._stop:
+            try:
+                self.q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _run(self, loader):
+        try:
+            torch.cuda.set_device(self.dev)
+            for window in loader:
+                staged = {}
+                for k, v in window.data.items():
+                    if not v.is_cuda and not v.is_pinned():
+                        v = torch.empty(v.shape, dtype=v.dtype, pin_memory=True).copy_(v)
+                    staged[k] = v
+                with torch.cuda.stream(self.stream):
+                    win = {k: v.to(self.dev, torch.float32, non_blocking=True) for k, v in staged.items()}
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                if not self._put((window, win, ev)):
+                    return
+            self._put(self._END)
+        except BaseException as exc:       # handed to the consumer, which re-raises it in its own thread
+            self._put(exc)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is self._END:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            window, win, ev = item
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_event(ev)
+            for v in win.values():
+                v.record_stream(cur)      # allocated on the side stream, used (and released) on the compute stream
+            yield window, win
+
+    def close(self):
+        self._stop = True
+        while self.thread.is_alive():
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                pass
+            self.thread.join(timeout=0.05)
+
+
+def _sync_windows(loader, dev: torch.device):
+    for window in loader:
+        yield window, {k: v.to(dev, torch.float32, non_blocking=True) for k, v in window.data.items()}
+
+
+class _ChunkedMetrics(Mapping):
+    """`metrics` of a window that ran as several device batches (`max_batch`): the reference's loss is a mean over the batch
+    rows (`darcy_loss.py:214-228`), so the window's value is the row-weighted mean of the chunks' values."""
+
+    def __init__(self, parts: List[Tuple[int, Mapping[str, torch.Tensor]]]):
+        self._parts, self._values = parts, None
+
+    def _resolve(self):
+        if self._values is None:
+            n = float(sum(r for r, _ in self._parts))
+            keys = list(self._parts[0][1].keys())
+            self._values = {k: sum(m[k] * (r / n) for r, m in self._parts) for k in keys}
+        return self._values
+
+    def __getitem__(self, key):
+        return self._resolve()[key]
+
+    def __iter__(self):
+        return iter(self._resolve())
+
+    def __len__(self):
+        return len(self._resolve())
+
+
 def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps_in_memory: int,
                   n_ensemble_members: int = 1, eval_device=None, writer=None, derive: Optional[Callable] = None,
                   host_outputs: bool = False, trajectory_offset: int = 0,
-                  unit_range: Optional[Tuple[int, int]] = None) -> Dict[str, float]:
+                  unit_range: Optional[Tuple[int, int]] = None, prefetch: int = 2,
+                  max_batch: Optional[int] = None) -> Dict[str, float]:
     """`data`: an object with `.loader` (iterable of windows with `.data`: name -> (n_sample, steps + 1, H, W) and
     `.times`) or such an iterable.
 
@@ -150,7 +259,13 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
         ONE initial condition split over ranks, or any ragged share of ICs x members.  Writer / aggregator then receive
         flat `(count, time, H, W)` predictions with `start_sample=start`, targets for the initial conditions touched.
     Without `unit_range` every member of every initial condition present runs and predictions are presented as the
-    reference stacks them: `(members, n_sample, time, H, W)`."""
+    reference stacks them: `(members, n_sample, time, H, W)`.
+
+    `prefetch`: windows pulled ahead of the compute on a background thread (0 = pull each window on the calling thread, after
+    the previous one has been handed to the writer, as the reference's loop does without DataLoader workers).
+    `max_batch`: at most this many trajectories per device batch; a larger share runs as consecutive chunks of the same
+    window (each with its own `batch_offset`, so every trajectory still draws the stream of its global index) whose outputs
+    are concatenated -- bounds the network workspace (about 0.9 GB per trajectory at 180 x 360, E = 256)."""
     writer = writer if writer is not None else NullDataWriter()
     aggregator = aggregator if aggregator is not None else NullAggregator()
     members = int(n_ensemble_members)
@@ -158,77 +273,135 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
     dev = torch.device(eval_device) if eval_device is not None else torch.device("cuda", torch.cuda.current_device())
     if dev.type != "cuda":
         raise RuntimeError("sdy_amd.run_inference runs on the GPU only (no CPU fallback)")
+    if max_batch is not None and max_batch < 1:
+        raise ValueError(f"max_batch must be >= 1, got {max_batch}")
     if host_outputs:
         writer = _DeferredHostWriter(writer, dev)
     stitcher = WindowStitcher(n_forward_steps, writer, is_ensemble=ens)
     loader = data.loader if hasattr(data, "loader") else data
     timers: Dict[str, float] = defaultdict(float)
-    now = time.time()
+    t_begin = now = time.time()
     module = stepper.module
     n_rows = 0
-    for i, window in enumerate(loader):
-        timers["data_loading"] += time.time() - now
-        now = time.time()
-        i_time = i * forward_steps_in_memory
-        win = {k: v.to(dev, torch.float32, non_blocking=True) for k, v in window.data.items()}
-        n_sample = next(iter(win.values())).shape[0]
-        start, n_rows, ic_list, _, rect = plan_rows(n_sample, members, trajectory_offset, unit_range)
-        ic_rows = torch.tensor(ic_list, dtype=torch.long, device=dev)
-        # IC-major batch: row r is global trajectory start + r = (IC ic_rows[r], member (start + r) % members)
-        batch = {k: v.index_select(0, ic_rows) for k, v in win.items()}
-        # the stitcher carries targets for the initial conditions this process touches (all of them unless ragged)
-        stitcher.apply_initial_condition(batch, ic_rows if rect else ic_rows - ic_list[0])
-        if hasattr(module, "set_batch_offset"):
-            module.set_batch_offset(start)
-        stepped = stepper.run_on_batch(batch, None, n_forward_steps=forward_steps_in_memory)
-        last_state = {k: v[:, -1] for k, v in stepped.gen_data.items()}
-        if rect:       # present like the reference: members on a leading axis (a strided view, no copy)
-            ics = slice(None)
-            unfold = (lambda d: {k: v.view(n_sample, members, *v.shape[1:]).transpose(0, 1) for k, v in d.items()}) \
-                if ens else (lambda d: d)
-            first = slice(0, n_rows, members)
-        else:          # a ragged share: flat rows, targets of the initial conditions touched
-            ics = slice(ic_list[0], ic_list[-1] + 1)
-            unfold = lambda d: d  # noqa: E731
-            first = torch.tensor([ic_list.index(c) for c in range(ic_list[0], ic_list[-1] + 1)], device=dev)
-        flat = not rect
-        win = {k: v[ics] for k, v in win.items()}
-        target_data = derive(win) if derive is not None else win
-        gen_data, gen_norm = unfold(stepped.gen_data), unfold(stepped.gen_data_norm)
-        if derive is not None:
-            gen_data = derive(gen_data)
-        tgt_norm = {k: v[first] for k, v in stepped.target_data_norm.items()}
-        out = SteppedData(metrics=stepped.metrics, gen_data=gen_data, target_data=target_data, gen_data_norm=gen_norm,
-                          target_data_norm=tgt_norm)
-        torch.cuda.current_stream(dev).synchronize()
-        timers["run_on_batch"] += time.time() - now
-        now = time.time()
-        # ---- _inference_internal_loop (loop.py:120-153)
-        times = window.times
-        stacked = ens and not flat
-        if i_time > 0:
-            out = SteppedData(metrics=out.metrics, gen_data=_remove_ic(out.gen_data, stacked),
-                              target_data={k: v[:, 1:] for k, v in out.target_data.items()},
-                              gen_data_norm=_remove_ic(out.gen_data_norm, stacked),
-                              target_data_norm={k: v[:, 1:] for k, v in out.target_data_norm.items()})
-            if times is not None and hasattr(times, "isel"):
-                times = times.isel(time=slice(1, None))
-            i_time_agg = i_time + 1
-        else:
-            i_time_agg = i_time
-        stitcher.append(out.target_data, out.gen_data, times, last_state=last_state, start_sample=start if flat else 0)
+    prefetcher = _WindowPrefetcher(loader, dev, prefetch) if prefetch > 0 else None
+    windows = prefetcher if prefetcher is not None else _sync_windows(loader, dev)
+    device_spans = []          # (start event, end event) around each window's device work
+    pending = None             # the previous window's record_batch, issued once ITS loss has arrived (no drain of this one)
+
+    def flush(p):
+        if p is None:
+            return
+        out, i_time_agg, weights = p
+        kw = {"sample_weights": weights} if (weights is not None and getattr(aggregator, "accepts_sample_weights", False)) \
+            else {}
         aggregator.record_batch(loss=float(out.metrics["loss"]), target_data=out.target_data, gen_data=out.gen_data,
                                 target_data_norm=out.target_data_norm, gen_data_norm=out.gen_data_norm,
-                                i_time_start=i_time_agg)
-        del stepped, out
-        timers["writer_and_aggregator"] += time.time() - now
-        now = time.time()
+                                i_time_start=i_time_agg, **kw)
+
+    try:
+        for i, (window, win) in enumerate(windows):
+            timers["data_loading"] += time.time() - now
+            now = time.time()
+            i_time = i * forward_steps_in_memory
+            cur = torch.cuda.current_stream(dev)
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(cur)
+            n_sample = next(iter(win.values())).shape[0]
+            start, n_rows, ic_list, _, rect = plan_rows(n_sample, members, trajectory_offset, unit_range)
+            ic_rows = torch.tensor(ic_list, dtype=torch.long, device=dev)
+            # IC-major batch: row r is global trajectory start + r = (IC ic_rows[r], member (start + r) % members)
+            batch = {k: v.index_select(0, ic_rows) for k, v in win.items()}
+            # the stitcher carries targets for the initial conditions this process touches (all of them unless ragged)
+            stitcher.apply_initial_condition(batch, ic_rows if rect else ic_rows - ic_list[0])
+            step = n_rows if max_batch is None else min(n_rows, int(max_batch))
+            parts = []
+            for r0 in range(0, n_rows, step):
+                r1 = min(n_rows, r0 + step)
+                if hasattr(module, "set_batch_offset"):
+                    module.set_batch_offset(start + r0)
+                chunk = batch if (r0 == 0 and r1 == n_rows) else {k: v[r0:r1] for k, v in batch.items()}
+                parts.append((r1 - r0, stepper.run_on_batch(chunk, None, n_forward_steps=forward_steps_in_memory,
+                                                            defer_metrics=True)))
+            if len(parts) == 1:
+                stepped = parts[0][1]
+            else:
+                cat = lambda name: {k: torch.cat([getattr(s, name)[k] for _, s in parts], dim=0)  # noqa: E731
+                                    for k in getattr(parts[0][1], name)}
+                stepped = SteppedData(metrics=_ChunkedMetrics([(r, s.metrics) for r, s in parts]), gen_data=cat("gen_data"),
+                                      target_data=batch, gen_data_norm=cat("gen_data_norm"),
+                                      target_data_norm=cat("target_data_norm"))
+            del parts
+            last_state = {k: v[:, -1] for k, v in stepped.gen_data.items()}
+            weights = None
+            if rect:       # present like the reference: members on a leading axis (a strided view, no copy)
+                ics = slice(None)
+                unfold = (lambda d: {k: v.view(n_sample, members, *v.shape[1:]).transpose(0, 1) for k, v in d.items()}) \
+                    if ens else (lambda d: d)
+                first = slice(0, n_rows, members)
+            else:          # a ragged share: flat rows, targets of the initial conditions touched
+                ics = slice(ic_list[0], ic_list[-1] + 1)
+                unfold = lambda d: d  # noqa: E731
+                touched = list(range(ic_list[0], ic_list[-1] + 1))
+                first = torch.tensor([ic_list.index(c) for c in touched], device=dev)
+                # share of each touched initial condition's members that runs HERE: what its targets weigh in a mean over
+                # ranks (an initial condition cut by the shard boundary is touched by two ranks)
+                weights = [ic_list.count(c) / members for c in touched]
+            flat = not rect
+            win = {k: v[ics] for k, v in win.items()}
+            target_data = derive(win) if derive is not None else win
+            gen_data, gen_norm = unfold(stepped.gen_data), unfold(stepped.gen_data_norm)
+            if derive is not None:
+                gen_data = derive(gen_data)
+            tgt_norm = {k: v[first] for k, v in stepped.target_data_norm.items()}
+            out = SteppedData(metrics=stepped.metrics, gen_data=gen_data, target_data=target_data, gen_data_norm=gen_norm,
+                              target_data_norm=tgt_norm)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(cur)
+            device_spans.append((ev0, ev1))
+            if prefetch <= 0:      # the reference's timer semantics: the window is complete when the clock is read
+                cur.synchronize()
+            timers["run_on_batch_host"] += time.time() - now
+            now = time.time()
+            # ---- _inference_internal_loop (loop.py:120-153)
+            times = window.times
+            stacked = ens and not flat
+            if i_time > 0:
+                out = SteppedData(metrics=out.metrics, gen_data=_remove_ic(out.gen_data, stacked),
+                                  target_data={k: v[:, 1:] for k, v in out.target_data.items()},
+                                  gen_data_norm=_remove_ic(out.gen_data_norm, stacked),
+                                  target_data_norm={k: v[:, 1:] for k, v in out.target_data_norm.items()})
+                if times is not None and hasattr(times, "isel"):
+                    times = times.isel(time=slice(1, None))
+                i_time_agg = i_time + 1
+            else:
+                i_time_agg = i_time
+            stitcher.append(out.target_data, out.gen_data, times, last_state=last_state, start_sample=start if flat else 0)
+            flush(pending)         # window i - 1: its loss arrived long ago; the device is busy with window i meanwhile
+            pending = (out, i_time_agg, weights)
+            if prefetch <= 0:
+                flush(pending)
+                pending = None
+            del stepped, out
+            timers["writer_and_aggregator"] += time.time() - now
+            now = time.time()
+        flush(pending)
+        pending = None
+    finally:
+        if prefetcher is not None:
+            prefetcher.close()
     if hasattr(writer, "flush"):
         writer.flush()
-    total = timers["run_on_batch"]
-    if total > 0:
-        # the reference logs n_forward_steps x n_ICs per second (inference.py:294-298); here: x trajectories of this process
-        timers["forecast_steps_per_second"] = stitcher.i_time * max(n_rows, 1) / total
+    torch.cuda.current_stream(dev).synchronize()
+    timers["writer_and_aggregator"] += time.time() - now
+    timers["run_on_batch"] = sum(a.elapsed_time(b) for a, b in device_spans) * 1e-3     # device time of the windows
+    wall = time.time() - t_begin
+    timers["wall"] = wall
+    units = stitcher.i_time * max(n_rows, 1)
+    if wall > 0:
+        # the reference logs n_forward_steps x n_ICs over the whole duration (inference.py:294-298); here: x trajectories
+        timers["forecast_steps_per_second"] = units / wall
+    if timers["run_on_batch"] > 0:
+        timers["forecast_steps_per_second_run_on_batch"] = units / timers["run_on_batch"]
     for name, duration in timers.items():
-        print(f"{name}: {duration:.2f}" + ("" if name.endswith("per_second") else "s"))
+        print(f"{name}: {duration:.2f}" + ("" if "per_second" in name else "s"))
     return dict(timers)

@@ -10,7 +10,7 @@ the ensemble mean -- in ONE pass over the ensemble on the device (`sdy_ensemble_
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
@@ -53,9 +53,9 @@ def ensemble_metrics(truth: torch.Tensor, predicted: torch.Tensor, weights: torc
 
 
 class TorchDistributed:
-    """`reduce_mean` of the reference's `Distributed` singleton (`src/ace_inference/core/distributed.py`): mean over ranks
-    with `torch.distributed.all_reduce` (RCCL over xGMI on the GPU box; identity without a process group).  The reduce is
-    issued on a side stream: it belongs to `get_logs`, not to the sampling path, and never blocks the compute stream."""
+    """`reduce_mean` / `reduce_sum` of the reference's `Distributed` singleton (`src/ace_inference/core/distributed.py:70-94`):
+    `torch.distributed.all_reduce` over ranks (RCCL over xGMI on the GPU box; identity without a process group).  The reduce
+    is issued on a side stream: it belongs to `get_logs`, not to the sampling path, and never blocks the compute stream."""
 
     def __init__(self):
         import torch.distributed as dist
@@ -67,22 +67,26 @@ class TorchDistributed:
     def world_size(self) -> int:
         return self._dist.get_world_size() if self._dist is not None else 1
 
-    def reduce_mean(self, tensor: torch.Tensor) -> torch.Tensor:
+    def reduce_sum(self, tensor: torch.Tensor) -> torch.Tensor:
         if self._dist is None:
             return tensor
         if not tensor.is_cuda:
             out = tensor.clone()
             self._dist.all_reduce(out)
-            return out / self.world_size
+            return out
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=tensor.device)
         self._stream.wait_stream(torch.cuda.current_stream(tensor.device))
         with torch.cuda.stream(self._stream):
             out = tensor.clone()
             self._dist.all_reduce(out)
-            out /= self.world_size
         torch.cuda.current_stream(tensor.device).wait_stream(self._stream)
         return out
+
+    def reduce_mean(self, tensor: torch.Tensor) -> torch.Tensor:
+        if self._dist is None:
+            return tensor
+        return self.reduce_sum(tensor) / self.world_size
 
 
 class TimeMeanAggregator:
@@ -92,10 +96,20 @@ class TimeMeanAggregator:
     Same constructor keywords that matter (`area_weights`, `dist`, `target`, `is_ensemble`), same `record_batch(loss,
     target_data, gen_data, target_data_norm, gen_data_norm, i_time_start)` (what `run_inference` calls once per window) and
     the same numbers from `get_logs(label)`: `rmse/<name>`, `bias/<name>`, `rmse/channel_mean` of the time-mean maps.  The
-    maps stay on the device (`time_mean_maps()`), one HIP launch per variable and window adds a window's mean over members,
-    samples and time (`sdy_time_mean_accumulate`, strided views welcome); `get_logs` reduces the maps over ranks
-    (`dist.reduce_mean`) and takes RMSE / bias with `sdy_ensemble_metrics`.  The matplotlib / wandb images of the reference
-    are out of scope."""
+    maps stay on the device (`time_mean_maps()`), one HIP launch per variable and window adds a window's time means
+    (`sdy_time_mean_accumulate`, strided views welcome); `get_logs` combines ranks and takes RMSE / bias with
+    `sdy_ensemble_metrics`.  The matplotlib / wandb images of the reference are out of scope.
+
+    Ranks.  The reference shards whole initial conditions over ranks and averages the ranks' maps with equal weight
+    (`time_mean.py:147-148`, `Distributed.reduce_mean`).  Here a rank's share is any contiguous range of trajectories
+    (`ensemble.shard`: 25 members over 8 GPUs are 4, 3, 3, ... rows), so the maps are kept as SUMS over rows of per-row time
+    means next to the row count, both are summed over ranks (`dist.reduce_sum`) and divided at the end: every trajectory
+    weighs the same whatever the sharding, and one process gets exactly the reference's numbers.  Generated data may be the
+    member-stacked `(members, samples, time, lat, lon)` or, for a ragged share, flat `(rows, time, lat, lon)`; for a ragged
+    share `run_inference` also passes `sample_weights` (the fraction of each touched initial condition's members that ran on
+    this rank), which weigh the target maps the same way."""
+
+    accepts_sample_weights = True
 
     def __init__(self, area_weights: torch.Tensor, dist=None, target: str = "denorm", metadata=None,
                  log_individual_channels: bool = True, is_ensemble: bool = False):
@@ -108,44 +122,66 @@ class TimeMeanAggregator:
         self._dist = TorchDistributed() if dist is None else dist
         self._target_data: Dict[str, torch.Tensor] = {}
         self._gen_data: Dict[str, torch.Tensor] = {}
+        self._target_rows = 0.0       # sum over windows of the (weighted) sample count behind the target maps
+        self._gen_rows = 0.0          # ... of the trajectory count behind the generated maps
         self._n_batches = 0
 
     @staticmethod
-    def _accumulate(maps: Dict[str, torch.Tensor], data, t0: int, ensemble: bool) -> None:
+    def _accumulate(maps: Dict[str, torch.Tensor], data, t0: int, ensemble: bool,
+                    sample_weights: Optional[Sequence[float]] = None) -> float:
+        """maps[name] += sum over rows of the row's mean over times t0..T-1 (row weights optional); returns the row count."""
+        rows = 0.0
         for name, v in data.items():
             if not v.is_cuda:
                 raise RuntimeError("sdy_amd aggregators run on the GPU only (no CPU fallback)")
             v = v.to(torch.float32)
-            if ensemble:
-                assert v.dim() == 5, "ensemble data are (members, samples, time, lat, lon)"
+            if ensemble and v.dim() == 5:
                 n0, n1, T, H, W = v.shape
             else:
-                assert v.dim() == 4, "data are (samples, time, lat, lon)"
+                assert v.dim() == 4, "data are (samples, time, lat, lon) [or (members, samples, time, lat, lon)]"
                 (n1, T, H, W), n0 = v.shape, 1
             if v.stride(-1) != 1 or v.stride(-2) != W or v.stride(-3) != H * W:
                 v = v.contiguous()
-            s0, s1 = (v.stride(0), v.stride(1)) if ensemble else (0, v.stride(0))
+            s0, s1 = (v.stride(0), v.stride(1)) if v.dim() == 5 else (0, v.stride(0))
             if name not in maps:
                 maps[name] = torch.zeros(H, W, dtype=torch.float32, device=v.device)
             with torch.cuda.device(v.device):
-                check(lib.sdy_time_mean_accumulate(ptr(v), n0, s0, n1, s1, t0, T, H * W, 1.0 / (n0 * n1 * (T - t0)),
-                                                   ptr(maps[name]), current_stream()), "sdy_time_mean_accumulate")
+                if sample_weights is None:
+                    check(lib.sdy_time_mean_accumulate(ptr(v), n0, s0, n1, s1, t0, T, H * W, 1.0 / (T - t0), ptr(maps[name]),
+                                                       current_stream()), "sdy_time_mean_accumulate")
+                    rows = float(n0 * n1)
+                else:
+                    assert n0 == 1 and len(sample_weights) == n1, "one weight per sample"
+                    for j, wj in enumerate(sample_weights):
+                        check(lib.sdy_time_mean_accumulate(ptr(v[j]), 1, 0, 1, 0, t0, T, H * W, float(wj) / (T - t0),
+                                                           ptr(maps[name]), current_stream()), "sdy_time_mean_accumulate")
+                    rows = float(sum(sample_weights))
+        return rows
 
     @torch.no_grad()
-    def record_batch(self, loss, target_data, gen_data, target_data_norm, gen_data_norm, i_time_start: int = 0):
+    def record_batch(self, loss, target_data, gen_data, target_data_norm, gen_data_norm, i_time_start: int = 0,
+                     sample_weights: Optional[Sequence[float]] = None):
         if self._target == "norm":
             target_data, gen_data = target_data_norm, gen_data_norm
         t0 = 1 if i_time_start == 0 else 0          # the very first time of a run is the initial condition
-        self._accumulate(self._target_data, target_data, t0, ensemble=False)
-        self._accumulate(self._gen_data, gen_data, t0, ensemble=self._is_ensemble)
+        self._target_rows += self._accumulate(self._target_data, target_data, t0, ensemble=False,
+                                              sample_weights=sample_weights)
+        self._gen_rows += self._accumulate(self._gen_data, gen_data, t0, ensemble=self._is_ensemble)
         self._n_batches += 1
 
     def time_mean_maps(self) -> Dict[str, Dict[str, torch.Tensor]]:
-        """{"gen": {name: (H, W)}, "target": {...}}: time means so far, reduced over ranks, on the device."""
+        """{"gen": {name: (H, W)}, "target": {...}}: time means so far over every rank's trajectories, on the device."""
         if self._n_batches == 0:
             raise ValueError("No data recorded.")
-        red = lambda d: {k: self._dist.reduce_mean(v / self._n_batches) for k, v in d.items()}  # noqa: E731
-        return {"gen": red(self._gen_data), "target": red(self._target_data)}
+
+        def red(d, rows):
+            if not d:
+                return {}
+            dev = next(iter(d.values())).device
+            n = float(self._dist.reduce_sum(torch.tensor([rows], dtype=torch.float64, device=dev))[0])
+            return {k: self._dist.reduce_sum(v) / n for k, v in d.items()}
+
+        return {"gen": red(self._gen_data, self._gen_rows), "target": red(self._target_data, self._target_rows)}
 
     @torch.no_grad()
     def get_logs(self, label: str) -> Dict[str, float]:
@@ -159,3 +195,115 @@ class TimeMeanAggregator:
                 logs[f"bias/{name}"] = float(m["bias"])
         logs["rmse/channel_mean"] = sum(rmse_all.values()) / len(rmse_all)
         return {f"{label}/{k}": v for k, v in logs.items()} if len(label) != 0 else logs
+
+
+SERIES_METRICS = ("weighted_rmse", "weighted_bias", "weighted_mean_gen", "weighted_mean_target", "weighted_std_gen",
+                  "weighted_std_target")
+SERIES_METRICS_ENSEMBLE = ("weighted_crps", "weighted_ssr")
+
+
+def ensemble_series(truth: torch.Tensor, predicted: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """truth (n_sample, T, H, W), predicted (members, n_sample, T, H, W) -- any strides on the two leading axes, so the window
+    driver's member-stacked VIEW is read in place -- weights (H, W)  ->  (n_sample, T, 8) fp64: the area-weighted means of
+    (ens. mean - truth)^2 | member variance (unbiased) | fair CRPS | ens. mean - truth | ens. mean | (ens. mean)^2 | truth |
+    truth^2 per (sample, time) plane (`sdy_ensemble_series`: one pass, members in registers)."""
+    if not predicted.is_cuda:
+        raise RuntimeError("sdy_amd metrics run on the GPU only (no CPU fallback)")
+    assert predicted.dim() == 5 and predicted.shape[1:] == truth.shape, \
+        f"truth {tuple(truth.shape)} vs predicted {tuple(predicted.shape)}"
+    dev = predicted.device
+    M, n_sample, T, H, W = predicted.shape
+    p = predicted.to(torch.float32)
+    if p.stride(-1) != 1 or p.stride(-2) != W or p.stride(-3) != H * W:
+        p = p.contiguous()
+    t = truth.to(dev, torch.float32)
+    if t.stride(-1) != 1 or t.stride(-2) != W or t.stride(-3) != H * W:
+        t = t.contiguous()
+    w = weights.to(dev, torch.float32).contiguous()
+    out = torch.zeros(n_sample, T, 8, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.sdy_ensemble_series(ptr(p), M, p.stride(0), p.stride(1), ptr(t), t.stride(0), ptr(w), n_sample, T, H * W,
+                                      ptr(out), current_stream()), "sdy_ensemble_series")
+    return out / w.double().sum()
+
+
+class MeanAggregator:
+    """Per-timestep series of area-weighted metrics: host mirror of `MeanAggregator` / `AreaWeightedReducedMetric`
+    (`src/ace_inference/core/aggregator/inference/reduced.py:105-266`) minus the wandb table / xarray packaging.
+
+    Same constructor keywords that matter (`area_weights`, `target`, `n_timesteps`, `is_ensemble`, `dist`), same
+    `record_batch(loss, target_data, gen_data, target_data_norm, gen_data_norm, i_time_start)`; `get_series()` returns
+    `{"<metric>/<variable>": (n_timesteps,) fp64 tensor}` -- the arrays the reference puts into its table: mean over the
+    windows' samples, accumulated at `i_time_start ...` and divided by the number of windows that touched a time index, then
+    averaged over ranks (`dist.reduce_mean`, `reduced.py:247`).  Metrics: `weighted_rmse`, `weighted_bias` (of the ensemble
+    mean), `weighted_mean_gen / _target`, `weighted_std_gen / _target`, and for ensembles `weighted_crps` (fair) and
+    `weighted_ssr`; the reference's `weighted_grad_mag_percent_diff` is not computed (out of scope).
+    One `sdy_ensemble_series` launch per variable and window reads the member-stacked view in place; the accumulators are
+    (n_timesteps,) fp64 tensors on the device.
+
+    Ensemble metrics need every member of an initial condition on one rank (the reference's IC sharding): a ragged share
+    (`run_inference(unit_range=...)` cutting through an IC's members) hands over flat rows and is refused."""
+
+    def __init__(self, area_weights: torch.Tensor, target: str = "denorm", n_timesteps: int = 1, is_ensemble: bool = False,
+                 dist=None, device=None, metadata=None):
+        if target not in ("norm", "denorm"):
+            raise ValueError(f"target must be 'norm' or 'denorm', got {target!r}")
+        self._area_weights = area_weights
+        self._target = target
+        self._n_timesteps = int(n_timesteps)
+        self.is_ensemble = is_ensemble
+        self._dist = TorchDistributed() if dist is None else dist
+        self._total: Dict[str, Dict[str, torch.Tensor]] = {}      # metric -> variable -> (n_timesteps,) fp64
+        self._n_batches: Optional[torch.Tensor] = None            # (n_timesteps,) int32, as AreaWeightedReducedMetric
+
+    @property
+    def metric_names(self) -> List[str]:
+        return list(SERIES_METRICS + (SERIES_METRICS_ENSEMBLE if self.is_ensemble else ()))
+
+    @torch.no_grad()
+    def record_batch(self, loss, target_data, gen_data, target_data_norm, gen_data_norm, i_time_start: int = 0):
+        if self._target == "norm":
+            target_data, gen_data = target_data_norm, gen_data_norm
+        n_time = None
+        for name, gen in gen_data.items():
+            if self.is_ensemble:
+                if gen.dim() != 5:
+                    raise ValueError("MeanAggregator(is_ensemble=True) needs member-stacked (members, samples, time, lat, lon) "
+                                     "predictions: ensemble-mean RMSE / CRPS / spread of an initial condition need all of its "
+                                     "members on one rank (shard whole initial conditions, or use TimeMeanAggregator)")
+                pred = gen
+            else:
+                pred = gen[None]
+            s = ensemble_series(target_data[name], pred, self._area_weights)       # (n_sample, T, 8)
+            E = pred.shape[0]
+            mse, var, crps, bias, mg, mg2, mt, mt2 = s.unbind(dim=-1)
+            rmse = mse.sqrt()
+            vals = {"weighted_rmse": rmse, "weighted_bias": bias, "weighted_mean_gen": mg, "weighted_mean_target": mt,
+                    "weighted_std_gen": (mg2 - mg * mg).clamp_min(0.0).sqrt(),
+                    "weighted_std_target": (mt2 - mt * mt).clamp_min(0.0).sqrt()}
+            if self.is_ensemble:
+                vals["weighted_crps"] = crps
+                vals["weighted_ssr"] = var.sqrt() * ((E + 1) / E) ** 0.5 / rmse
+            n_time = s.shape[1]
+            sl = slice(i_time_start, i_time_start + n_time)
+            for metric, v in vals.items():
+                tot = self._total.setdefault(metric, {})
+                if name not in tot:
+                    tot[name] = torch.zeros(self._n_timesteps, dtype=torch.float64, device=s.device)
+                tot[name][sl] += v.mean(dim=0)                                        # mean over the window's samples
+            if self._n_batches is None:
+                self._n_batches = torch.zeros(self._n_timesteps, dtype=torch.int32, device=s.device)
+        if n_time is not None:
+            self._n_batches[i_time_start:i_time_start + n_time] += 1
+
+    @torch.no_grad()
+    def get_series(self) -> Dict[str, torch.Tensor]:
+        if not self._total:
+            raise ValueError("No batches have been recorded.")
+        return {f"{metric}/{name}": self._dist.reduce_mean(tot / self._n_batches)
+                for metric, per_var in self._total.items() for name, tot in per_var.items()}
+
+    @torch.no_grad()
+    def get_logs(self, label: str):
+        """`reduced.py:252-266` puts the series into one wandb table under `<label>/series`; here: the arrays themselves."""
+        return {f"{label}/series": {k: v.cpu().numpy() for k, v in self.get_series().items()}}

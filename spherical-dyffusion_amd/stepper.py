@@ -9,11 +9,15 @@ condition as their first time step), same semantics of `Packer`, `StandardNormal
 MI355X-first differences: every variable stays on the device for the whole window (the reference moves each generated
 step to the CPU, `stepper_multistep.py:410`); normalise+pack, prescriber+unpack+denormalise+AR-feedback and the loss
 terms are one HIP launch each per step (`sdy_norm_pack`, `sdy_step_finish`, `sdy_lp_rel_terms`); the only host sync is
-one read of the loss terms at the end of the window.  torch owns the buffers; no arithmetic runs in torch.
+one read of the loss terms at the end of the window -- and with `defer_metrics=True` not even that: the terms and the
+device's sticky status word travel to pinned host memory behind the window's last launch and `SteppedData.metrics`
+waits for them on first access (the window driver reads them while the NEXT window computes).  torch owns the buffers;
+no arithmetic runs in torch.
 """
 from __future__ import annotations
 
 import ctypes as C
+from collections.abc import Mapping
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -33,6 +37,47 @@ class Prescriber:
     def __post_init__(self):
         if self.interpolate and self.mask_value != 1:
             raise ValueError(f"Interpolation requires mask_value to be 1, but it is set to {self.mask_value}.")
+
+
+class WindowMetrics(Mapping):
+    """`SteppedData.metrics` of a window whose LpLoss terms (and status word) are still on their way to the host: a read-only
+    mapping `loss`, `loss_step_<i>` (LpLoss.rel, `src/ace_inference/training/utils/darcy_loss.py:214-228`) that waits for the
+    copy's event on first access, then raises if a kernel of the window flagged an fp16-range overflow / non-finite
+    statistics (include/sdy_amd.h, `sdy_status_flags`)."""
+
+    def __init__(self, terms_host: torch.Tensor, flags_host: Optional[torch.Tensor], event, where: str):
+        self._terms, self._flags, self._event, self._where = terms_host, flags_host, event, where
+        self._values: Optional[Dict[str, torch.Tensor]] = None
+
+    def ready(self) -> bool:
+        return self._values is not None or self._event.query()
+
+    def _resolve(self) -> Dict[str, torch.Tensor]:
+        if self._values is None:
+            self._event.synchronize()
+            if self._flags is not None:
+                from . import ops
+                flags = int(self._flags[0])
+                # a NaN slips through the kernels' max-based range guards (fmax ignores NaN) and the last block's MLP output
+                # meets no InstanceNorm: the prediction error read back here is the last line of defence
+                if not bool(torch.isfinite(self._terms[..., 0]).all()) and bool(torch.isfinite(self._terms[..., 1]).all()):
+                    flags |= ops.FLAG_NONFINITE
+                ops.raise_on_status_flags(flags, self._where)
+            terms = self._terms
+            per_step = (terms[..., 0].sqrt() / terms[..., 1].sqrt()).mean(dim=1)
+            vals = {f"loss_step_{i}": per_step[i].to(torch.float32) for i in range(per_step.shape[0])}
+            vals["loss"] = per_step.sum().to(torch.float32)
+            self._values = vals
+        return self._values
+
+    def __getitem__(self, key):
+        return self._resolve()[key]
+
+    def __iter__(self):
+        return iter(self._resolve())
+
+    def __len__(self):
+        return len(self._resolve())
 
 
 @dataclass
@@ -79,7 +124,9 @@ class MultiStepStepper:
 
     # ---- run_on_batch -------------------------------------------------------------------------------------------------
     def run_on_batch(self, data: Dict[str, torch.Tensor], optimization=None, n_forward_steps: int = 1,
-                     aggregator=None) -> SteppedData:
+                     aggregator=None, defer_metrics: bool = False) -> SteppedData:
+        """`defer_metrics=True` (not in the reference): return without draining the stream; `metrics` then waits for the
+        window's loss terms on first access (`WindowMetrics`)."""
         any_t = next(iter(data.values()))
         assert any_t.dim() == 4, "expected (n_sample, n_timesteps, n_lat, n_lon) per variable"
         B, T1, H, W = any_t.shape
@@ -159,14 +206,17 @@ class MultiStepStepper:
                     forcing = torch.empty(B, n_f, H, W, dtype=torch.float32, device=dev)
                     check(lib.sdy_norm_pack(C.byref(f_tab), th, T1, B, HW, ptr(forcing), stream()), "sdy_norm_pack")
 
-        # metrics (LpLoss.rel, darcy_loss.py:214-228): one device->host read for the whole window
-        terms = loss_terms.cpu()
-        if self.check_status:     # the stream is drained by the read above: the sticky status word costs one 4-byte copy
-            from . import ops
-            ops.raise_on_status_flags(ops.status_flags(reset=True, device=dev), "MultiStepStepper.run_on_batch")
-        per_step = (terms[..., 0].sqrt() / terms[..., 1].sqrt()).mean(dim=1)
-        metrics = {f"loss_step_{i}": per_step[i].to(torch.float32) for i in range(n_forward_steps)}
-        metrics["loss"] = per_step.sum().to(torch.float32)
+            # metrics (LpLoss.rel, darcy_loss.py:214-228): one device->host copy for the whole window, into pinned memory
+            # behind the window's last launch, with the sticky status word (4 bytes) right behind it
+            terms_host = torch.empty(loss_terms.shape, dtype=torch.float64, pin_memory=True)
+            terms_host.copy_(loss_terms, non_blocking=True)
+            flags_host = None
+            if self.check_status:
+                flags_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+                check(lib.sdy_status_flags_async(ptr(flags_host), 1, stream()), "sdy_status_flags_async")
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        metrics = WindowMetrics(terms_host, flags_host, done, "MultiStepStepper.run_on_batch")
         # normalised targets for the caller (full_data_norm of the reference): one launch per variable, the (B, T1) axes
         # flattened into the batch axis of the same kernel
         target_norm = {}
@@ -179,6 +229,8 @@ class MultiStepStepper:
                     target_norm[name] = out
                 else:
                     target_norm[name] = v
+        if not defer_metrics:
+            len(metrics)          # waits for the copy; raises on a flagged window
         if aggregator is not None:
             aggregator.record_batch(float(metrics["loss"]), target_data=data, gen_data=gen, target_data_norm=target_norm,
                                     gen_data_norm=gen_norm)

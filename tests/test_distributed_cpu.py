@@ -127,3 +127,50 @@ def test_time_mean_maps_reduce_over_ranks():
     from sdy_amd.metrics import TorchDistributed
     assert TorchDistributed().reduce_mean(torch.ones(2)).tolist() == [1.0, 1.0]     # no process group: identity
 
+
+
+def _weighted_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sdy_amd import ensemble
+    from sdy_amd.metrics import TimeMeanAggregator, TorchDistributed
+
+    # 5 members of one initial condition over 2 ranks -> 3 + 2 rows; two windows.  What record_batch leaves behind on a rank
+    # (the sums over ITS rows of the rows' time means, and its row count) is written directly: the accumulation kernel needs a
+    # GPU (tests/test_gpu_golden.py), the combination over ranks is what this test is about.
+    g = torch.Generator().manual_seed(5)
+    tm = torch.randn(2, 5, 4, 8, generator=g)                 # per-window, per-trajectory time means
+    tgt = torch.randn(2, 4, 8, generator=g)                   # per-window target time mean (one IC)
+    start, cnt, _, _ = ensemble.shard(1, 5, rank, world)
+    agg = TimeMeanAggregator(torch.ones(4, 8), dist=TorchDistributed(), is_ensemble=True)
+    agg._gen_data = {"a": tm[:, start:start + cnt].sum(dim=(0, 1))}
+    agg._gen_rows = 2.0 * cnt
+    w = cnt / 5.0                                             # run_inference's sample_weights for a cut initial condition
+    agg._target_data = {"a": (tgt * w).sum(dim=0)}
+    agg._target_rows = 2.0 * w
+    agg._n_batches = 2
+    maps = agg.time_mean_maps()
+    ret[rank] = (cnt, maps["gen"]["a"], maps["target"]["a"], tm.mean(dim=(0, 1)), tgt.mean(dim=0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_time_mean_maps_weigh_ranks_by_their_rows():
+    """Uneven shards (25 members over 8 GPUs are 4, 3, 3, ...; here 5 over 2 = 3 + 2): the maps over ranks must equal the
+    single-process maps, i.e. every trajectory weighs the same -- sums and row counts are all-reduced, not rank means."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_weighted_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert [ret[r][0] for r in range(2)] == [3, 2]
+    for r in range(2):
+        _, gen, tgt, gen_want, tgt_want = ret[r]
+        assert torch.allclose(gen, gen_want, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(tgt, tgt_want, rtol=1e-6, atol=1e-6)
+    # an unweighted mean of the two ranks' means would NOT be the single-process map
+    g = torch.Generator().manual_seed(5)
+    tm = torch.randn(2, 5, 4, 8, generator=g)
+    naive = 0.5 * (tm[:, :3].mean(dim=(0, 1)) + tm[:, 3:].mean(dim=(0, 1)))
+    assert not torch.allclose(naive, tm.mean(dim=(0, 1)), rtol=1e-3, atol=1e-3)

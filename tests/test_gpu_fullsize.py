@@ -105,6 +105,127 @@ def test_c4_rollout_25_members_through_the_window_driver():
 
     r = c4_rollout.run(torch.device("cuda", 0), steps=12, members=25)
     assert r["finite"] and r["windows"] == 2
+    assert r["wall_over_run_on_batch"] < 1.5, r          # the loader is prefetched: wall time ~ device time of the windows
     assert r["prediction_shape"] == (25, 1, 6, NLAT, NLON)          # second window: initial time dropped, members stacked
     assert r["member_forecast_steps_per_s"] > 10.0
     assert r["time_mean_rmse_channel_mean"] > 0.0
+
+
+def test_c5_shape_4_ics_x_25_members_whole_job_and_8_gpu_shares():
+    """BASELINE.json configs[4] in one window: 4 initial conditions x 25 members at full grid / width / depth through
+    run_inference -> stepper -> sampler (`src/configs/inference/ckpts_from_huggingface_10years.yaml`; the reference shards
+    initial conditions over ranks, `src/ace_inference/core/data_loading/inference.py:110-113`).  Once as the whole job on one
+    GPU (B = 100, also as two device batches of 50: `max_batch`), then as the shares `ensemble.shard(4, 25, rank, 8)` gives
+    ranks 0, 3 and 7 of an 8-GPU node: 13 rows of IC 0; 13 rows that straddle ICs 1 and 2 (the cut inside an IC's members);
+    the last 12 rows of IC 3.  A share's rows must equal the whole job's rows (2e-5: masks are bit-identical, InstanceNorm sums
+    depend on the batch), everything finite, aggregator logs present."""
+    import os
+    import sys
+
+    import sdy_amd
+    from sdy_amd import ensemble
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import c4_rollout
+
+    dev = torch.device("cuda", 0)
+    n_ics, members, window = 4, 25, 6
+    exp, stepper, names, out_names = c4_rollout.build(dev)
+    wins = list(c4_rollout.windows(names, 1, window, NLAT, NLON, seed=77, n_ics=n_ics))
+    keep = [out_names[0], out_names[-1]]
+    w = sdy_amd.metrics.spherical_area_weights(torch.linspace(-89.5, 89.5, NLAT), NLON)
+
+    def run(**kw):
+        exp.model.model._call = 0
+        exp.model.interpolator.model._call = 0
+        got = {}
+
+        class W:
+            def append_batch(self, target, prediction, start_timestep, start_sample, batch_times=None):
+                got["start"] = start_sample
+                got["pred"] = {k: prediction[k].clone() for k in keep}
+                got["target_rows"] = next(iter(target.values())).shape[0]
+                got["finite"] = all(bool(torch.isfinite(v).all()) for v in prediction.values())
+
+        agg = sdy_amd.metrics.TimeMeanAggregator(w, is_ensemble=True)
+        data = wins
+        if "unit_range" in kw:      # a rank's loader holds only the initial conditions its share touches
+            lo, n = kw.pop("ics")
+            data = [type(wins[0])(data={k: v[lo:lo + n] for k, v in wins[0].data.items()}, times=None)]
+            kw["trajectory_offset"] = lo
+        timers = sdy_amd.run_inference(agg, stepper, data, window, window, n_ensemble_members=members, eval_device=dev,
+                                       writer=W(), **kw)
+        got["logs"] = agg.get_logs("inference")
+        got["timers"] = timers
+        return got
+
+    whole = run()
+    assert whole["finite"] and whole["pred"][keep[0]].shape == (members, n_ics, window + 1, NLAT, NLON)
+    assert whole["timers"]["forecast_steps_per_second"] > 10.0 and whole["timers"]["wall"] >= whole["timers"]["run_on_batch"] * 0.5
+    assert len(whole["logs"]) == 2 * len(out_names) + 1 and all(v == v for v in whole["logs"].values())
+    v = whole["pred"][keep[0]]
+    assert float((v[0, 0, -1] - v[1, 0, -1]).abs().max()) > 1e-3          # members of an IC diverge
+    assert float((v[0, 0, -1] - v[0, 1, -1]).abs().max()) > 1e-3          # ICs differ
+
+    halves = run(max_batch=50)                                              # the same job as two device batches
+    for k in keep:
+        e = rel_l2(halves["pred"][k], whole["pred"][k])
+        assert e < 2e-5, f"max_batch=50 vs one batch, {k}: {e:.3e}"
+    assert abs(halves["logs"]["inference/rmse/channel_mean"] - whole["logs"]["inference/rmse/channel_mean"]) < 1e-4
+
+    for rank, want in ((0, (0, 13, 0, 1)), (3, (39, 13, 1, 2)), (7, (88, 12, 3, 1))):
+        start, cnt, ic_lo, n_ic = ensemble.shard(n_ics, members, rank, 8)
+        assert (start, cnt, ic_lo, n_ic) == want
+        part = run(unit_range=(start, cnt), ics=(ic_lo, n_ic))
+        assert part["finite"] and part["start"] == start and part["target_rows"] == n_ic
+        assert all(v == v for v in part["logs"].values()) and len(part["logs"]) == 2 * len(out_names) + 1
+        for k in keep:
+            assert part["pred"][k].shape == (cnt, window + 1, NLAT, NLON)      # a ragged share: flat rows
+            for r in (0, cnt // 2, cnt - 1):
+                ic, m = divmod(start + r, members)
+                e = rel_l2(part["pred"][k][r], whole["pred"][k][m, ic])
+                assert e < 2e-5, f"rank {rank} of 8, {k}, unit {start + r} = (IC {ic}, member {m}): {e:.3e}"
+
+
+def test_bench_two_ranks_as_the_driver_launches_it():
+    """The driver's SCALE step runs `bench.py --gpus N`; on a 1-GPU box the same code path runs with both ranks on GPU 0
+    (`--share-gpu`, gloo): a fresh subprocess (the parent must start its children before anything touches HIP), rank 0's JSON
+    line, the member split of `ensemble.partition`."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "0",
+           "--members", "5", "--no-cpu-baseline", "--no-extras"]
+    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["members_per_gpu"] == [3, 2]
+    assert res["scaling"] == "strong" and res["value"] > 0 and res["steps"] == 1
+    assert res["config"]["forecast_steps_per_step"] == 5 * 6
+
+
+def test_c4_rollout_two_ranks_shared_gpu():
+    """`tools/c4_rollout.py --gpus 2 --share-gpu`: the C4 / C5 runner's own N > 1 path (run_inference(unit_range=shard),
+    TimeMeanAggregator combined over ranks) as a fresh self-launching subprocess on a small network."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "tools", "c4_rollout.py"), "--steps", "12", "--members", "5", "--layers", "2",
+            "--embed", "16", "--grid", "32", "64"]
+    one = subprocess.run(base, cwd=root, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run(base + ["--gpus", "2", "--share-gpu"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r1["finite"] and r2["finite"] and r2["n_gpus"] == 2 and r2["rows"] == 3 and r1["rows"] == 5
+    # the ranks' time-mean maps, weighted by their row counts (3 + 2), reproduce the one-process statistics
+    assert abs(r1["time_mean_rmse_channel_mean"] - r2["time_mean_rmse_channel_mean"]) < 2e-4 * r1["time_mean_rmse_channel_mean"]

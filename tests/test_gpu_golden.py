@@ -81,7 +81,7 @@ def test_network_vs_reference_with_recorded_dropout():
     assert err < TOL_TIGHT, f"rel L2 {err:.3e}"
 
 
-@pytest.mark.parametrize("name", ["fx_sample_tiny", "fx_sample_tiny_hack", "fx_sample_tiny_masks"])
+@pytest.mark.parametrize("name", ["fx_sample_tiny", "fx_sample_tiny_hack", "fx_sample_tiny_masks", "fx_sample_tiny_refine"])
 def test_sampler_vs_reference(name):
     import sdy_amd
 
@@ -96,9 +96,11 @@ def test_sampler_vs_reference(name):
         inet.mask_injector = _injector(gu.masks_per_forward(gu.recorded_masks(z), icfg), icfg)
     exp = sdy_amd.MultiHorizonForecastingDYffusion(
         fnet, sdy_amd.InterpolationExperiment(inet, horizon=6), horizon=6,
-        diffusion_config=dict(hack_for_imprecise_interpolation=hack, enable_interpolator_dropout=dropout))
+        diffusion_config=dict(hack_for_imprecise_interpolation=hack, enable_interpolator_dropout=dropout,
+                              **(json.loads(str(z["diffusion_extra"])) if "diffusion_extra" in z.files else {})))
     kw = {k: _cu(_t(z, k)) for k in ("dynamical_condition", "static_condition") if k in z.files}
     out = exp.model.sample(_cu(_t(z, "x0")), **kw)
+    assert fnet._call + inet._call == len(json.loads(str(z["trace"])))       # 16 network calls (21 with the refining sweep)
     ref = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out::")}
     assert sorted(out) == sorted(ref)
     for k in ref:
@@ -327,3 +329,42 @@ def test_time_mean_aggregator_vs_reference():
         sdy_amd.metrics.TimeMeanAggregator(w).record_batch(0.0, {"a": torch.zeros(1, 2, 16, 32)}, {"a": torch.zeros(1, 2, 16, 32)},
                                                         {}, {})
 
+
+
+def test_mean_aggregator_series_vs_reference():
+    """sdy_amd.metrics.MeanAggregator (one `sdy_ensemble_series` launch per variable and window on the member-stacked VIEW,
+    device accumulators indexed by i_time_start) vs the reference's own MeanAggregator fed the same three windows
+    (fx_mean_series.npz; reduced.py:144-266)."""
+    import sdy_amd
+
+    z = gu.load("fx_mean_series")
+    names = json.loads(str(z["names"]))
+    W = z["ens::tgt0::a"].shape[-1]
+    w = sdy_amd.metrics.spherical_area_weights(torch.from_numpy(z["lats"]), W)
+    n_t = int(z["n_timesteps"])
+    for key, ens in (("ens", True), ("det", False)):
+        agg = sdy_amd.metrics.MeanAggregator(w, target="denorm", n_timesteps=n_t, is_ensemble=ens)
+        for i in range(3):
+            tgt = {n: torch.from_numpy(z[f"{key}::tgt{i}::{n}"]).cuda() for n in names}
+            gen = {n: torch.from_numpy(z[f"{key}::gen{i}::{n}"]).cuda() for n in names}
+            if ens:   # as the window driver presents it: a transposed view of the IC-major batch
+                gen = {n: v.transpose(0, 1).contiguous().transpose(0, 1) for n, v in gen.items()}
+                assert not gen[names[0]].is_contiguous()
+            agg.record_batch(0.0, tgt, gen, tgt, gen, i_time_start=int(z[f"{key}::i_time_start{i}"]))
+        series = agg.get_series()
+        metrics = json.loads(str(z[f"{key}::metrics"]))
+        assert sorted(agg.metric_names) == metrics
+        for m in metrics:
+            for n in names:
+                want = torch.from_numpy(z[f"{key}::series::{m}/{n}"])
+                got = series[f"{m}/{n}"].cpu()
+                assert got.shape == want.shape == (n_t,)
+                assert torch.allclose(got, want, rtol=5e-5, atol=5e-6), (key, m, n, got, want)
+        logs = agg.get_logs("inference")
+        assert set(logs["inference/series"]) == set(series)
+    with pytest.raises(ValueError):
+        sdy_amd.metrics.MeanAggregator(w, n_timesteps=4).get_series()
+    with pytest.raises(ValueError):      # a ragged share hands flat rows: ensemble metrics need whole initial conditions
+        a = sdy_amd.metrics.MeanAggregator(w, n_timesteps=4, is_ensemble=True)
+        x = torch.zeros(3, 2, 16, 32).cuda()
+        a.record_batch(0.0, {"a": x[:1]}, {"a": x}, {}, {})

@@ -132,3 +132,38 @@ def test_c2_full_size_interpolator_forward():
     x2 = torch.cat([x, x.flip(0)], 0).cuda()
     got2 = net(x2, time=torch.tensor([3.0, 3.0]).cuda(), condition=torch.cat([cond, cond], 0).cuda())
     assert torch.equal(got2[0], got[0]) and torch.equal(got2[1], got[0])
+
+
+def test_c2_full_size_interpolator_forward_with_dropout():
+    """BASELINE.json configs[1] exactly as SURVEY.md 8(d) writes it: interpolator SFNO, 180x360, E = 256, ALL 8 blocks,
+    68 + 2 -> 34 channels, B = 1, time = 3.0, dropout AND drop path ON -- the fused `mlp_h3_kernel<true>` at full depth
+    (layers 1-6 with their intermediate drop-path rates, the LG <-> LG blocks, stream ids of every layer) against the oracle
+    replaying the Philox stream (reference: src/models/sfno/sfnonet.py:622,789-794, layers.py:76-78, drop_path.py:15-22).
+    The dropout seed is chosen (by the oracle's generator, on the host) so that trajectory 0 loses at least one whole MLP
+    branch to drop path at an inner layer AND keeps at least one, so both outcomes of the draw are compared."""
+    from oracle.philox import drop_path_keep
+
+    cfg = SFNOConfig(in_chans=70, out_chans=34, nlat=180, nlon=360, embed_dim=256, num_layers=8, with_time_emb=True,
+                     dropout_mlp=0.1, drop_path_rate=0.1, min_time=1.0, max_time=5.0)
+    rates = cfg.drop_path_rates
+
+    def kept(seed):
+        return [bool(drop_path_keep(seed, 0, layer, rates[layer], 1)[0]) for layer in range(8)]
+
+    seed = next(sd for sd in range(5000, 5400) if not all(kept(sd)[1:7]) and sum(kept(sd)) >= 5)
+    assert kept(seed)[0], "layer 0 has rate 0: always kept (sfnonet.py:252)"
+    net, ora, _ = make_pair(cfg, 68, 2, net_seed=seed)
+    x, cond = _inputs(cfg, 68, 2, 1)
+    t = torch.tensor([3.0])
+    masks = PhiloxMasks(cfg, seed=seed)
+    masks.call = 0
+    ref = ora(x, time=t, condition=cond, mask_fn=masks)
+    net.enable_inference_dropout()
+    got = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
+    assert torch.isfinite(got).all()
+    err = rel_l2(got, ref)
+    assert err < TOL_NET, f"C2 full-size, dropout on: rel L2 {err:.3e} (bound 1e-4)"
+    assert err < TOL_TIGHT, f"C2 full-size, dropout on: rel L2 {err:.3e} (fp32-MFMA expectation)"
+    # the masks matter at this depth: the next call of the stream gives a visibly different field
+    again = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
+    assert rel_l2(again, ref) > 1e-3

@@ -37,16 +37,35 @@ def test_schedule_maths_matches_reference_semantics(sdy):
     assert d2.sampling_schedule == [0, 3, 4, 5, 6, 7]
     d2.sampling_schedule = [3, 4.0, 5, 6, 7]          # explicit lists: 0 is prepended, integral floats become ints
     assert d2.sampling_schedule == [0, 3, 4, 5, 6, 7]
-    with pytest.raises(NotImplementedError):         # names that select artificial steps are outside the shipped config
-        d2.sampling_schedule = "every2"
+    # the reference's schedule NAMES (dyffusion.py:369-455): known answers produced by the reference's own setter
+    # (BaseDYffusion with timesteps = 6 and k = 2 / k = 5 artificial steps), recorded in the build container
+    known = {
+        2: {"only_dynamics": [0, 3, 4, 5, 6, 7], "only_dynamics_plus1": [0, 1.5, 3, 4, 5, 6, 7],
+            "only_dynamics_plus3": [0, 0.75, 1.5, 2.25, 3, 4, 5, 6, 7], "only_dynamics_plus_discrete2": [0, 1, 2, 3, 4, 5, 6, 7],
+            "every2": [0, 1, 3, 4, 5, 6, 7], "every3rd": [0, 1, 3, 4, 5, 6, 7], "first1": [0, 1, 3, 4, 5, 6, 7],
+            "first2": [0, 1, 2, 3, 4, 5, 6, 7], "first0.5": [0, 1, 3, 4, 5, 6, 7], "first0.3": [0, 1, 3, 4, 5, 6, 7]},
+        5: {"only_dynamics": [0, 6, 7, 8, 9, 10], "only_dynamics_plus1": [0, 3, 6, 7, 8, 9, 10],
+            "only_dynamics_plus3": [0, 1.5, 3, 4.5, 6, 7, 8, 9, 10], "only_dynamics_plus_discrete2": [0, 2, 4, 6, 7, 8, 9, 10],
+            "every2": [0, 1, 3, 5, 6, 7, 8, 9, 10], "every3rd": [0, 1, 4, 6, 7, 8, 9, 10], "first1": [0, 1, 6, 7, 8, 9, 10],
+            "first2": [0, 1, 2, 6, 7, 8, 9, 10], "first0.5": [0, 1, 2, 3, 6, 7, 8, 9, 10], "first0.3": [0, 1, 2, 6, 7, 8, 9, 10],
+            "first9": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]},
+    }
+    for k, table in known.items():
+        dk = _sampler(sdy, additional_interpolation_steps=k)
+        for name, want in table.items():
+            dk.sampling_schedule = name
+            assert dk.sampling_schedule == want, (k, name, dk.sampling_schedule)
+    with pytest.raises(AssertionError):
+        d2.sampling_schedule = "first9"               # more steps than the schedule has (the reference asserts too)
+    with pytest.raises(ValueError):
+        d2.sampling_schedule = "bogus"
     with pytest.raises(AssertionError):
         d2.sampling_schedule = [0, 2, 2]
     with pytest.raises(AssertionError):
         d2.sampling_schedule = [0, 9]
-    with pytest.raises(NotImplementedError):
-        _sampler(sdy, refine_intermediate_predictions=True)
-    with pytest.raises(NotImplementedError):
-        _sampler(sdy, log_every_t=1)
+    # capabilities a checkpoint's diffusion_config may carry: constructing must not refuse them
+    assert _sampler(sdy, refine_intermediate_predictions=True).hparams.refine_intermediate_predictions
+    assert _sampler(sdy, log_every_t="auto").hparams.log_every_t == "auto"
     with pytest.raises(AssertionError):
         d.diffusion_step_to_interpolation_step(6)
     with pytest.raises(ValueError):
@@ -294,3 +313,23 @@ def test_window_stitcher_carries_state_per_trajectory(sdy):
     assert calls[-1] == (T1, 0) and st.i_time == 2 * T1 - 1
     with pytest.raises(ValueError):
         st.apply_initial_condition(batch, ic_rows)
+
+
+def test_synthetic_weights_equal_the_oracle_generator(sdy):
+    """`sdy_amd.synthetic.trained_like_state_dict` (what bench.py / tools build their networks from, product code) and
+    `oracle.sfno.make_state_dict` (what the parity tests load into both sides) are the same generator, value for value: a
+    benchmark network and a parity-test network of one seed are the same network."""
+    import torch
+
+    from oracle.sfno import SFNOConfig, make_state_dict
+
+    for drop, cond, big_skip, temb in ((0.1, 2, True, True), (0.0, 0, False, False)):
+        cfg = SFNOConfig(in_chans=6 + cond, out_chans=4, nlat=16, nlon=32, embed_dim=8, num_layers=2, dropout_mlp=drop,
+                         drop_path_rate=drop, with_time_emb=temb, big_skip=big_skip, pos_embed=big_skip)
+        net = sdy.SphericalFourierNeuralOperatorNet(6, 4, num_conditional_channels=cond, spatial_shape_in=(16, 32), embed_dim=8,
+                                                    num_layers=2, dropout_mlp=drop, drop_path_rate=drop, with_time_emb=temb,
+                                                    big_skip=big_skip, pos_embed=big_skip)
+        a, b = sdy.synthetic.trained_like_state_dict(net, seed=77), make_state_dict(cfg, seed=77)
+        assert list(a) == list(b)
+        assert all(torch.equal(a[k], b[k]) for k in a)
+        net.load_state_dict(a, strict=True)

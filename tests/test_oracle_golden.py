@@ -235,3 +235,33 @@ def test_oracle_time_mean_vs_reference_aggregator():
             bias = float(weighted_mean((gen[n] - tgt[n]).double(), w.double()))
             assert abs(rmse - float(z[f"{key}::rmse::{n}"])) < 1e-6 and abs(bias - float(z[f"{key}::bias::{n}"])) < 1e-6
 
+
+
+def test_oracle_mean_series_vs_reference_aggregator():
+    """oracle.metrics.mean_series vs the reference's own MeanAggregator (fx_mean_series.npz: three windows, ensemble and
+    deterministic; every metric of reduced.py:182-197 but the gradient magnitude)."""
+    import json
+
+    import numpy as np
+    import torch
+
+    from oracle.metrics import mean_series
+
+    z = gu.load("fx_mean_series")
+    names = json.loads(str(z["names"]))
+    lats = torch.from_numpy(z["lats"])
+    W = z["ens::tgt0::a"].shape[-1]
+    w = torch.cos(torch.deg2rad(lats)).repeat(W, 1).t()
+    w = w / w.sum()
+    n_t = int(z["n_timesteps"])
+    for key, ens in (("ens", True), ("det", False)):
+        wins = [(int(z[f"{key}::i_time_start{i}"]), {n: torch.from_numpy(z[f"{key}::tgt{i}::{n}"]) for n in names},
+                 {n: torch.from_numpy(z[f"{key}::gen{i}::{n}"]) for n in names}, w) for i in range(3)]
+        got = mean_series(wins, ens, n_t)
+        metrics = json.loads(str(z[f"{key}::metrics"]))
+        assert ("weighted_crps" in metrics) == ens and "weighted_rmse" in metrics and len(metrics) == (8 if ens else 6)
+        for m in metrics:
+            for n in names:
+                want = z[f"{key}::series::{m}/{n}"]
+                assert want.shape == (n_t,)
+                assert np.allclose(got[f"{m}/{n}"].numpy(), want, rtol=2e-5, atol=2e-6), (key, m, n)

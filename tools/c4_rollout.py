@@ -1,78 +1,65 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[3] / [4] through the whole product path: `run_inference` (window driver) -> `MultiStepStepper`
-(normalise, pack, prescriber-free AR loop, denormalise, LpLoss terms) -> `get_preds_at_t_for_batch` -> DYffusion sampler ->
-SFNO, with the on-device `TimeMeanAggregator`, for an M-member ensemble of one initial condition on synthetic standardised
-data.  Prints one JSON line: member-forecast-steps/s of the driver (its own `forecast_steps_per_second` timer, i.e. the
-reference's "Total steps per second" log line x trajectories), finiteness and the aggregator's channel-mean RMSE.
+"""BASELINE.json configs[3] / [4] through the whole product path: `run_inference` (window driver, loader prefetch) ->
+`MultiStepStepper` (normalise, pack, prescriber-free AR loop, denormalise, LpLoss terms) -> `get_preds_at_t_for_batch` ->
+DYffusion sampler -> SFNO, with the on-device `TimeMeanAggregator`, for (initial conditions) x (members) trajectories on
+synthetic standardised data.  Rank 0 prints one JSON line: member-forecast-steps/s of the driver BY WALL TIME (the
+reference's "Total steps per second", `src/ace_inference/inference/inference.py:294-298`, x trajectories) with the device
+time of the windows beside it, finiteness and the aggregator's channel-mean RMSE.
 
-    python tools/c4_rollout.py --steps 102 --members 25          # C4: 25 members x ~100 steps = 17 windows of 6
-    python tools/c4_rollout.py --steps 600 --members 25          # a C5-style long sample (600 steps), extrapolated
+    python tools/c4_rollout.py --steps 102 --members 25                    # C4: 25 members x ~100 steps = 17 windows of 6
+    python tools/c4_rollout.py --steps 600 --members 25                    # a C5-style long sample, extrapolated
+    python tools/c4_rollout.py --steps 102 --members 25 --gpus 8           # C4 as specified: members over 8 GPUs (4,3,3,...)
+    python tools/c4_rollout.py --steps 600 --members 25 --ics 4 --gpus 8   # C5's job (100 trajectories, 12-13 per GPU)
+
+`--gpus N` works by itself: the parent starts one child per GPU before anything touches HIP (never re-executes a process
+that has); every rank runs `run_inference(unit_range=ensemble.shard(...))` on its own share -- no collective on the data
+path -- and the `TimeMeanAggregator(dist=TorchDistributed())` combines the ranks' maps once, at log time (RCCL).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-import types
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def build(device, n_out=63, n_forc=2, layers=8, embed=256, nlat=180, nlon=360, horizon=6):
     """The shipped layout: one input-only channel (HGTsfc) carried in front of the state (hack_for_imprecise_interpolation)."""
-    import torch
+    from sdy_amd import synthetic
 
-    import sdy_amd
-    from helpers import make_pair
-    from oracle.sfno import SFNOConfig
-
-    cs = n_out + 1
-    fcfg = SFNOConfig(in_chans=cs + n_forc, out_chans=n_out, nlat=nlat, nlon=nlon, embed_dim=embed, num_layers=layers,
-                      with_time_emb=True, min_time=0.0, max_time=horizon - 1.0)
-    icfg = SFNOConfig(in_chans=2 * cs + n_forc, out_chans=n_out, nlat=nlat, nlon=nlon, embed_dim=embed, num_layers=layers,
-                      with_time_emb=True, dropout_mlp=0.1, drop_path_rate=0.1, min_time=1.0, max_time=horizon - 1.0)
-    with torch.cuda.device(device):
-        fnet, _, _ = make_pair(fcfg, cs, n_forc, seed=4321)
-        inet, _, _ = make_pair(icfg, 2 * cs, n_forc, seed=4322, net_seed=1000)
-    exp = sdy_amd.MultiHorizonForecastingDYffusion(
-        fnet, sdy_amd.InterpolationExperiment(inet, horizon=horizon), horizon=horizon,
-        diffusion_config=dict(hack_for_imprecise_interpolation=True))
-    out_names = [f"v{i}" for i in range(n_out)]
-    in_names = ["HGTsfc"] + out_names
-    forcing = [f"f{i}" for i in range(n_forc)]
-    names = in_names + forcing
-    stepper = sdy_amd.MultiStepStepper(exp, names, out_names, forcing, {n: 0.0 for n in names}, {n: 1.0 for n in names}, None)
+    exp, _, _ = synthetic.build_sampler(device, state_chans=n_out, forcing_chans=n_forc, nlat=nlat, nlon=nlon, embed=embed,
+                                        layers=layers, horizon=horizon, carried_input_only_channel=True)
+    stepper, names, out_names = synthetic.build_stepper(exp, n_out, n_forc, carried_input_only_channel=True)
     return exp, stepper, names, out_names
 
 
-def windows(names, n_windows, window, nlat, nlon, seed=1234):
-    """Synthetic standardised series, generated window by window on the host (targets are only used for the loss terms)."""
-    import torch
+def windows(names, n_windows, window, nlat, nlon, seed=1234, n_ics=1):
+    from sdy_amd import synthetic
 
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    last = {n: torch.randn(1, 1, nlat, nlon, generator=g) for n in names}
-    for _ in range(n_windows):
-        data = {}
-        for n in names:
-            nxt = torch.randn(1, window, nlat, nlon, generator=g)
-            data[n] = torch.cat([last[n], nxt], dim=1)
-            last[n] = data[n][:, -1:]
-        yield types.SimpleNamespace(data=data, times=None)
+    return synthetic.windows(names, n_windows, window, nlat, nlon, n_ics=n_ics, seed=seed)
 
 
-def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=360, aggregate=True, warmup=True):
+def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=360, aggregate=True, warmup=True, n_ics=1,
+        rank=0, world=1, prefetch=2, max_batch=None, dist=None):
     import torch
 
     import sdy_amd
+    from sdy_amd import ensemble
 
     assert steps % window == 0, "--steps must be a multiple of the window (6)"
     exp, stepper, names, out_names = build(device, layers=layers, embed=embed, nlat=nlat, nlon=nlon)
+    start, cnt, ic_lo, n_ic = ensemble.shard(n_ics, members, rank, world)
+    kw = dict(n_ensemble_members=members, eval_device=device, prefetch=prefetch, max_batch=max_batch)
+    if world > 1:
+        kw.update(unit_range=(start, cnt), trajectory_offset=ic_lo)
     agg = None
     if aggregate:
         w = sdy_amd.metrics.spherical_area_weights(torch.linspace(-89.5, 89.5, nlat), nlon)
-        agg = sdy_amd.metrics.TimeMeanAggregator(w, is_ensemble=members > 1)
+        agg = sdy_amd.metrics.TimeMeanAggregator(w, is_ensemble=members > 1, dist=dist)
     finite = {"ok": True}
 
     class Writer:     # stands for the reference's data writer: only checks what it is handed
@@ -81,31 +68,141 @@ def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=36
             finite["ok"] = finite["ok"] and bool(torch.isfinite(v).all())
             finite["shape"] = tuple(v.shape)
 
+    def loader(n_windows, seed):     # a rank's loader delivers only the initial conditions its share touches
+        for wdw in windows(names, n_windows, window, nlat, nlon, seed=seed, n_ics=n_ics):
+            if world > 1:
+                wdw.data = {k: v[ic_lo:ic_lo + n_ic] for k, v in wdw.data.items()}
+            yield wdw
+
+    if cnt == 0:
+        return {"steps": steps, "members": members, "rows": 0}
     if warmup:   # one untimed window: native objects, weight upload and the workspace are created on first use (~8 s)
-        sdy_amd.run_inference(None, stepper, windows(names, 1, window, nlat, nlon, seed=7), window, window,
-                              n_ensemble_members=members, eval_device=device)
+        sdy_amd.run_inference(None, stepper, loader(1, 7), window, window, **kw)
+    if dist is not None and world > 1:
+        torch.cuda.synchronize(device)
+        import torch.distributed as td
+        td.barrier()
     t0 = time.perf_counter()
-    timers = sdy_amd.run_inference(agg, stepper, windows(names, steps // window, window, nlat, nlon), steps, window,
-                                   n_ensemble_members=members, eval_device=device, writer=Writer())
+    timers = sdy_amd.run_inference(agg, stepper, loader(steps // window, 1234), steps, window, writer=Writer(), **kw)
     wall = time.perf_counter() - t0
-    res = {"steps": steps, "members": members, "windows": steps // window, "wall_s": round(wall, 2),
-           "run_on_batch_s": round(timers["run_on_batch"], 2),
+    res = {"steps": steps, "members": members, "ics": n_ics, "rows": cnt, "windows": steps // window, "wall_s": round(wall, 2),
+           "run_on_batch_s": round(timers["run_on_batch"], 2), "data_loading_wait_s": round(timers["data_loading"], 2),
            "member_forecast_steps_per_s": round(timers["forecast_steps_per_second"], 2),
+           "member_forecast_steps_per_s_device_time": round(timers["forecast_steps_per_second_run_on_batch"], 2),
+           "wall_over_run_on_batch": round(wall / max(timers["run_on_batch"], 1e-9), 3),
            "finite": finite["ok"], "prediction_shape": finite.get("shape")}
     if agg is not None:
         res["time_mean_rmse_channel_mean"] = round(agg.get_logs("")["rmse/channel_mean"], 5)
     return res
 
 
-if __name__ == "__main__":
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_children(n):
+    """One child per GPU, started before this process imports torch or touches HIP (same rule as bench.py)."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, pending = 0, list(procs)
+    while pending:
+        for p in list(pending):
+            r = p.poll()
+            if r is None:
+                continue
+            pending.remove(p)
+            if r != 0:
+                rc = rc or r
+                for q in pending:       # a rank failed: the others would wait in a barrier forever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=102)
     ap.add_argument("--members", type=int, default=25)
+    ap.add_argument("--ics", type=int, default=1, help="initial conditions (C5: 4)")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--prefetch", type=int, default=2, help="windows pulled ahead of the compute (0: the synchronous loop)")
+    ap.add_argument("--max-batch", type=int, default=None, help="at most this many trajectories per device batch")
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--embed", type=int, default=256)
+    ap.add_argument("--grid", type=int, nargs=2, default=(180, 360))
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: all ranks on GPU 0 with the gloo backend (exercises the N>1 path on a 1-GPU box)")
     a = ap.parse_args()
-    import torch
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_children(a.gpus))
 
-    dev = torch.device("cuda", 0)
+    import torch
+    import torch.distributed as td
+
+    import sdy_amd
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    r = run(dev, a.steps, a.members)
-    r["c5_hours_1gpu"] = round(100 * 14600 / r["member_forecast_steps_per_s"] / 3600.0, 2)   # 4 ICs x 25 members x 14600 steps
-    print(json.dumps(r), flush=True)
+    dist = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.share_gpu:
+            td.init_process_group("gloo")
+        else:
+            td.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        dist = sdy_amd.metrics.TorchDistributed() if not a.share_gpu else _HostDist(td)
+    r = run(dev, a.steps, a.members, layers=a.layers, embed=a.embed, nlat=a.grid[0], nlon=a.grid[1], n_ics=a.ics, rank=rank,
+            world=world, prefetch=a.prefetch, max_batch=a.max_batch, dist=dist)
+    if world > 1:     # whole-job rate: every rank's trajectories over the slowest rank's wall time
+        t = torch.tensor([r.get("wall_s", 0.0), float(r.get("rows", 0))], dtype=torch.float64,
+                         device="cpu" if a.share_gpu else dev)
+        tmax, tsum = t.clone(), t.clone()
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        td.all_reduce(tsum, op=td.ReduceOp.SUM)
+        r["n_gpus"] = world
+        r["job_wall_s"] = round(float(tmax[0]), 2)
+        r["job_member_forecast_steps_per_s"] = round(float(tsum[1]) * a.steps / max(float(tmax[0]), 1e-9), 2)
+    if rank == 0:
+        rate = r.get("job_member_forecast_steps_per_s", r.get("member_forecast_steps_per_s", 0.0))
+        if rate:
+            r["c5_hours"] = round(100 * 14600 / rate / 3600.0, 2)    # 4 ICs x 25 members x 14600 steps at this job's rate
+        print(json.dumps(r), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+class _HostDist:
+    """--share-gpu only: gloo cannot reduce device tensors, so the maps take a round trip through the host."""
+
+    def __init__(self, td):
+        self.td = td
+
+    @property
+    def world_size(self):
+        return self.td.get_world_size()
+
+    def reduce_sum(self, t):
+        h = t.detach().cpu().clone()
+        self.td.all_reduce(h)
+        return h.to(t.device)
+
+    def reduce_mean(self, t):
+        return self.reduce_sum(t) / self.world_size
+
+
+if __name__ == "__main__":
+    main()

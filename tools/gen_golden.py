@@ -128,7 +128,7 @@ def gen_sfno(tag, cfg, n_in, n_cond, B, times, seed, with_masks):
     print(f"{tag}: y std {float(y.std()):.4f}, saved")
 
 
-def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i):
+def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i, extra=None):
     import src.experiment_types._base_experiment as be
     from src.experiment_types.forecasting_multi_horizon import MultiHorizonForecastingDYffusion
     from src.experiment_types.interpolation import InterpolationExperiment
@@ -157,7 +157,7 @@ def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i):
     ipol.model.load_state_dict(isd, strict=False)
     dcfg = AttrDict(_target_="src.diffusion.dyffusion.DYffusion", timesteps=6, forward_conditioning="none",
                     interpolator=ipol, interpolator_local_checkpoint_path=None, time_encoding="dynamics",
-                    hack_for_imprecise_interpolation=hack, enable_interpolator_dropout=bool(dropout))
+                    hack_for_imprecise_interpolation=hack, enable_interpolator_dropout=bool(dropout), **(extra or {}))
     fc = MultiHorizonForecastingDYffusion(model_config=mcfg(), datamodule_config=dm, diffusion_config=dcfg,
                                           verbose=False)
     fcfg = SFNOConfig(in_chans=cs + n_forc, out_chans=C, nlat=H, nlon=W, embed_dim=E, num_layers=L,
@@ -170,9 +170,9 @@ def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i):
     return fc, ipol, fcfg, icfg, fsd, isd, cs
 
 
-def gen_sample(tag, hack, dropout):
+def gen_sample(tag, hack, dropout, extra=None):
     C, n_forc, H, W, E, L = 6, 2, 32, 64, 16, 2
-    fc, ipol, fcfg, icfg, fsd, isd, cs = build_experiments(C, n_forc, H, W, E, L, hack, dropout, 11, 22)
+    fc, ipol, fcfg, icfg, fsd, isd, cs = build_experiments(C, n_forc, H, W, E, L, hack, dropout, 11, 22, extra)
     g = torch.Generator(device="cpu").manual_seed(1234)
     B = 2
     x0 = torch.randn(B, cs, H, W, generator=g)
@@ -191,6 +191,8 @@ def gen_sample(tag, hack, dropout):
     hi.remove()
     out = dict(x0=x0.numpy(), hack=np.array(int(hack)), dropout=np.array(int(dropout)),
                fcfg=json.dumps(fcfg.__dict__), icfg=json.dumps(icfg.__dict__), trace=json.dumps(trace))
+    if extra:
+        out["diffusion_extra"] = json.dumps(extra)
     out.update({"f::" + k: v.numpy() for k, v in fsd.items()})
     out.update({"i::" + k: v.numpy() for k, v in isd.items()})
     for k, v in kw.items():
@@ -208,6 +210,12 @@ def gen_sample(tag, hack, dropout):
     return trace
 
     # also exercise the stepper-facing surface once (get_preds_at_t_for_batch), results must equal sample()
+
+
+def gen_sample_refine():
+    """`refine_intermediate_predictions=True` (src/diffusion/dyffusion.py:551-563: a second interpolator sweep from the last
+    forecast) with the carried input-only channel; 6 + 10 + 5 network calls."""
+    return gen_sample("fx_sample_tiny_refine", hack=True, dropout=False, extra=dict(refine_intermediate_predictions=True))
 
 
 def gen_stepper(tag="fx_stepper_tiny"):
@@ -435,6 +443,52 @@ def gen_time_mean(tag="fx_time_mean"):
     print(f"{tag}: ens rmse a {out['ens::rmse::a']}, saved")
 
 
+def gen_mean_series(tag="fx_mean_series"):
+    """The reference's own MeanAggregator (src/ace_inference/core/aggregator/inference/reduced.py:144-266: the per-timestep
+    series of area-weighted metrics) fed three windows the way run_inference feeds it (loop.py:133-149), ensemble and
+    deterministic.  The gradient-magnitude metric is not stored (out of the build's scope)."""
+    from src.ace_inference.core import metrics as M
+    from src.ace_inference.core.aggregator.inference.reduced import MeanAggregator
+
+    class NoDist:            # single process: reduce_mean is the identity (core/distributed.py)
+        def reduce_mean(self, t):
+            return t
+
+    g = torch.Generator(device="cpu").manual_seed(43)
+    E, S, T, H, W = 4, 2, 3, 16, 32
+    names = ["a", "b"]
+    lats = torch.linspace(-84.375, 84.375, H)
+    w = M.spherical_area_weights(lats, W)
+    n_timesteps = 1 + 3 * T
+    out = dict(lats=lats.numpy(), names=json.dumps(names), n_timesteps=n_timesteps)
+    for is_ens in (True, False):
+        agg = MeanAggregator(w, target="denorm", n_timesteps=n_timesteps, is_ensemble=is_ens, dist=NoDist(),
+                             device=torch.device("cpu"))
+        key = "ens" if is_ens else "det"
+        i_time = 0
+        for win in range(3):
+            nt = T + 1 if win == 0 else T           # the first window keeps its initial condition (loop.py:133-141)
+            tgt = {n: torch.randn(S, nt, H, W, generator=g) * 2.0 + 1.0 for n in names}
+            shp = (E, S, nt, H, W) if is_ens else (S, nt, H, W)
+            gen = {n: (tgt[n][None] if is_ens else tgt[n]) + torch.randn(*shp, generator=g) * 0.5 + 0.2 for n in names}
+            agg.record_batch(loss=0.0, target_data=tgt, gen_data=gen, target_data_norm=tgt, gen_data_norm=gen,
+                             i_time_start=i_time)
+            for n in names:
+                out[f"{key}::tgt{win}::{n}"] = tgt[n].numpy()
+                out[f"{key}::gen{win}::{n}"] = gen[n].numpy()
+            out[f"{key}::i_time_start{win}"] = i_time
+            i_time += nt
+        metrics = []
+        for d in agg._get_series_data():
+            if "grad_mag" in d.metric_name:
+                continue
+            out[f"{key}::series::{d.metric_name}/{d.var_name}"] = np.asarray(d.data, dtype=np.float64)
+            metrics.append(d.metric_name)
+        out[f"{key}::metrics"] = json.dumps(sorted(set(metrics)))
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"{tag}: ens weighted_crps/a {out['ens::series::weighted_crps/a'][:3]}, saved")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1:      # regenerate selected fixtures only: python tools/gen_golden.py gen_time_mean
@@ -454,6 +508,7 @@ if __name__ == "__main__":
     t1 = gen_sample("fx_sample_tiny", hack=False, dropout=False)
     gen_sample("fx_sample_tiny_hack", hack=True, dropout=False)
     gen_sample("fx_sample_tiny_masks", hack=True, dropout=True)
+    gen_sample_refine()
     with open(os.path.join(OUT, "fx_trace.json"), "w") as f:
         json.dump(t1, f)
     gen_stepper()
@@ -461,5 +516,6 @@ if __name__ == "__main__":
     gen_ckpt_layout()
     gen_metrics()
     gen_time_mean()
+    gen_mean_series()
     sizes = {n: os.path.getsize(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT))}
     print(sizes)
