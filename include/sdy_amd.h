@@ -254,6 +254,9 @@ int sdy_sfno_set_param(sdy_sfno* net, const char* name, const float* host, size_
 int sdy_sfno_ready(const sdy_sfno* net);
 const char* sdy_sfno_missing(const sdy_sfno* net);
 size_t sdy_sfno_workspace_floats(const sdy_sfno* net, int B);
+/* Largest B one sdy_sfno_forward call takes (32-bit lane offsets inside the spectral workspace: 60 rows at 180 x 360,
+ * embed 256); larger batches run as consecutive calls on row ranges, each with its own batch_offset (the Python module does). */
+int sdy_sfno_max_batch(const sdy_sfno* net);
 
 typedef struct sdy_sfno_fwd_args {
   /* up to three channel groups concatenated on dim 1 (inputs | condition | static_condition) */

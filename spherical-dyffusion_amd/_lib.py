@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdy_amd.so")
+# SDY_AMD_LIB: another build of the same library (A/B measurements of compile-time kernel switches, csrc/Makefile); never a fallback
+LIB_PATH = os.environ.get("SDY_AMD_LIB") or os.path.join(_HERE, "libsdy_amd.so")
 
 SDY_GRID = {"equiangular": 0, "legendre-gauss": 1}
 
@@ -167,6 +168,7 @@ SIGNATURES = {
     "sdy_sfno_ready": (C.c_int, [C.c_void_p]),
     "sdy_sfno_missing": (C.c_char_p, [C.c_void_p]),
     "sdy_sfno_workspace_floats": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "sdy_sfno_max_batch": (C.c_int, [C.c_void_p]),
     "sdy_sfno_forward": (C.c_int, [C.c_void_p, C.POINTER(SdySfnoFwdArgs), C.c_void_p]),
     "sdy_sfno_time_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_norm_pack": (C.c_int, [C.POINTER(SdyVarTable), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -884,6 +884,18 @@ extern "C" size_t sdy_sfno_workspace_floats(const sdy_sfno* n, int B) {
   return ws_layout(n, B).total;
 }
 
+// Largest batch one sdy_sfno_forward call covers.  The kernels address rows as (wave-uniform 64-bit base) + (32-bit lane byte
+// offset); the widest lane offset is the Legendre synthesis reading up to 192 degree rows of the coefficient tensor
+// Cs[l][m][b][2E], whose row stride is mtr * 2 B E floats (leg_par.hip: sdy_leg_par_launch refuses larger strides).
+extern "C" int sdy_sfno_max_batch(const sdy_sfno* n) {
+  if (!n) return 0;
+  const int mtr = n->cfg.mmax < n->cfg.lmax ? n->cfg.mmax : n->cfg.lmax;
+  const long per_row = 192L * mtr * 2 * n->cfg.embed_dim * 4 + 2L * n->cfg.embed_dim * 4;   // bytes of lane offset per batch row
+  long b = ((1L << 32) - 1) / per_row;
+  if (b > 65535) b = 65535;
+  return b < 1 ? 1 : (int)b;
+}
+
 extern "C" int sdy_sfno_time_embed(sdy_sfno* n, const float* time, int B, float* t_repr, float* ss, void* stream) {
   if (!n || !time || B <= 0) return SDY_ERR_ARG;
   SDY_TRY(sdy_sfno_ready(n));

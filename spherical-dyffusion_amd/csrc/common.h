@@ -145,6 +145,42 @@ __device__ __forceinline__ sdy_gf2 gelu_erf2(sdy_gf2 x) {
   const sdy_gf2 pos = x * (1.0f - hq), neg = x * hq;
   return sdy_gf2{x.x >= 0.0f ? pos.x : neg.x, x.y >= 0.0f ? pos.y : neg.y};
 }
+// ---- exact-erf GELU from a table: 16 gelu(v) with NO transcendental and 9 plain VALU instructions ------------------
+// The persistent kernels are VALU-issue bound: gelu_erf above costs ~14 plain instructions plus v_rcp and
+// v_exp (8 issue cycles each).  Here Phi(v) = (1 + erf(v / sqrt 2)) / 2 is a cubic Taylor piece around the nearest of 385 nodes
+// spaced 1/32 apart on [-6, 6] -- |error| <= 0.55 * (1/64)^4 / 24 = 1.4e-9, far below the 7.5e-8 of the A&S formula -- with
+// the four coefficients of a node in ONE 16-byte LDS word.  The kernels work on w = 8 v (their accumulator scale and bias
+// absorb the 8), which makes every multiplier an inline constant and leaves one scalar operand per instruction, the most a
+// gfx9 VOP3 encoding takes (with v itself the constants 32.0 and +-6.0 need VGPRs):
+//     wc = med3(w, -48, 48)                    clamp (the end nodes hold exactly 0 and 1 with zero slope)
+//     t  = fma(wc, 4, 2^23 + 192)              the node index lands in the low mantissa bits (round to nearest)
+//     a  = (bits(t) << 4) + const              its byte address: one v_lshl_add_u32, the constant cancels the exponent bits
+//     f  = fma(wc, 4, -(t - MAGIC))            offset from the node in node spacings, |f| <= 1/2 (exact)
+//     16 gelu(v) = w * (c0 + f (c1 + f (c2 + f c3)))        coefficients pre-multiplied by 16 / 8
+// The table is built once per device in fp64 (pointwise.hip) and copied into LDS by the kernels that use it.
+#define SDY_GELU_NODES 385
+#define SDY_GELU_TAB_BYTES (SDY_GELU_NODES * 16)
+#define SDY_GELU_SX 16.0f       // activation pre-scale of the split-fp16 kernels: the table yields SDY_GELU_SX * gelu
+#define SDY_GELU_WS 8.0f        // w = SDY_GELU_WS * v
+#define SDY_GELU_MAGIC (8388608.0f + 192.0f)
+int sdy_gelu_table_ptr(const float** table_dev);   // device pointer of the current device's table ([385][4] floats)
+typedef const f32x4 __attribute__((address_space(3)))* sdy_lds_f32x4_cptr;
+__device__ __forceinline__ f32x4 gelu_tab_load(unsigned addr) { return *reinterpret_cast<sdy_lds_f32x4_cptr>((uintptr_t)addr); }
+// w = SDY_GELU_WS * v; tab_lds_base = LDS byte address of the table; returns SDY_GELU_SX * gelu(v)
+__device__ __forceinline__ float gelu_tab16(float w, unsigned tab_lds_base) {
+  const float wc = __builtin_amdgcn_fmed3f(w, -6.0f * SDY_GELU_WS, 6.0f * SDY_GELU_WS);
+  const float t = fmaf(wc, 4.0f, SDY_GELU_MAGIC);
+  const f32x4 c = gelu_tab_load((__builtin_bit_cast(unsigned, t) << 4) + (tab_lds_base - 0xB0000000u));   // bits(2^23) << 4
+  const float f = fmaf(wc, 4.0f, -(t - SDY_GELU_MAGIC));
+  return w * fmaf(fmaf(fmaf(c.w, f, c.z), f, c.y), f, c.x);
+}
+// cooperative copy of the table into LDS (dst 16-byte aligned; follow with a barrier).  `scale` multiplies the coefficients:
+// 1 gives SDY_GELU_SX * gelu from gelu_tab16, 1 / SDY_GELU_SX plain gelu.
+__device__ __forceinline__ void gelu_tab_to_lds(float* dst, const float* tab_global, int tid, int nthreads, float scale = 1.0f) {
+  for (int i = tid; i < SDY_GELU_NODES; i += nthreads)
+    reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(tab_global)[i] * scale;
+}
+
 __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 

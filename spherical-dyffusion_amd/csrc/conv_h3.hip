@@ -53,8 +53,11 @@ struct ConvCfg {
   static constexpr int GPW = MT * KSW;                  // groups per wave
   static constexpr int WGS = NW == 4 ? 2 : 1;           // workgroups per CU
   static constexpr int TILE_BYTES = 2 * CTN * KROW * 2; // hi + lo
-  static constexpr int LDS_BYTES = TILE_BYTES + CSTAT_BYTES + CE * 4;
+  static constexpr int LDS_BYTES = TILE_BYTES + CSTAT_BYTES + CE * 4 + SDY_GELU_TAB_BYTES;   // (4 waves: 2 x 76.8 KB per CU)
 };
+#ifndef SDY_CONV_GELU_TAB
+#define SDY_CONV_GELU_TAB 1      // GELU of the store loop from the LDS table (common.h, gelu_tab16); 0: gelu_erf2 (A&S 7.1.26)
+#endif
 
 struct ConvParams {
   const float* x; long x_bs;
@@ -69,6 +72,7 @@ struct ConvParams {
   int Cin;                         // input channels (the weight stream is zero-padded to KBLK * 64)
   float out_scale;
   unsigned* flags;                 // sticky status word (sdy_status_flags)
+  const float* gelu_tab;           // GELU table in global memory (sdy_gelu_table_ptr)
   unsigned long long* stamps;    // timing experiments only (SDY_CONV_STAMPS)
 };
 
@@ -130,6 +134,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
     Bs[tid] = p.bias ? p.bias[tid] / p.out_scale : 0.0f;
     Ss[2 * tid] = 0.0; Ss[2 * tid + 1] = 0.0;
   }
+  // GELU table (plain gelu: coefficients / 16); the store loop then works on w = 8 v, the accumulator pass scales by 8
+  float* Gt = reinterpret_cast<float*>(smem + G::TILE_BYTES + CSTAT_BYTES + CE * 4);
+  const unsigned gt_base = (unsigned)(uintptr_t)Gt;
+  const bool tab_gelu = SDY_CONV_GELU_TAB && p.act == 1;
+  if (tab_gelu) gelu_tab_to_lds(Gt, p.gelu_tab, tid, G::NT, 1.0f / SDY_GELU_SX);
+  const float os_scale = tab_gelu ? p.out_scale * SDY_GELU_WS : p.out_scale;
   // (ordered before their first use by the barrier that ends the first tile's phase 0)
 
   // Software pipeline over tiles.  Loads are issued ONE per step where they ride on other work, never as a burst inside
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = 32 * (CMT * wave + mi) + (r & 3) + 8 * (r >> 2) + 4 * h;
-          Os[row * CTN + 32 * j + l31] = acc[mi][j][r] * p.out_scale;
+          Os[row * CTN + 32 * j + l31] = acc[mi][j][r] * os_scale;
         }
     __syncthreads();
     stamp(5);
@@ -300,10 +310,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
 #pragma unroll
       for (int i = 0; i < CRPT; ++i) {
         f32x4 v = *reinterpret_cast<const f32x4*>(Os + (o0 + CRS * i) * CTN + 4 * q0);
+        if (tab_gelu) {   // (workgroup-uniform) v holds 8 x the pre-activation: 10 plain VALU instructions per value, no v_rcp / v_exp
+          if (p.add_mode == 1) v = addv[i] * SDY_GELU_WS + v;
+          v = f32x4{gelu_tab16(v.x, gt_base), gelu_tab16(v.y, gt_base), gelu_tab16(v.z, gt_base), gelu_tab16(v.w, gt_base)};
+        } else {
         if (p.add_mode == 1) v += addv[i];
         if (p.act == 1) {
           const sdy_gf2 g0 = gelu_erf2(sdy_gf2{v.x, v.y}), g1 = gelu_erf2(sdy_gf2{v.z, v.w});
           v = f32x4{g0.x, g0.y, g1.x, g1.y};
+        }
         }
         if (p.add_mode == 2) v += addv[i];
         if (c_ok) sdy_st16s(oz + (long)(CRS * i) * p.HW, ro, v);
@@ -433,6 +448,7 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   p.out = a->out; p.out_bs = a->out_bstride;
   p.stats = a->stats;
   SDY_TRY(sdy_flags_ptr(&p.flags));
+  SDY_TRY(sdy_gelu_table_ptr(&p.gelu_tab));
   p.HW = a->HW; p.B = a->B; p.Cin = a->Cin;
   p.out_scale = 1.0f / (a->w_frag_scale * CSX);
   p.stamps = nullptr;

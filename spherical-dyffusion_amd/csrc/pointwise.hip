@@ -1,5 +1,7 @@
 // HBM-bound pointwise / reduction kernels of the SFNO block and the DYffusion sampler, gfx950.
+#include <cmath>
 #include <mutex>
+#include <vector>
 #include "common.h"
 #include "pointwise.h"
 
@@ -620,6 +622,34 @@ int sdy_flags_ptr(unsigned** flags) {
   *flags = words[dev];
   return SDY_OK;
 }
+// ---- GELU table (common.h): cubic Taylor pieces of 16 Phi(x) around 385 nodes on [-6, 6], fp64 on the host --------------
+int sdy_gelu_table_ptr(const float** table_dev) {
+  static float* tabs[SDY_MAX_DEVICES] = {};
+  static std::mutex mu;
+  int dev = 0;
+  SDY_TRY(sdy_current_device(&dev));
+  std::lock_guard<std::mutex> g(mu);
+  if (!tabs[dev]) {
+    std::vector<float> h((size_t)SDY_GELU_NODES * 4);
+    const double hstep = 1.0 / 32.0, sx = (double)SDY_GELU_SX / (double)SDY_GELU_WS, inv_sqrt_2pi = 0.39894228040143267794;
+    for (int n = 0; n < SDY_GELU_NODES; ++n) {
+      const double x = -6.0 + n * hstep;
+      const double Phi = 0.5 * std::erfc(-x * 0.70710678118654752440), phi = inv_sqrt_2pi * std::exp(-0.5 * x * x);
+      double c0 = sx * Phi, c1 = sx * phi * hstep, c2 = -sx * x * phi * hstep * hstep / 2.0,
+             c3 = sx * (x * x - 1.0) * phi * hstep * hstep * hstep / 6.0;
+      if (n == 0) { c0 = 0.0; c1 = c2 = c3 = 0.0; }                       // clamped inputs: exactly 0 ...
+      if (n == SDY_GELU_NODES - 1) { c0 = sx; c1 = c2 = c3 = 0.0; }       // ... and exactly 16 v = 2 w
+      h[4 * n] = (float)c0; h[4 * n + 1] = (float)c1; h[4 * n + 2] = (float)c2; h[4 * n + 3] = (float)c3;
+    }
+    float* d = nullptr;
+    SDY_HIP_TRY(hipMalloc(&d, h.size() * sizeof(float)));
+    SDY_HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    tabs[dev] = d;
+  }
+  *table_dev = tabs[dev];
+  return SDY_OK;
+}
+
 extern "C" int sdy_status_flags(unsigned* flags, int reset, void* stream) {
   if (!flags) return SDY_ERR_ARG;
   unsigned* d = nullptr;

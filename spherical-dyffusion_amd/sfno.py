@@ -365,6 +365,28 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                     f"time must be in [{self.min_time}, {self.max_time}], but time is {tv}"
 
         h = self._get_native(dev)
+        max_b = int(lib.sdy_sfno_max_batch(h))
+        if B > max_b:
+            # One native call covers `max_b` rows (32-bit lane offsets in the spectral workspace: 60 at 180 x 360, E = 256).
+            # A larger batch runs as consecutive calls on near-equal row ranges; every row keeps its dropout stream (same call
+            # number, batch_offset + first row of the range), so the result equals the single call's row for row.
+            if rows_per_call not in (None, B) or keep_masks is not None or drop_path_keep is not None or \
+                    (self.mask_injector is not None and self.inference_dropout):
+                raise _lib.SdyError(f"batch {B} > {max_b} rows per native call cannot be split with stacked calls / injected masks")
+            n_chunks = -(-B // max_b)
+            step = -(-B // n_chunks)
+            call0, off0, outs = self._call, self.batch_offset, []
+            try:
+                for r0 in range(0, B, step):
+                    r1 = min(B, r0 + step)
+                    self._call, self.batch_offset = call0, off0 + r0
+                    outs.append(self.forward(inputs[r0:r1], time=None if tt is None else tt[r0:r1],
+                                             condition=None if condition is None else condition[r0:r1],
+                                             static_condition=None if static_condition is None else static_condition[r0:r1]))
+            finally:
+                self.batch_offset = off0
+            self._call = call0 + 1
+            return torch.cat(outs, dim=0)
         ws = self._workspace(h, dev, B)
         out = torch.empty(B, self.out_chans, nlat, nlon, dtype=torch.float32, device=dev)
         a = SdySfnoFwdArgs()
