@@ -914,33 +914,55 @@ const char* const kStageNames[ST_COUNT] = {
   "concat", "time_mlp", "encoder.0 conv", "encoder.2 conv", "instnorm coefficients", "rfft (lon)", "legendre analysis",
   "legendre synthesis", "irfft (lon)", "dhconv", "inner-skip conv", "mlp fused", "mlp fused (dropout)", "mlp fc1", "mlp fc2",
   "decoder.0 conv", "decoder.2 conv"};
+// Single-threaded by contract (one host thread issues forwards while the switch is on); the mutex only keeps the record list
+// consistent against a concurrent sdy_profile_read.  Events come from a pool and are reused across reads.
 struct SdyProfiler {
   bool on = false;
-  struct Rec { int stage; hipEvent_t e0, e1; };
+  struct Rec { int stage; hipEvent_t e0, e1; bool closed; };
   std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
   std::mutex mu;
-  int begin(int stage, hipStream_t s) {
-    Rec r{stage, nullptr, nullptr};
-    SDY_HIP_TRY(hipEventCreate(&r.e0));
-    SDY_HIP_TRY(hipEventCreate(&r.e1));
-    SDY_HIP_TRY(hipEventRecord(r.e0, s));
-    std::lock_guard<std::mutex> g(mu);
-    recs.push_back(r);
+  int get_event(hipEvent_t* e) {   // (under mu)
+    if (!pool.empty()) { *e = pool.back(); pool.pop_back(); return SDY_OK; }
+    SDY_HIP_TRY(hipEventCreate(e));
     return SDY_OK;
   }
-  int end(hipStream_t s) {
+  // returns the record's index (>= 0) in *idx; nothing is leaked when an event cannot be created or recorded
+  int begin(int stage, hipStream_t s, int* idx) {
     std::lock_guard<std::mutex> g(mu);
-    SDY_HIP_TRY(hipEventRecord(recs.back().e1, s));
+    Rec r{stage, nullptr, nullptr, false};
+    SDY_TRY(get_event(&r.e0));
+    int rc = get_event(&r.e1);
+    if (rc == SDY_OK) {
+      hipError_t e = hipEventRecord(r.e0, s);
+      if (e != hipSuccess) rc = (int)e;
+    }
+    if (rc != SDY_OK) {
+      pool.push_back(r.e0);
+      if (r.e1) pool.push_back(r.e1);
+      return rc;
+    }
+    recs.push_back(r);
+    *idx = (int)recs.size() - 1;
+    return SDY_OK;
+  }
+  int end(int idx, hipStream_t s) {
+    std::lock_guard<std::mutex> g(mu);
+    if (idx < 0 || idx >= (int)recs.size()) return SDY_ERR_STATE;   // the list was read in between: drop the sample
+    SDY_HIP_TRY(hipEventRecord(recs[idx].e1, s));
+    recs[idx].closed = true;
     return SDY_OK;
   }
 } g_prof;
 }  // namespace
 
-#define SDY_STAGE(stage, call)                                   \
-  do {                                                           \
-    if (g_prof.on) SDY_TRY(g_prof.begin((stage), stream));       \
-    SDY_TRY(call);                                               \
-    if (g_prof.on) SDY_TRY(g_prof.end(stream));                  \
+// (a launch that fails returns before end(): its record stays open and sdy_profile_read skips it)
+#define SDY_STAGE(stage, call)                                              \
+  do {                                                                      \
+    int prof_idx_ = -1;                                                     \
+    if (g_prof.on) SDY_TRY(g_prof.begin((stage), stream, &prof_idx_));      \
+    SDY_TRY(call);                                                          \
+    if (prof_idx_ >= 0) (void)g_prof.end(prof_idx_, stream);                \
   } while (0)
 
 extern "C" int sdy_profile_enable(int on) {
@@ -957,13 +979,15 @@ extern "C" int sdy_profile_read(double* total_ms, long* launches, int n) {
   std::lock_guard<std::mutex> g(g_prof.mu);
   int rc = SDY_OK;
   for (auto& r : g_prof.recs) {
-    float ms = 0.f;
-    hipError_t e = hipEventSynchronize(r.e1);
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.e0, r.e1);
-    if (e != hipSuccess) rc = (int)e;
-    else { total_ms[r.stage] += ms; launches[r.stage] += 1; }
-    (void)hipEventDestroy(r.e0);
-    (void)hipEventDestroy(r.e1);
+    if (r.closed) {   // records whose launch failed were never closed: no elapsed time exists for them
+      float ms = 0.f;
+      hipError_t e = hipEventSynchronize(r.e1);
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.e0, r.e1);
+      if (e != hipSuccess) rc = (int)e;
+      else { total_ms[r.stage] += ms; launches[r.stage] += 1; }
+    }
+    g_prof.pool.push_back(r.e0);
+    g_prof.pool.push_back(r.e1);
   }
   g_prof.recs.clear();
   return rc;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/sdy_amd.h"
 
@@ -31,18 +32,22 @@ static inline int sdy_current_device(int* dev) {
   return (*dev >= 0 && *dev < SDY_MAX_DEVICES) ? SDY_OK : SDY_ERR_ARG;
 }
 inline int sdy_cu_count(int* n_cu) {                 // compute units of the CURRENT device
-  static int cache[SDY_MAX_DEVICES] = {};
+  static std::atomic<int> cache[SDY_MAX_DEVICES] = {};   // (atomics: two host threads may issue a device's first launch)
   int dev = 0;
   SDY_TRY(sdy_current_device(&dev));
-  if (!cache[dev]) SDY_HIP_TRY(hipDeviceGetAttribute(&cache[dev], hipDeviceAttributeMultiprocessorCount, dev));
-  *n_cu = cache[dev];
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (!v) {
+    SDY_HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    cache[dev].store(v, std::memory_order_relaxed);
+  }
+  *n_cu = v;
   return SDY_OK;
 }
 // Device address of the current device's sticky status word (allocated and zeroed on first use; pointwise.hip).
 int sdy_flags_ptr(unsigned** flags);
 struct SdyOncePerDevice {                            // `static SdyOncePerDevice once;` next to a kernel's attribute setup
-  bool done[SDY_MAX_DEVICES] = {};
-  int slot(bool** flag) {
+  std::atomic<bool> done[SDY_MAX_DEVICES] = {};      // (setting a function attribute twice is harmless; the flag is not a lock)
+  int slot(std::atomic<bool>** flag) {
     int dev = 0;
     SDY_TRY(sdy_current_device(&dev));
     *flag = &done[dev];
@@ -87,6 +92,14 @@ __device__ __forceinline__ void sdy_flag_range(unsigned* flags, float amax) {
 #define SDY_STREAM_STORE(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// MEASUREMENT BUILDS ONLY (csrc/Makefile EXTRA=-DSDY_H3_PASSES=1): drop the two cross terms Ah.Bl + Al.Bh of every
+// split-precision product, i.e. single-pass f16 MFMA arithmetic (fp16-class accuracy: ~1e-3) with everything else -- the
+// hi / lo splits, the loads of the lo fragments, the schedules -- unchanged.  Bounds what the three passes cost and gives the
+// "bf16-class" number BASELINE.json's configs[1] label asks about; never the shipped arithmetic.
+#ifndef SDY_H3_PASSES
+#define SDY_H3_PASSES 3
+#endif
+#define SDY_CROSS_TERM(stmt) do { if (SDY_H3_PASSES == 3) { stmt; } } while (0)
 
 // 16-byte global access as (wave-uniform 64-bit base in SGPRs) + (32-bit byte offset per lane): the SADDR form of
 // global_load / global_store.  The persistent kernels address rows as image base + row * HW + lane part; written as plain

@@ -261,9 +261,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
           const int g = kb * CGPK + CMT * i + mi;   // group of the tile's stream
           const int s = g % CRING;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[mi][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[mi][j], 0, 0, 0));
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], acc[mi][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], acc[mi][j], 0, 0, 0));
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], acc[mi][j], 0, 0, 0);
           r_hi[s] = wp[s * CGROUP];

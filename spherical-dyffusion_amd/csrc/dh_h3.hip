@@ -167,8 +167,8 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.0f;
     auto mma3 = [&](f32x16& c, const f16x8& ah, const f16x8& al, const f16x8& bhi, const f16x8& blo) {
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo, c, 0, 0, 0);
+      SDY_CROSS_TERM(c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi, c, 0, 0, 0));
+      SDY_CROSS_TERM(c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo, c, 0, 0, 0));
       c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi, c, 0, 0, 0);
     };
 #pragma unroll
@@ -337,7 +337,7 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
   SDY_TRY(sdy_cu_count(&n_cu));
   const int smem = 2 * DTN * DK * (int)sizeof(_Float16) + DWAVES * 8 * 64 * (int)sizeof(float);   // x tile + staging
   static SdyOncePerDevice once;
-  bool* attr_done = nullptr;
+  std::atomic<bool>* attr_done = nullptr;
   SDY_TRY(once.slot(&attr_done));
   if (!*attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dh_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));

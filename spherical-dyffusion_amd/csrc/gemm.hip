@@ -219,7 +219,7 @@ int launch_inst(const GemmParams& p, hipStream_t stream) {
   constexpr int LDA_S = A_KCONTIG ? BM + 1 : BM;
   constexpr size_t smem = (size_t)2 * BK * (LDA_S + BN) * sizeof(float);
   static SdyOncePerDevice once;
-  bool* attr_done = nullptr;
+  std::atomic<bool>* attr_done = nullptr;
   SDY_TRY(once.slot(&attr_done));
   if (!*attr_done) {
     if (smem > 48 * 1024) {

@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmParams p, con
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          SDY_CROSS_TERM(acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0));
+          SDY_CROSS_TERM(acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0));
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -315,7 +315,7 @@ int launch_h3(const GemmParams& p, const H3Packed& pk, float sx, float out_scale
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr size_t smem = (size_t)(2 * BM + 2 * BN) * HLD * sizeof(_Float16);
   static SdyOncePerDevice once;
-  bool* attr_done = nullptr;
+  std::atomic<bool>* attr_done = nullptr;
   SDY_TRY(once.slot(&attr_done));
   if (!*attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<WM, WN, MODE, TAG>),
@@ -466,8 +466,8 @@ __global__ __launch_bounds__(512) void gemm_h3_wide_kernel(const GemmParams p, c
         for (int i = 0; i < WM; ++i)
 #pragma unroll
           for (int j = 0; j < WN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            SDY_CROSS_TERM(acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0));
+            SDY_CROSS_TERM(acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0));
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           }
       }
@@ -482,7 +482,7 @@ template <int TAG>
 int launch_h3_wide(const GemmParams& p, const H3Packed& pk, float sx, float out_scale, hipStream_t stream) {
   constexpr size_t smem = (size_t)(2 * 256 + 2 * 128) * WLD * sizeof(_Float16);
   static SdyOncePerDevice once;
-  bool* attr_done = nullptr;
+  std::atomic<bool>* attr_done = nullptr;
   SDY_TRY(once.slot(&attr_done));
   if (!*attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_wide_kernel<TAG>),

@@ -136,9 +136,9 @@ __global__ __launch_bounds__(192, 3) void leg_h3_kernel(const LegParams p) {
         for (int mi = 0; mi < 2; ++mi) {
           const int s = 2 * i + mi;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[mi][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[mi][j], 0, 0, 0));
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], acc[mi][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], acc[mi][j], 0, 0, 0));
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], acc[mi][j], 0, 0, 0);
         }

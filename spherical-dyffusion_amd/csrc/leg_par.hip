@@ -201,9 +201,9 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
         }
         const int s = 2 * (ks & 3) + hf;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[hf][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[hf][j], 0, 0, 0));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], acc[hf][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], acc[hf][j], 0, 0, 0));
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], acc[hf][j], 0, 0, 0);
       }

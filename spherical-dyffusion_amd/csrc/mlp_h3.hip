@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   // beside fc2's MFMAs are full: 4 calls (row groups g4) x 10 rounds, one round behind every other MFMA; words kept in
   // mw[g4][].  In the network: 3.39 -> 3.26 ms per launch (together with the scalar chain and the pinned loops, which the
   // dropout variant could not use while the rounds sat in the chain).
+  static_assert(SDY_MLP_PINNED || !SDY_MLP_PHILOX_AHEAD, "the ahead-of-time Philox rounds ride on the pinned fc1 loop");
   uint32_t mw[4][4];
   uint32_t ac0 = 0, ac1 = 0, ac2 = 0, ac3 = 0, ak0 = 0, ak1 = 0;
   auto philox_ahead = [&](int hc, int idx) {   // idx = 10 g4 + round
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         const int j = k & 1;
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? a_lo : a_hi, (k >= 2 && k < 4) ? bl[c][j] : bh[c][j], acc[j], 0, 0, 0);
+        if (SDY_H3_PASSES == 3 || k >= 4)   // (k < 4: the cross terms, dropped by single-pass measurement builds only)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? a_lo : a_hi, (k >= 2 && k < 4) ? bl[c][j] : bh[c][j], acc[j], 0, 0, 0);
         if (k < 4) { if (ks + 1 < KS1) ldb1(c ^ 1, ks + 1, k); }
         else if (k == 4) r_lo[ks] = wp[ks * GROUP_F8 + 64];
         else r_hi[ks] = wp[ks * GROUP_F8];
@@ -292,9 +294,9 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         for (int part = 0; part < 4; ++part) ldb1(c ^ 1, ks + 1, part);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[ks], bh[c][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[ks], bh[c][j], acc[j], 0, 0, 0));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks], bl[c][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks], bl[c][j], acc[j], 0, 0, 0));
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[ks], bh[c][j], acc[j], 0, 0, 0);
       r_hi[ks] = wp[ks * GROUP_F8];
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
           const int j = k & 1;
           const f16x8 a = (k < 2) ? r_lo[s] : r_hi[s];
           const f16x8 b = (k >= 2 && k < 4) ? bl[c][j] : bh[c][j];
-          oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, oacc[mi][j], 0, 0, 0);
+          if (SDY_H3_PASSES == 3 || k >= 4) oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, oacc[mi][j], 0, 0, 0);
           if (SDY_MLP_PINNED && mi == 0 && k < 4 && t + 1 < KSC) ldb1(c ^ 1, t + 1, k);   // one LDS read behind each MFMA
           if (SDY_MLP_PINNED && !CHAIN) __builtin_amdgcn_sched_barrier(0);
           if constexpr (CHAIN) {
@@ -867,7 +869,7 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));   // persistent: one workgroup per CU (128 KB of LDS each)
   constexpr size_t smem = (size_t)(2 * TN * ME + 4 * TN * HC) * sizeof(_Float16) + 5 * ME * sizeof(float);
   static SdyOncePerDevice once;
-  bool* attr_done = nullptr;
+  std::atomic<bool>* attr_done = nullptr;
   SDY_TRY(once.slot(&attr_done));
   if (!*attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel<false>),

@@ -149,6 +149,15 @@ class MultiHorizonForecastingDYffusion(_BaseExperiment):
         self.model.model.batch_offset = int(offset)                      # forecaster SFNO (no dropout today)
         self.model.interpolator.model.batch_offset = int(offset)         # interpolator SFNO
 
+    def dropout_calls(self):
+        """Position of both networks in their dropout streams (the call counters that key the Philox stream beside the
+        trajectory index).  A driver that runs one window as several device batches restores it before each batch
+        (`set_dropout_calls`), so a trajectory's draws do not depend on how the window was cut (`run_inference(max_batch=)`)."""
+        return (self.model.model._call, self.model.interpolator.model._call)
+
+    def set_dropout_calls(self, state) -> None:
+        self.model.model._call, self.model.interpolator.model._call = int(state[0]), int(state[1])
+
     def get_preds_at_t_for_batch(self, batch: Dict[str, Tensor], horizon, split: str = "predict", ensemble: bool = False,
                                  is_autoregressive: bool = False, prepare_inputs: bool = True, **kwargs):
         """forecasting_multi_horizon.py:331-381 (cache_preds branch: DYffusion predicts all horizons at once)."""

@@ -315,10 +315,13 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
             stitcher.apply_initial_condition(batch, ic_rows if rect else ic_rows - ic_list[0])
             step = n_rows if max_batch is None else min(n_rows, int(max_batch))
             parts = []
+            calls0 = module.dropout_calls() if hasattr(module, "dropout_calls") else None
             for r0 in range(0, n_rows, step):
                 r1 = min(n_rows, r0 + step)
                 if hasattr(module, "set_batch_offset"):
                     module.set_batch_offset(start + r0)
+                if calls0 is not None:      # every chunk of the window replays the same call numbers of the dropout streams
+                    module.set_dropout_calls(calls0)
                 chunk = batch if (r0 == 0 and r1 == n_rows) else {k: v[r0:r1] for k, v in batch.items()}
                 parts.append((r1 - r0, stepper.run_on_batch(chunk, None, n_forward_steps=forward_steps_in_memory,
                                                             defer_metrics=True)))
