@@ -10,7 +10,7 @@ import bench
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-exp, _ = bench.build_models(dev)
+exp = bench.build_models(dev)
 x, f = bench.synthetic_state(0, bench.MEMBERS, dev)
 ip = exp.model.interpolator
 inp = torch.cat([x, x], dim=1)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-2 profile set (GPU box, via gpurun): bash tools/profile_r2.sh <tag>
+# Per-round profile set (GPU box, via gpurun): bash tools/profile_round.sh <tag>     (r2a, r2b, r3a, ...)
 #   1. bench line (default run) + rocprofv3 --kernel-trace --stats of the same command
 #   2. PMC passes over one interpolator + one forecaster forward at B = 25 (tools/pmc_forward25.py), each counter group in its
 #      own pass with --kernel-trace only: FETCH_SIZE, WRITE_SIZE (HBM traffic), matrix-pipe / issue counters
-TAG=${1:-r2a}
+TAG=${1:-r3a}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 export TMPDIR=/tmp
