@@ -112,6 +112,19 @@ class MultiStepStepper:
         # one entry per distinct variable of (in packer) U (out packer)
         self._entries = list(dict.fromkeys(self.in_names + self.out_names))
 
+    @classmethod
+    def from_statistics(cls, module, in_names: List[str], out_names: List[str], forcing_names: Optional[List[str]] = None,
+                        data_dir_stats=None, data_dir=None, prescriber: Optional[Prescriber] = None) -> "MultiStepStepper":
+        """The reference's constructor path (`stepper_multistep.py:103-131`): forcings default to the input-only names,
+        the scalars of `normalize_names` = in U out come from `centering` / `scaling` found in `data_dir_stats`, `data_dir`
+        or the packaged statistics (`normalizer.find_statistics`)."""
+        from .normalizer import find_statistics, get_normalizer
+        if forcing_names is None:
+            forcing_names = [n for n in in_names if n not in out_names]
+        path_mean, path_std = find_statistics(data_dir_stats, data_dir)
+        norm = get_normalizer(path_mean, path_std, list(dict.fromkeys(list(in_names) + list(out_names))))
+        return cls(module, in_names, out_names, forcing_names, norm.means, norm.stds, prescriber)
+
     # ---- helpers ------------------------------------------------------------------------------------------------
     def _table(self, names: List[str], data: Dict[str, torch.Tensor]) -> SdyVarTable:
         t = SdyVarTable()

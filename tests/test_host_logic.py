@@ -333,3 +333,66 @@ def test_synthetic_weights_equal_the_oracle_generator(sdy):
         assert list(a) == list(b)
         assert all(torch.equal(a[k], b[k]) for k in a)
         net.load_state_dict(a, strict=True)
+
+
+# The variable lists of the shipped data module (`src/configs/datamodule/fv3gfs_prescriptive_only.yaml:22-60`).
+_FV3GFS_STATE = (["PRESsfc", "surface_temperature"] + [f"{v}_{k}" for v in
+                 ("air_temperature", "specific_total_water", "eastward_wind", "northward_wind") for k in range(8)])
+_FV3GFS_FORCING = ["DSWRFtoa", "HGTsfc"]
+
+
+def test_packaged_statistics_hold_the_reference_scalars(sdy, tmp_path):
+    """`data_statistics/{centering,scaling}.nc` of the reference, shipped HDF5-free (`tools/convert_statistics.py`): known
+    answers read off the reference's files (float32, printed to round-trip), the shipped variable lists are covered, the
+    reference's search order is kept (`stepper_multistep.py:112-127`), a NaN scaling is refused."""
+    import json
+    import math
+    import os
+    nz = sdy.normalizer
+    mean_p, std_p = nz.find_statistics()
+    assert mean_p.parent == nz.PACKAGED_STATISTICS and mean_p.name == "centering.json" and std_p.name == "scaling.json"
+    means, stds = nz.load_dict(mean_p), nz.load_dict(std_p)
+    assert len(means) == len(stds) == 55 and set(means) == set(stds)
+    known_mean = {"PRESsfc": 96794.3828125, "surface_temperature": 277.7657775878906, "air_temperature_7": 276.7269287109375,
+                  "specific_total_water_0": 2.01499710783537e-06, "DSWRFtoa": 298.72540283203125, "HGTsfc": 377.55096435546875}
+    known_std = {"DLWRFsfc": 61.89848709106445, "HGTsfc": 836.8834228515625, "PRESsfc": 791.6809692382812,
+                 "specific_total_water_0": 1.6999416985186144e-08, "northward_wind_3": 17.700998306274414}
+    for k, v in known_mean.items():
+        assert means[k] == v and np.float32(v) == v        # bit-exact float32
+    for k, v in known_std.items():
+        assert stds[k] == v and np.float32(v) == v
+    norm = nz.get_normalizer(mean_p, std_p, _FV3GFS_STATE + _FV3GFS_FORCING)
+    assert all(math.isfinite(norm.means[n]) and norm.stds[n] > 0 for n in _FV3GFS_STATE + _FV3GFS_FORCING)
+    assert nz.StandardNormalizer.from_state(norm.get_state()).stds == norm.stds
+    x = {"PRESsfc": torch.full((2, 2), 96794.3828125 + 791.6809692382812), "other": torch.ones(1)}
+    y = norm.normalize(x)
+    assert torch.allclose(y["PRESsfc"], torch.ones(2, 2)) and y["other"] is x["other"]           # normalizer.py:98-102
+    assert torch.allclose(norm.denormalize(y)["PRESsfc"], x["PRESsfc"])
+    assert math.isnan(stds["soil_moisture"])
+    with pytest.raises(ValueError, match="soil_moisture"):
+        nz.get_normalizer(mean_p, std_p, ["soil_moisture"])
+    with pytest.raises(KeyError):
+        nz.load_dict(mean_p, ["no_such_variable"])
+    # a directory given by the caller wins over the packaged copy
+    for stem, val in (("centering", 1.5), ("scaling", 2.5)):
+        with open(tmp_path / (stem + ".json"), "w") as fh:
+            json.dump({"variables": {"a": val}}, fh)
+    m2, s2 = nz.find_statistics(data_dir_stats=tmp_path)
+    assert m2.parent == tmp_path and nz.load_dict(m2) == {"a": 1.5} and nz.load_dict(s2) == {"a": 2.5}
+    # the stepper's constructor path: forcings = input-only names, scalars by name
+    st = sdy.MultiStepStepper.from_statistics(None, _FV3GFS_STATE + _FV3GFS_FORCING, _FV3GFS_STATE)
+    assert sorted(st.forcing_names) == sorted(_FV3GFS_FORCING) and st.in_names == _FV3GFS_STATE
+    assert st.means["HGTsfc"] == known_mean["HGTsfc"] and st.stds["HGTsfc"] == known_std["HGTsfc"]
+    # where the reference's files and a libhdf5 are at hand (the build container), the converter reproduces the shipped JSON
+    src = "/root/reference/data_statistics"
+    if os.path.exists(src):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            "convert_statistics", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "convert_statistics.py"))
+        conv = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(conv)
+        try:
+            fresh = conv.read_scalars(os.path.join(src, "scaling.nc"))
+        except SystemExit:
+            return
+        assert {k: v for k, v in fresh.items() if v == v} == {k: v for k, v in stds.items() if v == v}
