@@ -152,6 +152,11 @@ def stage_work(B):
         "decoder.0 conv": (2.0 * E * HW * B * (E + (6 * cin_f + 10 * cin_i) / 16),
                            2 * act + 4.0 * HW * B * (6 * cin_f + 10 * cin_i) / 16, "hbm"),
         "decoder.2 conv": (2.0 * E * STATE_CH * HW * B, act + 4.0 * STATE_CH * HW * B, "hbm"),
+        # encoder / decoder as one launch each: the 256-channel hidden activation is neither written nor read
+        "encoder (fused pair)": (2.0 * E * HW * B * (E + (6 * cin_f + 10 * cin_i) / 16),
+                                 act + 4.0 * E * HW + 4.0 * HW * B * (6 * cin_f + 10 * cin_i) / 16, "hbm"),
+        "decoder (fused pair)": (2.0 * E * HW * B * (E + STATE_CH + (6 * cin_f + 10 * cin_i) / 16),
+                                 act + 4.0 * HW * B * (STATE_CH + (6 * cin_f + 10 * cin_i) / 16), "hbm"),
     }
     return w
 

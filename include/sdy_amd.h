@@ -221,6 +221,29 @@ int sdy_mlp_h3_pack(const float* w1_host, const float* w2_host, int E, int hidde
                     float* scale2);
 int sdy_mlp_h3(const sdy_mlp_args* args, void* stream);
 
+/* Two 1x1 convolutions with a GELU between them in ONE launch -- the encoder (src/models/sfno/sfnonet.py:609-618, with the
+ * position embedding of :824 as the addend) and the decoder (:734-744 on [block output | inputs], :831-837):
+ *   out[b] = W2 . GELU( W1 . x[b] + b1 ) + add[b or broadcast]
+ * The 256-channel hidden activation stays on the compute unit.  Split-fp16 arithmetic of sdy_conv1x1 (w_h3).  Supported
+ * shapes (sdy_pair_h3_supported): hidden == 256 and either Cout == 256 with Cin <= 144, or Cout <= 64 with Cin <= 416;
+ * anything else returns SDY_ERR_UNSUPPORTED and the caller issues two sdy_conv1x1 calls. */
+typedef struct sdy_pair_args {
+  const float* x;  long x_bstride;     /* dev (B, >=Cin, HW) */
+  const void* w; float w1_scale; float w2_scale;     /* sdy_pair_h3_pack output and the two scales it returned */
+  const float* b1;                     /* dev [hidden] or NULL */
+  float* out;      long out_bstride;   /* dev (B, >=Cout, HW) */
+  const float* add; long add_bstride;  /* dev (B or 1, Cout, HW) or NULL; add_bstride 0 broadcasts over b */
+  int B, Cin, hidden, Cout, HW;
+  double* stats;                       /* dev [B*Cout*2] or NULL (Cout == 256 only): (sum, sum of squares) over HW of every
+                                          output plane are ADDED here, as in sdy_mlp_args */
+} sdy_pair_args;
+int sdy_pair_h3_supported(int Cin, int hidden, int Cout);
+size_t sdy_pair_h3_pack_bytes(int Cin, int hidden, int Cout);
+/* w1_host: (hidden, Cin) row-major;  w2_host: (Cout, hidden) row-major */
+int sdy_pair_h3_pack(const float* w1_host, const float* w2_host, int Cin, int hidden, int Cout, void* packed_dev,
+                     float* scale1, float* scale2);
+int sdy_pair_h3(const sdy_pair_args* args, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Whole network.  Replaces SphericalFourierNeuralOperatorNet.__init__/forward
  * (src/models/sfno/sfnonet.py:426-841) + BaseModel.concat_condition_if_needed (src/models/_base_model.py:166-192)

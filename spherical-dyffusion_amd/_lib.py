@@ -64,6 +64,18 @@ class SdyMlpArgs(C.Structure):
     ]
 
 
+class SdyPairArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_bstride", C.c_long),
+        ("w", C.c_void_p), ("w1_scale", C.c_float), ("w2_scale", C.c_float),
+        ("b1", C.c_void_p),
+        ("out", C.c_void_p), ("out_bstride", C.c_long),
+        ("add", C.c_void_p), ("add_bstride", C.c_long),
+        ("B", C.c_int), ("Cin", C.c_int), ("hidden", C.c_int), ("Cout", C.c_int), ("HW", C.c_int),
+        ("stats", C.c_void_p),
+    ]
+
+
 SDY_MAX_VARS = 96
 
 
@@ -155,6 +167,11 @@ SIGNATURES = {
     "sdy_mlp_h3_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float),
                                   C.POINTER(C.c_float)]),
     "sdy_mlp_h3": (C.c_int, [C.POINTER(SdyMlpArgs), C.c_void_p]),
+    "sdy_pair_h3_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "sdy_pair_h3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "sdy_pair_h3_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float),
+                                   C.POINTER(C.c_float)]),
+    "sdy_pair_h3": (C.c_int, [C.POINTER(SdyPairArgs), C.c_void_p]),
     "sdy_conv256_h3_supported": (C.c_int, [C.c_int, C.c_int]),
     "sdy_conv256_h3_pack_bytes": (C.c_size_t, []),
     "sdy_conv256_h3_pack_bytes_cin": (C.c_size_t, [C.c_int]),

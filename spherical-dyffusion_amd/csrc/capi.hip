@@ -577,6 +577,8 @@ struct sdy_sfno {
   sdy_sht_plan* plan_data = nullptr;  // data grid (first forward / last inverse)
   sdy_sht_plan* plan_lg = nullptr;    // legendre-gauss (inner transforms); may alias plan_data
   DevBuf pos, e0w, e0b, e2w, d0w, d0b, d2w;
+  // encoder / decoder as ONE launch each (pair_h3.hip): host copies until both weights of a pair are known
+  struct Pair { std::vector<float> w1_host, w2_host; void* w = nullptr; float s1 = 1.0f, s2 = 1.0f; } enc, dec;
   DevBuf t1w, t1b, t3w, t3b, freq, wbt, bb;
   std::vector<BlockW> blk;
   SdyTimeMlp tm;
@@ -691,6 +693,8 @@ extern "C" void sdy_sfno_destroy(sdy_sfno* n) {
     for (DevBuf* b : bs) dev_free(*b);
     if (w.mlp) (void)hipFree(w.mlp);
   }
+  if (n->enc.w) (void)hipFree(n->enc.w);
+  if (n->dec.w) (void)hipFree(n->dec.w);
   delete n;
 }
 
@@ -720,13 +724,36 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
     return SDY_OK;
   }
   if (name == "pos_embed") { EXPECT_NUMEL((size_t)E * n->HW); return dev_upload(n->pos, host, numel); }
-  if (name == "encoder.0.weight") { EXPECT_NUMEL((size_t)E * Cin); return dev_upload_conv(n->e0w, host, E, Cin, E, h3); }
+  // (the pair kernel's weight stream needs both matrices of a pair: packed when the second one arrives)
+  auto pack_pair = [&](sdy_sfno::Pair& pr, int cin, int cout) -> int {
+    if (!h3 || !sdy_pair_h3_supported(cin, E, cout) || pr.w1_host.empty() || pr.w2_host.empty()) return SDY_OK;
+    if (!pr.w) SDY_HIP_TRY(hipMalloc(&pr.w, sdy_pair_h3_pack_bytes(cin, E, cout)));
+    return sdy_pair_h3_pack(pr.w1_host.data(), pr.w2_host.data(), cin, E, cout, pr.w, &pr.s1, &pr.s2);
+  };
+  if (name == "encoder.0.weight") {
+    EXPECT_NUMEL((size_t)E * Cin);
+    n->enc.w1_host.assign(host, host + numel);
+    SDY_TRY(pack_pair(n->enc, Cin, E));
+    return dev_upload_conv(n->e0w, host, E, Cin, E, h3);
+  }
   if (name == "encoder.0.bias") { EXPECT_NUMEL(E); return dev_upload(n->e0b, host, numel); }
-  if (name == "encoder.2.weight") { EXPECT_NUMEL((size_t)E * E); return dev_upload_conv(n->e2w, host, E, E, E, h3); }
-  if (name == "decoder.0.weight") { EXPECT_NUMEL((size_t)E * n->decC); return dev_upload_conv(n->d0w, host, E, n->decC, E, h3); }
+  if (name == "encoder.2.weight") {
+    EXPECT_NUMEL((size_t)E * E);
+    n->enc.w2_host.assign(host, host + numel);
+    SDY_TRY(pack_pair(n->enc, Cin, E));
+    return dev_upload_conv(n->e2w, host, E, E, E, h3);
+  }
+  if (name == "decoder.0.weight") {
+    EXPECT_NUMEL((size_t)E * n->decC);
+    n->dec.w1_host.assign(host, host + numel);
+    SDY_TRY(pack_pair(n->dec, n->decC, c.out_chans));
+    return dev_upload_conv(n->d0w, host, E, n->decC, E, h3);
+  }
   if (name == "decoder.0.bias") { EXPECT_NUMEL(E); return dev_upload(n->d0b, host, numel); }
   if (name == "decoder.2.weight") {
     EXPECT_NUMEL((size_t)c.out_chans * E);
+    n->dec.w2_host.assign(host, host + numel);
+    SDY_TRY(pack_pair(n->dec, n->decC, c.out_chans));
     return dev_upload_conv(n->d2w, host, c.out_chans, E, n->ldo, h3);
   }
   if (c.with_time_emb) {
@@ -908,12 +935,12 @@ extern "C" int sdy_sfno_time_embed(sdy_sfno* n, const float* time, int B, float*
 namespace {
 enum SdyStage {
   ST_CONCAT, ST_TIME_MLP, ST_ENC0, ST_ENC2, ST_NORM_COEFFS, ST_FFT_FWD, ST_LEG_FWD, ST_LEG_INV, ST_FFT_INV, ST_DHCONV,
-  ST_SKIP_CONV, ST_MLP_FUSED, ST_MLP_FUSED_DROP, ST_FC1, ST_FC2, ST_DEC0, ST_DEC2, ST_COUNT
+  ST_SKIP_CONV, ST_MLP_FUSED, ST_MLP_FUSED_DROP, ST_FC1, ST_FC2, ST_DEC0, ST_DEC2, ST_ENC_PAIR, ST_DEC_PAIR, ST_COUNT
 };
 const char* const kStageNames[ST_COUNT] = {
   "concat", "time_mlp", "encoder.0 conv", "encoder.2 conv", "instnorm coefficients", "rfft (lon)", "legendre analysis",
   "legendre synthesis", "irfft (lon)", "dhconv", "inner-skip conv", "mlp fused", "mlp fused (dropout)", "mlp fc1", "mlp fc2",
-  "decoder.0 conv", "decoder.2 conv"};
+  "decoder.0 conv", "decoder.2 conv", "encoder (fused pair)", "decoder (fused pair)"};
 // Single-threaded by contract (one host thread issues forwards while the switch is on); the mutex only keeps the record list
 // consistent against a concurrent sdy_profile_read.  Events come from a pool and are reused across reads.
 struct SdyProfiler {
@@ -1047,6 +1074,17 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   };
 
   // ---- encoder (sfnonet.py:609-618,810,824): conv+bias -> GELU -> conv (no bias) -> + pos_embed
+  static const bool no_pair = std::getenv("SDY_NO_PAIR") != nullptr;   // A/B: the two-launch encoder / decoder
+  static const bool no_stats0 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
+  if (n->enc.w && !no_pair) {   // one launch (pair_h3.hip), block 0's norm0 statistics from its epilogue
+    sdy_pair_args pa{};
+    pa.x = cat_in; pa.x_bstride = cat_bs; pa.w = n->enc.w; pa.w1_scale = n->enc.s1; pa.w2_scale = n->enc.s2;
+    pa.b1 = n->e0b.p; pa.out = xb; pa.out_bstride = (long)E * HW;
+    if (c.pos_embed) { pa.add = n->pos.p; pa.add_bstride = 0; }
+    pa.B = B; pa.Cin = Cin; pa.hidden = E; pa.Cout = E; pa.HW = HW;
+    if (!no_stats0) { pa.stats = st0; have_st0 = true; }
+    SDY_STAGE(ST_ENC_PAIR, sdy_pair_h3(&pa, stream));
+  } else {
   conv_reset();
   cv.x = cat_in; cv.x_bstride = cat_bs; use_w(n->e0w); cv.ldw = E; cv.out = xa; cv.out_bstride = (long)E * HW;
   cv.Cin = Cin; cv.Cout = E; cv.bias = n->e0b.p; cv.act = 1;
@@ -1055,11 +1093,10 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   cv.x = xa; cv.x_bstride = (long)E * HW; use_w(n->e2w); cv.ldw = E; cv.out = xb; cv.out_bstride = (long)E * HW;
   cv.Cin = E; cv.Cout = E;
   if (c.pos_embed) { cv.add = n->pos.p; cv.add_bstride = 0; cv.add_mode = 2; }
-  {   // block 0's norm0 statistics from this convolution's epilogue (persistent kernel only): no pass over its output
-    static const bool no_stats0 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
-    if (cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats0) { cv.stats = st0; have_st0 = true; }
-  }
+  // block 0's norm0 statistics from this convolution's epilogue (persistent kernel only): no pass over its output
+  if (cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats0) { cv.stats = st0; have_st0 = true; }
   SDY_STAGE(ST_ENC2, sdy_conv1x1(&cv, stream));
+  }
 
   float* cur = xb;
   float* nxt = xa;
@@ -1158,6 +1195,14 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   }
 
   // ---- decoder (sfnonet.py:734-744,831-837)
+  if (n->dec.w && !no_pair) {
+    sdy_pair_args pa{};
+    pa.x = cat; pa.x_bstride = cat_bs; pa.w = n->dec.w; pa.w1_scale = n->dec.s1; pa.w2_scale = n->dec.s2;
+    pa.b1 = n->d0b.p; pa.out = a->out; pa.out_bstride = (long)c.out_chans * HW;
+    pa.B = B; pa.Cin = n->decC; pa.hidden = E; pa.Cout = c.out_chans; pa.HW = HW;
+    SDY_STAGE(ST_DEC_PAIR, sdy_pair_h3(&pa, stream));
+    return SDY_OK;
+  }
   float* dh = xa;
   conv_reset();
   cv.x = cat; cv.x_bstride = cat_bs; use_w(n->d0w); cv.ldw = E;

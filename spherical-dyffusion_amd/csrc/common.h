@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/sdy_amd.h"
 
@@ -56,6 +57,15 @@ struct SdyOncePerDevice {                            // `static SdyOncePerDevice
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Compile-time loop: f(std::integral_constant<int, I>) for I = B .. E - 1.  `#pragma unroll` gives up on long bodies
+// ("unrolled size too large"), and register arrays indexed by the loop variable then live in scratch.
+template <int B, int E, class F>
+__device__ __forceinline__ void sdy_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    sdy_static_for<B + 1, E>(f);
+  }
+}
 // fp16 hi / lo split of 8 fp32 values (already scaled) for the split-precision MFMA kernels, written on 2-vectors so that it
 // compiles to packed conversions (v_cvt_pk_f16_f32, v_pk_add_f32 / fma_mix) instead of ~6 scalar VALU ops per element.
 typedef float sdy_f32x2 __attribute__((ext_vector_type(2)));

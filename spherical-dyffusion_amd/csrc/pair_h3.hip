@@ -1,0 +1,716 @@
+// Two 1x1 convolutions with a GELU between them in ONE launch for gfx950: the encoder and the decoder of the SFNO,
+//     out = W2 . GELU(W1 . x + b1) + add
+// (src/models/sfno/sfnonet.py:609-618 + the position embedding of :824 -- Cin -> 256 -> 256 -- and :734-744 applied to
+// [block output | inputs] at :831-837 -- 256 + Cin -> 256 -> Cout).  Run as two convolutions the pair writes its 256-channel
+// hidden activation to HBM and reads it back (3.3 of the encoder's 5.7 GB and of the decoder's 6.1 GB at B = 25); here one
+// workgroup owns 64 pixels end to end as in mlp_h3.hip and the hidden tile stays in LDS.
+//
+//   x tile    fp32 -> x16, fp16 hi / lo -> LDS [px][k], rows padded to an ODD number of 16-byte chunks (fragment reads and
+//             staging writes are then bank-conflict free for any row length).  More than 13 k-steps of input (the decoder)
+//             go through the tile in NPART = 2 parts, fc1 accumulating over both.
+//   fc1       wave w: hidden rows 32 w .. +32 of BOTH 128-row chunks, all 64 px (2 x 2 accumulator tiles): a k-step's four
+//             LDS fragment reads feed 12 MFMAs.
+//   chain     bias + exact-erf GELU, x16, split -> LDS H[chunk][px][128 k] (mlp_h3's layout).  chain(0) stands alone;
+//             chain(1) runs beside the MFMAs of fc2(0) when there are enough of them (256 output rows), else alone.
+//   fc2       256 output rows: wave w rows 64 w .. +64 (2 x 2 tiles) as in mlp_h3.  <= 64 output rows (decoder): wave w
+//             owns ONE tile, rows 32 (w / 2) .. +32 of pixels 32 (w % 2) .. +32.
+//   epilogue  through LDS -> 16-byte row stores with the addend (position embedding: batch stride 0) and, for the encoder,
+//             the InstanceNorm statistics of what is stored (block 0's norm0), fp64 per row and image as in mlp_h3.
+// The weights stream from L2 as MFMA A-fragment pairs in consumption order through a ring of 16 groups; a tile's N groups
+// are numbered 0 .. NPAD - 1 (NPAD = N rounded up to 16; the holes are never loaded), so ring slot = position mod 16 holds
+// for every tile, and position g's slot is refilled with group g + 16 right behind g's last MFMA.
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef const f16x8 __attribute__((address_space(1)))* wptr_t;   // (explicit global address space: see mlp_h3.hip)
+
+namespace {
+
+constexpr int PH = 256;        // hidden channels
+constexpr int PTN = 64;        // pixels per workgroup
+constexpr int PHC = 128;       // hidden channels per chunk
+constexpr int PKSC = PHC / 16; // k-steps of fc2 per chunk
+constexpr int PRING = 16;
+constexpr int PGROUP = 2 * 64; // f16x8 elements per group (hi | lo)
+constexpr float PSX = 16.0f;   // activation pre-scale
+
+template <int KSP, int NPART, int MO>
+struct PairCfg {
+  static_assert(MO == 8 || MO == 2, "256 output rows (8 row tiles) or <= 64 (2)");
+  static constexpr int NF1 = 2 * NPART * KSP;             // fc1 groups per wave and tile
+  static constexpr int NF2 = MO == 8 ? 16 : 8;            // fc2 groups per chunk
+  static constexpr int N = NF1 + 2 * NF2;
+  static constexpr int NPAD = (N + PRING - 1) / PRING * PRING;
+  static constexpr int XROW = 16 * KSP + 8;               // halfs per pixel row of the x tile (2 KSP + 1 chunks)
+  static constexpr int NI = (2 * KSP + 15) / 16;          // channel octets per thread in the staging role
+  static constexpr int KMAX = 16 * KSP * NPART;           // input channels
+  static constexpr size_t XS_BYTES = (size_t)2 * PTN * XROW * 2;
+  static constexpr size_t HS_BYTES = (size_t)4 * PTN * PHC * 2;
+  static constexpr size_t LDS_BYTES = XS_BYTES + HS_BYTES + PH * 4;
+  static_assert(N >= PRING, "the first ring fill takes 16 real groups");
+  static_assert(MO == 8 || XS_BYTES >= (size_t)64 * PTN * 4, "the 64-row output tile is staged in the x tile's storage");
+};
+
+// chain(0) beside the MFMAs of fc1's last part (chunk-major there) or on its own behind a k-step-major fc1
+#ifndef SDY_PAIR_FC1_CHAIN
+#define SDY_PAIR_FC1_CHAIN 1
+#endif
+constexpr bool kChainInFc1 = SDY_PAIR_FC1_CHAIN != 0;
+
+struct PairParams {
+  const float* x; long x_bs; int Cin;
+  const f16x8* w;                          // [4 waves][NPAD + 16 groups][hi | lo][64 lanes]
+  const float* b1;
+  float* out; long out_bs; int Cout;
+  const float* add; long add_bs;
+  int HW, B;
+  float s1, s2;                            // accumulator scales: 1 / (w_scale * PSX)
+  double* stats;                           // optional [B][256][2] (MO == 8 only)
+  unsigned* flags;
+  unsigned long long* stamps;              // timing experiments only (SDY_PAIR_STAMPS)
+};
+
+__device__ __forceinline__ int hs_swz(int px) { return (px & 15) ^ (((px >> 4) & 1) * 3); }   // (mlp_h3.hip, px_swz)
+__device__ __forceinline__ int hs_off(int px, int c) { return px * PHC + (((c ^ hs_swz(px)) & 15) << 3); }
+
+struct Piece { float v[4], t[4], e[4], q[4]; };
+constexpr float G_CT = 0.3275911f * 0.70710678118654752440f, G_KAP = -0.5f * 1.44269504088896340736f, G_HS = 0.5f * PSX;
+constexpr float G_A5 = 1.061405429f * G_HS, G_A4 = -1.453152027f * G_HS, G_A3 = 1.421413741f * G_HS,
+                G_A2 = -0.284496736f * G_HS, G_A1 = 0.254829592f * G_HS;
+// PSX * gelu(v) = HS v + |v| (HS - Q),  Q = t poly(t) exp(-v^2 / 2),  t = 1 / (1 + CT |v|)  (A&S 7.1.26: the arithmetic of
+// gelu_erf in common.h and of mlp_h3's chain), in 10 slots of <= 6 plain VALU instructions: one slot hides behind one MFMA.
+__device__ __forceinline__ void gelu_slot(Piece& s, int st) {
+  switch (st) {
+    case 1:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s.t[r] = fmaf(__builtin_fabsf(s.v[r]), G_CT, 1.0f);
+      s.e[0] = s.v[0] * G_KAP; s.e[1] = s.v[1] * G_KAP;
+      break;
+    case 2:
+      s.t[0] = __builtin_amdgcn_rcpf(s.t[0]); s.t[1] = __builtin_amdgcn_rcpf(s.t[1]);
+      s.e[2] = s.v[2] * G_KAP; s.e[3] = s.v[3] * G_KAP;
+      s.e[0] *= s.v[0]; s.e[1] *= s.v[1];
+      break;
+    case 3:
+      s.t[2] = __builtin_amdgcn_rcpf(s.t[2]); s.t[3] = __builtin_amdgcn_rcpf(s.t[3]);
+      s.e[2] *= s.v[2]; s.e[3] *= s.v[3];
+      s.q[0] = fmaf(s.t[0], G_A5, G_A4); s.q[1] = fmaf(s.t[1], G_A5, G_A4);
+      break;
+    case 4:
+      s.e[0] = __builtin_amdgcn_exp2f(s.e[0]); s.e[1] = __builtin_amdgcn_exp2f(s.e[1]);
+      s.q[2] = fmaf(s.t[2], G_A5, G_A4); s.q[3] = fmaf(s.t[3], G_A5, G_A4);
+      s.q[0] = fmaf(s.q[0], s.t[0], G_A3); s.q[1] = fmaf(s.q[1], s.t[1], G_A3);
+      break;
+    case 5:
+      s.e[2] = __builtin_amdgcn_exp2f(s.e[2]); s.e[3] = __builtin_amdgcn_exp2f(s.e[3]);
+      s.q[2] = fmaf(s.q[2], s.t[2], G_A3); s.q[3] = fmaf(s.q[3], s.t[3], G_A3);
+      s.q[0] = fmaf(s.q[0], s.t[0], G_A2); s.q[1] = fmaf(s.q[1], s.t[1], G_A2);
+      break;
+    case 6:
+      s.q[2] = fmaf(s.q[2], s.t[2], G_A2); s.q[3] = fmaf(s.q[3], s.t[3], G_A2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s.q[r] = fmaf(s.q[r], s.t[r], G_A1);
+      break;
+    case 7:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s.q[r] *= s.t[r];
+      s.q[0] = fmaf(-s.q[0], s.e[0], G_HS); s.q[1] = fmaf(-s.q[1], s.e[1], G_HS);   // HS - Q
+      break;
+    case 8:
+      s.q[2] = fmaf(-s.q[2], s.e[2], G_HS); s.q[3] = fmaf(-s.q[3], s.e[3], G_HS);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s.q[r] *= __builtin_fabsf(s.v[r]);
+      break;
+    case 9:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s.v[r] = fmaf(s.v[r], G_HS, s.q[r]);
+      break;
+    case 10:   // fp16 hi and the fp32 remainder (kept in e / t for the last slot)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const sdy_f16x2 h2 = __builtin_convertvector(sdy_f32x2{s.v[r], s.v[r + 1]}, sdy_f16x2);
+        s.e[r >> 1] = __builtin_bit_cast(float, h2);
+        s.t[r] = s.v[r] - (float)h2[0]; s.t[r + 1] = s.v[r + 1] - (float)h2[1];
+      }
+      break;
+    default: break;
+  }
+}
+
+template <int KSP, int NPART, int MO>
+__global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
+  using Cfg = PairCfg<KSP, NPART, MO>;
+  constexpr int XROW = Cfg::XROW, NI = Cfg::NI, NF1 = Cfg::NF1, NF2 = Cfg::NF2, N = Cfg::N, NPAD = Cfg::NPAD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
+  _Float16* Xs_lo = Xs_hi + PTN * XROW;
+  _Float16* Hs = reinterpret_cast<_Float16*>(smem + Cfg::XS_BYTES);   // [chunk][hi | lo][px][PHC]
+  float* Cb1 = reinterpret_cast<float*>(smem + Cfg::XS_BYTES + Cfg::HS_BYTES);
+  float* Os = MO == 8 ? reinterpret_cast<float*>(Hs) : reinterpret_cast<float*>(smem);   // output tile [rows][64 px]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int h = lane >> 5, l31 = lane & 31;
+  const int tpi = (p.HW + PTN - 1) / PTN;
+  const int ntiles = tpi * p.B;
+  const int t_per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;   // contiguous tile range per workgroup
+  const int t_begin = (int)blockIdx.x * t_per;
+  const int t_end = (t_begin + t_per < ntiles) ? t_begin + t_per : ntiles;
+
+  // ---- weight ring
+  f16x8 r_hi[PRING], r_lo[PRING];
+  auto wbase_of = [&](int ln) { return (wptr_t)(p.w + (size_t)wave * (NPAD + PRING) * PGROUP + ln); };
+  wptr_t wp = wbase_of(lane);
+#pragma unroll
+  for (int s = 0; s < PRING; ++s) {
+    r_hi[s] = wp[s * PGROUP];
+    r_lo[s] = wp[s * PGROUP + 64];
+  }
+  wp += PRING * PGROUP;   // wp[i * PGROUP] = group i of the 16-block AFTER the one being consumed
+  // behind the last MFMA of position g: its slot takes the group 16 positions on (a hole of the numbering is not loaded)
+  auto refill = [&](int g, int which) {   // which: 0 = the lo fragment, 1 = the hi fragment (after lo), 2 = both
+    if ((g + PRING) % NPAD < N) {
+      if (which != 1) r_lo[g & 15] = wp[(g & 15) * PGROUP + 64];
+      if (which != 0) r_hi[g & 15] = wp[(g & 15) * PGROUP];
+    }
+    if ((g & 15) == 15 && which != 0) wp += PRING * PGROUP;
+  };
+
+  // ---- x staging: thread = (pixel quad q0, channel octets o0 + 16 i)
+  int q0 = tid & 15, o0 = tid >> 4;
+  f32x4 xr[NI][8];
+  // One 16-byte load of the staging role (idx = 8 i + e: octet o0 + 16 i, channel e of it), branch-free so that the
+  // compiler's vmcnt bookkeeping of the weight ring stays exact (a predicated load makes every later ring wait ~16 loads too
+  // strict): channels past Cin (zero weights; zeroed at the conversion) and the idle lanes of the last octet round read the
+  // last real channel.  Issued as ONE burst where nothing that is needed soon queues up behind it (vmcnt retires in order):
+  // spread one behind an MFMA each, every ring refill issued after an x load waits for HBM instead of L2 (measured: the
+  // decoder's fc1 4.6k -> 8.9k cycles).
+  auto load_x = [&](int t, int part) {
+    const int tu = __builtin_amdgcn_readfirstlane(t);   // (workgroup-uniform; the base below must sit in SGPRs)
+    const int zz = tu / tpi, nn = (tu - zz * tpi) * PTN;
+    const bool ok = nn + 4 * q0 < p.HW;
+    const float* xz = p.x + (long)zz * p.x_bs;
+    const unsigned pxo = (unsigned)(ok ? nn + 4 * q0 : 0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int ch = 16 * KSP * part + 8 * (o0 + 16 * i) + e;
+        ch = ch < p.Cin ? ch : p.Cin - 1;
+        xr[i][e] = sdy_ld16s(xz, ((unsigned)ch * (unsigned)p.HW + pxo) * 4u);
+      }
+  };
+  auto split_x_impl = [&](int part, int n0, bool full, auto plain_t) {
+    constexpr bool plain = decltype(plain_t)::value;   // a full tile of real channels: no select per value
+    float amax = 0.0f;
+    const bool ok = full || (n0 + 4 * q0 < p.HW);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int o = o0 + 16 * i;
+      if (o < 2 * KSP) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          const int px = 4 * q0 + pp;
+          sdy_f16x8 vh, vl;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = (plain || (ok && 16 * KSP * part + 8 * o + e < p.Cin)) ? xr[i][e][pp] * PSX : 0.0f;
+          sdy_split8(v, vh, vl, amax);
+          *reinterpret_cast<sdy_f16x8*>(Xs_hi + px * XROW + 8 * o) = vh;
+          *reinterpret_cast<sdy_f16x8*>(Xs_lo + px * XROW + 8 * o) = vl;
+        }
+      }
+    }
+    sdy_flag_range(p.flags, amax);
+  };
+  auto split_x = [&](int part, int n0, bool full) {
+    if (full && 16 * KSP * (part + 1) <= p.Cin) split_x_impl(part, n0, full, std::true_type{});   // (workgroup-uniform)
+    else split_x_impl(part, n0, full, std::false_type{});
+  };
+
+  Cb1[tid] = p.b1 ? p.b1[tid] : 0.0f;
+  if (t_begin < t_end) load_x(t_begin, 0);
+  double psum[MO == 8 ? 16 : 1], psq[MO == 8 ? 16 : 1];
+#pragma unroll
+  for (int i = 0; i < (MO == 8 ? 16 : 1); ++i) { psum[i] = 0.0; psq[i] = 0.0; }
+  __syncthreads();
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    asm volatile("" : "+v"(l31), "+v"(h), "+v"(q0), "+v"(o0));   // (lane indices laundered per tile: see mlp_h3.hip)
+    const int z = tile / tpi;
+    const int n0 = (tile - z * tpi) * PTN;
+    const bool full = n0 + PTN <= p.HW;
+    const int tile_it = tile - t_begin;
+    auto stamp = [&](int i) {
+      if (p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= 2 && tile_it < 6)
+        p.stamps[(tile_it - 2) * 16 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
+    f32x16 acc[2][2];     // [chunk][pixel tile]: hidden rows 128 c + 32 wave .. +32
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.0f;
+
+    // ---- chain: bias + GELU + split of the accumulators -> hidden chunk in LDS, 8 pieces (pixel tile j, row group g4) of
+    //      12 slots each
+    auto chain_store = [&](const Piece& s, int c, int j, int g4) {
+      _Float16* Hh = Hs + c * (2 * PTN * PHC);
+      _Float16* Hl = Hh + PTN * PHC;
+      f16x4 vh, vl;
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const sdy_f16x2 h2 = __builtin_bit_cast(sdy_f16x2, s.e[r >> 1]);
+        const sdy_f16x2 l2 = __builtin_convertvector(sdy_f32x2{s.t[r], s.t[r + 1]}, sdy_f16x2);
+        vh[r] = h2[0]; vh[r + 1] = h2[1];
+        vl[r] = l2[0]; vl[r + 1] = l2[1];
+      }
+      const int off = hs_off(32 * j + l31, 4 * wave + g4) + 4 * h;   // local k = 32 wave + 8 g4 + 4 h .. +3
+      *reinterpret_cast<f16x4*>(Hh + off) = vh;
+      *reinterpret_cast<f16x4*>(Hl + off) = vl;
+    };
+    auto chain_slot = [&](Piece& s, int st, int c, int j, int g4) {
+      if (st == 0) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(Cb1 + PHC * c + 32 * wave + 4 * h + 8 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.v[r] = fmaf(acc[c][j][4 * g4 + r], p.s1, b4[r]);
+      } else if (st < 11) {
+        gelu_slot(s, st);
+      } else {
+        chain_store(s, c, j, g4);
+      }
+    };
+    auto chain_alone = [&](int c, int first_piece) {
+#pragma unroll
+      for (int pc = first_piece; pc < 8; ++pc) {
+        Piece s;
+#pragma unroll
+        for (int st = 0; st < 12; ++st) chain_slot(s, st, c, pc & 1, pc >> 1);
+      }
+    };
+
+    // ---- fc1 over the parts of the input.  Every part but the last: k-step major, both chunks behind one set of fragment
+    //      reads.  The last part: chunk major, and the first NPI pieces of chain(0) ride in the slots beside chunk 1's MFMAs.
+    constexpr int NPI = !kChainInFc1 ? 0 : (KSP / 2 < 8 ? KSP / 2 : 8);
+#pragma unroll
+    for (int part = 0; part < NPART; ++part) {
+      if (part > 0) __syncthreads();          // every wave is done reading the previous part
+      split_x(part, n0, full);
+      if (part + 1 < NPART) load_x(tile, part + 1);   // the x registers are free: they take the next part
+      __syncthreads();
+      stamp(1 + 2 * part);
+      f16x8 bh[2][2], bl[2][2];
+      auto ldb1 = [&](int set, int ks, int what) {   // (hi j0, hi j1, lo j0, lo j1)
+        const int j = what & 1;
+        const int off = (32 * j + l31) * XROW + 8 * (2 * ks + h);
+        if (what < 2) bh[set][j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
+        else bl[set][j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
+      };
+#pragma unroll
+      for (int what = 0; what < 4; ++what) ldb1(0, 0, what);
+      if (part + 1 < NPART || !kChainInFc1) {
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) {
+          const int cur = ks & 1;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int g = 2 * (part * KSP + ks) + c;
+            const f16x8 a_lo = r_lo[g & 15], a_hi = r_hi[g & 15];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              const int j = k & 1;
+              if (SDY_H3_PASSES == 3 || k >= 4)
+                acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? a_lo : a_hi, (k >= 2 && k < 4) ? bl[cur][j] : bh[cur][j],
+                                                                   acc[c][j], 0, 0, 0);
+              // one memory instruction behind each MFMA (mlp_h3.hip, SDY_MLP_PINNED)
+              if (c == 0 && k < 4) { if (ks + 1 < KSP) ldb1(cur ^ 1, ks + 1, k); }
+              else if (k == 4) refill(g, 0);
+              else if (k == 5) refill(g, 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      } else {
+        Piece ps;
+        sdy_static_for<0, 2 * KSP>([&](auto i_c) {
+          constexpr int i = decltype(i_c)::value;
+          constexpr int c = i / KSP, ks = i % KSP, cur = i & 1;
+          const int g = 2 * part * KSP + i;
+          const f16x8 a_lo = r_lo[g & 15], a_hi = r_hi[g & 15];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const int j = k & 1;
+            if (SDY_H3_PASSES == 3 || k >= 4)
+              acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? a_lo : a_hi, (k >= 2 && k < 4) ? bl[cur][j] : bh[cur][j],
+                                                                 acc[c][j], 0, 0, 0);
+            if (k < 4) { if (i + 1 < 2 * KSP) ldb1(cur ^ 1, (ks + 1) % KSP, k); }
+            else if (k == 4) refill(g, 0);
+            else refill(g, 1);
+            if (c == 1 && 6 * ks + k < 12 * NPI) {
+              const int pc = (6 * ks + k) / 12;
+              chain_slot(ps, (6 * ks + k) % 12, 0, pc & 1, pc >> 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+      }
+    }
+    stamp(4);
+    chain_alone(0, NPI);
+    if (MO != 8) chain_alone(1, 0);
+    stamp(5);
+    __syncthreads();
+    stamp(6);
+
+    // ---- fc2
+    const int e_col = n0 + 4 * (tid & 15);
+    const bool e_ok = full || e_col < p.HW;
+    const unsigned e_ro = (unsigned)((tid >> 4) * p.HW + (e_ok ? e_col : 0)) * 4u;
+    f32x16 oacc[MO == 8 ? 2 : 1][MO == 8 ? 2 : 1];
+#pragma unroll
+    for (int mi = 0; mi < (MO == 8 ? 2 : 1); ++mi)
+#pragma unroll
+      for (int j = 0; j < (MO == 8 ? 2 : 1); ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[mi][j][r] = 0.0f;
+    f32x4 rres[MO == 8 ? 16 : 1];
+
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const _Float16* Hh = Hs + c * (2 * PTN * PHC);
+      const _Float16* Hl = Hh + PTN * PHC;
+      if (c == 1) {
+        stamp(7);
+        if (MO == 8) __syncthreads();          // chain(1) wrote chunk 1 beside fc2(0)
+        const int nt = tile + 1;
+        load_x(nt < t_end ? nt : tile, 0);     // next tile's pixels; past the end a harmless re-read keeps it branch-free
+        stamp(11);
+      }
+      if constexpr (MO == 8) {
+        f16x8 bh[2][2], bl[2][2];
+        auto ldb1 = [&](int set, int t, int what) {
+          const int j = what & 1;
+          const int off = hs_off(32 * j + l31, 2 * t + h);
+          if (what < 2) bh[set][j] = *reinterpret_cast<const f16x8*>(Hh + off);
+          else bl[set][j] = *reinterpret_cast<const f16x8*>(Hl + off);
+        };
+#pragma unroll
+        for (int what = 0; what < 4; ++what) ldb1(0, 0, what);
+#pragma unroll
+        for (int t = 0; t < PKSC; ++t) {
+          const int cur = t & 1;
+          __builtin_amdgcn_sched_barrier(0);
+          Piece ps;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const int g = NF1 + NF2 * c + 2 * t + mi;
+            const f16x8 a_lo = r_lo[g & 15], a_hi = r_hi[g & 15];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              const int j = k & 1;
+              if (SDY_H3_PASSES == 3 || k >= 4)
+                oacc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? a_lo : a_hi, (k >= 2 && k < 4) ? bl[cur][j] : bh[cur][j],
+                                                                    oacc[mi][j], 0, 0, 0);
+              if (mi == 0 && k < 4 && t + 1 < PKSC) ldb1(cur ^ 1, t + 1, k);
+              if (c == 0) chain_slot(ps, 6 * mi + k, 1, t & 1, t >> 1);   // chain(1): piece t, one slot per MFMA
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            refill(g, 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
+        const int mi = wave >> 1, j = wave & 1;   // this wave's output tile
+        (void)mi;
+        f16x8 bh[2], bl[2];
+        auto ldb1 = [&](int set, int t, int what) {
+          const int off = hs_off(32 * j + l31, 2 * t + h);
+          if (what == 0) bh[set] = *reinterpret_cast<const f16x8*>(Hh + off);
+          else bl[set] = *reinterpret_cast<const f16x8*>(Hl + off);
+        };
+        ldb1(0, 0, 0); ldb1(0, 0, 1);
+#pragma unroll
+        for (int t = 0; t < PKSC; ++t) {
+          const int cur = t & 1;
+          const int g = NF1 + NF2 * c + t;
+          const f16x8 a_lo = r_lo[g & 15], a_hi = r_hi[g & 15];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            if (SDY_H3_PASSES == 3 || k == 2)
+              oacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k == 0 ? a_lo : a_hi, k == 1 ? bl[cur] : bh[cur], oacc[0][0], 0, 0, 0);
+            if (k < 2) { if (t + 1 < PKSC) ldb1(cur ^ 1, t + 1, k); }
+            else refill(g, 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+    stamp(12);
+    // the holes of the numbering: their slots take the next tile's first groups
+#pragma unroll
+    for (int g = N; g < NPAD; ++g) refill(g, 2);
+    {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      wp = wbase_of(ln) + PRING * PGROUP;   // the refills above fetched block 0 of the stream's tail = the next tile's
+    }
+    asm volatile("" : "+v"(wp));
+    stamp(8);
+
+    // ---- epilogue: accumulators -> LDS [rows][64 px] -> addend + 16-byte row stores (+ statistics)
+    if constexpr (MO == 8) {
+      if (p.add) {
+        const float* az = p.add + (long)z * p.add_bs;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rres[i] = sdy_ld16s(az + (long)(16 * i) * p.HW, e_ro);
+      }
+      __syncthreads();   // every wave is done reading the hidden chunks: their storage takes the output tile
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row0 = 64 * wave + 32 * mi + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            Os[(row0 + (r & 3) + 8 * (r >> 2)) * PTN + 32 * j + l31] = oacc[mi][j][r] * p.s2;
+      }
+      __syncthreads();
+      stamp(9);
+      if (e_ok) {
+        float* oz = p.out + (long)z * p.out_bs;
+        const float* os = Os + (tid >> 4) * PTN + 4 * (tid & 15);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(os + 16 * i * PTN);
+          if (p.add) v += rres[i];
+          sdy_st16s(oz + (long)(16 * i) * p.HW, e_ro, v);
+          if (p.stats) {
+            psum[i] += (double)((v.x + v.y) + (v.z + v.w));
+            psq[i] += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+          }
+        }
+      }
+      if (p.stats) {
+        const int nt = tile + 1;
+        if (nt >= t_end || nt / tpi != z) {   // workgroup-uniform: last tile here of image z
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            double s1 = psum[i], s2 = psq[i];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+              s1 += __shfl_xor(s1, m, 64);
+              s2 += __shfl_xor(s2, m, 64);
+            }
+            if ((tid & 15) == 0) {
+              double* st = p.stats + ((long)z * PH + (tid >> 4) + 16 * i) * 2;
+              __hip_atomic_fetch_add(st, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_fetch_add(st + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            psum[i] = 0.0; psq[i] = 0.0;
+          }
+        }
+      }
+    } else {
+      {
+        const int row0 = 32 * (wave >> 1) + 4 * h, px = 32 * (wave & 1) + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Os[(row0 + (r & 3) + 8 * (r >> 2)) * PTN + px] = oacc[0][0][r] * p.s2;
+      }
+      __syncthreads();
+      stamp(9);
+      if (e_ok) {
+        float* oz = p.out + (long)z * p.out_bs;
+        const float* az = p.add ? p.add + (long)z * p.add_bs : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (tid >> 4) + 16 * i;
+          if (row < p.Cout) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Os + row * PTN + 4 * (tid & 15));
+            if (az) v += sdy_ld16s(az + (long)(16 * i) * p.HW, e_ro);
+            sdy_st16s(oz + (long)(16 * i) * p.HW, e_ro, v);
+          }
+        }
+      }
+    }
+    stamp(10);
+    __syncthreads();   // the output tile's storage (hidden chunks / x tile) is free for the next tile
+  }
+}
+
+float pick_scale(const float* w, size_t n) {   // power of two that puts max|w| in [2^12, 2^13)
+  float mx = 0.f;
+  for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+  if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+  int e;
+  std::frexp(mx, &e);
+  return std::ldexp(1.0f, 13 - e);
+}
+
+// (hi, lo) A-fragment pair of rows 32 mt .. +32, columns 16 ks .. +16 of the row-major [rows][K] matrix w, zero outside it
+void put_group(_Float16* dst, const float* w, int rows, int K, int mt, int ks, float s) {
+  for (int ln = 0; ln < 64; ++ln)
+    for (int e = 0; e < 8; ++e) {
+      const int r = 32 * mt + (ln & 31), k = 16 * ks + 8 * (ln >> 5) + e;
+      const float v = (r < rows && k < K) ? w[(size_t)r * K + k] * s : 0.0f;
+      const _Float16 hv = (_Float16)v;
+      dst[ln * 8 + e] = hv;
+      dst[64 * 8 + ln * 8 + e] = (_Float16)(v - (float)hv);
+    }
+}
+
+struct Shape { int ksp, npart, mo; };
+bool pick_shape(int Cin, int hidden, int Cout, Shape* s) {
+  if (hidden != PH || Cin < 1 || Cout < 1) return false;
+  if (Cout == 256) {
+    if (Cin <= 80) { *s = {5, 1, 8}; return true; }
+    if (Cin <= 144) { *s = {9, 1, 8}; return true; }
+    return false;
+  }
+  if (Cout <= 64) {
+    if (Cin <= 352) { *s = {11, 2, 2}; return true; }
+    if (Cin <= 416) { *s = {13, 2, 2}; return true; }
+  }
+  return false;
+}
+
+template <int KSP, int NPART, int MO>
+size_t pack_bytes() { return (size_t)4 * (PairCfg<KSP, NPART, MO>::NPAD + PRING) * PGROUP * sizeof(f16x8); }
+
+template <int KSP, int NPART, int MO>
+void pack(const float* w1, const float* w2, int Cin, int Cout, float s1, float s2, std::vector<_Float16>& buf) {
+  using Cfg = PairCfg<KSP, NPART, MO>;
+  const size_t gh = (size_t)PGROUP * 8;   // halfs per group
+  buf.assign((size_t)4 * (Cfg::NPAD + PRING) * gh, (_Float16)0.0f);
+  for (int w = 0; w < 4; ++w) {
+    _Float16* base = buf.data() + (size_t)w * (Cfg::NPAD + PRING) * gh;
+    _Float16* d = base;
+    const int n_major = kChainInFc1 ? (NPART - 1) * KSP : NPART * KSP;
+    for (int ks = 0; ks < n_major; ++ks)             // every part but the last: k-step major
+      for (int c = 0; c < 2; ++c, d += gh) put_group(d, w1, PH, Cin, 4 * c + w, ks, s1);   // hidden rows 128 c + 32 w
+    for (int c = 0; c < 2; ++c)                      // the last part: chunk major
+      for (int ks = n_major; ks < NPART * KSP; ++ks, d += gh) put_group(d, w1, PH, Cin, 4 * c + w, ks, s1);
+    for (int c = 0; c < 2; ++c)
+      for (int t = 0; t < PKSC; ++t) {
+        if (MO == 8) {
+          for (int mi = 0; mi < 2; ++mi, d += gh) put_group(d, w2, Cout, PH, 2 * w + mi, PKSC * c + t, s2);
+        } else {
+          put_group(d, w2, Cout, PH, w >> 1, PKSC * c + t, s2);
+          d += gh;
+        }
+      }
+    // (holes stay zero) + the first 16 groups again: the ring's refills run one 16-block ahead across the tile boundary
+    std::copy(base, base + PRING * gh, base + (size_t)Cfg::NPAD * gh);
+  }
+}
+
+template <int KSP, int NPART, int MO>
+int launch(const PairParams& p, hipStream_t stream) {
+  using Cfg = PairCfg<KSP, NPART, MO>;
+  int n_cu = 0;
+  SDY_TRY(sdy_cu_count(&n_cu));
+  const long ntiles = (long)((p.HW + PTN - 1) / PTN) * p.B;
+  dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
+  static SdyOncePerDevice once;
+  std::atomic<bool>* attr_done = nullptr;
+  SDY_TRY(once.slot(&attr_done));
+  if (!*attr_done) {
+    SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_h3_kernel<KSP, NPART, MO>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+    *attr_done = true;
+  }
+  hipLaunchKernelGGL((pair_h3_kernel<KSP, NPART, MO>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
+  return sdy_launch_status();
+}
+
+#define PAIR_DISPATCH(s, CALL)                                      \
+  do {                                                              \
+    if ((s).ksp == 5) { CALL(5, 1, 8); }                            \
+    else if ((s).ksp == 9) { CALL(9, 1, 8); }                       \
+    else if ((s).ksp == 11) { CALL(11, 2, 2); }                     \
+    else { CALL(13, 2, 2); }                                        \
+  } while (0)
+
+}  // namespace
+
+static unsigned long long* g_pair_stamps = nullptr;
+// timing experiments: 4 tiles x 16 phase stamps of wave 0 of workgroup 3 (valid after a launch with SDY_PAIR_STAMPS set)
+extern "C" int sdy_pair_h3_debug_stamps(unsigned long long* host64) {
+  if (!g_pair_stamps || !host64) return SDY_ERR_STATE;
+  SDY_HIP_TRY(hipDeviceSynchronize());
+  SDY_HIP_TRY(hipMemcpy(host64, g_pair_stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return SDY_OK;
+}
+
+extern "C" int sdy_pair_h3_supported(int Cin, int hidden, int Cout) {
+  Shape s;
+  return pick_shape(Cin, hidden, Cout, &s) ? 1 : 0;
+}
+
+extern "C" size_t sdy_pair_h3_pack_bytes(int Cin, int hidden, int Cout) {
+  Shape s;
+  if (!pick_shape(Cin, hidden, Cout, &s)) return 0;
+#define PB(K, P, M) return pack_bytes<K, P, M>()
+  PAIR_DISPATCH(s, PB);
+#undef PB
+  return 0;
+}
+
+// w1_host: (hidden, Cin) row-major;  w2_host: (Cout, hidden) row-major
+extern "C" int sdy_pair_h3_pack(const float* w1_host, const float* w2_host, int Cin, int hidden, int Cout, void* packed_dev,
+                                float* scale1, float* scale2) {
+  if (!w1_host || !w2_host || !packed_dev || !scale1 || !scale2) return SDY_ERR_ARG;
+  Shape s;
+  if (!pick_shape(Cin, hidden, Cout, &s)) return SDY_ERR_UNSUPPORTED;
+  const float s1 = pick_scale(w1_host, (size_t)hidden * Cin), s2 = pick_scale(w2_host, (size_t)Cout * hidden);
+  std::vector<_Float16> buf;
+#define PK(K, P, M) pack<K, P, M>(w1_host, w2_host, Cin, Cout, s1, s2, buf)
+  PAIR_DISPATCH(s, PK);
+#undef PK
+  SDY_HIP_TRY(hipMemcpy(packed_dev, buf.data(), buf.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  *scale1 = s1;
+  *scale2 = s2;
+  return SDY_OK;
+}
+
+extern "C" int sdy_pair_h3(const sdy_pair_args* a, void* stream) {
+  if (!a || !a->x || !a->w || !a->out) return SDY_ERR_ARG;
+  if (a->B <= 0 || a->HW <= 0) return SDY_ERR_ARG;
+  Shape s;
+  if (!pick_shape(a->Cin, a->hidden, a->Cout, &s)) return SDY_ERR_UNSUPPORTED;
+  if ((a->HW & 3) || (a->x_bstride & 3) || (a->out_bstride & 3) || (a->add && (a->add_bstride & 3))) return SDY_ERR_ALIGN;
+  if ((long)a->HW * (a->Cin > 256 ? a->Cin : 256) * 4 >= (1L << 32)) return SDY_ERR_UNSUPPORTED;   // 32-bit lane offsets
+  if (a->stats && a->Cout != 256) return SDY_ERR_UNSUPPORTED;
+  if (a->B > 65535) return SDY_ERR_UNSUPPORTED;
+  PairParams p{};
+  p.x = a->x; p.x_bs = a->x_bstride; p.Cin = a->Cin;
+  p.w = reinterpret_cast<const f16x8*>(a->w);
+  p.b1 = a->b1;
+  p.out = a->out; p.out_bs = a->out_bstride; p.Cout = a->Cout;
+  p.add = a->add; p.add_bs = a->add_bstride;
+  p.HW = a->HW; p.B = a->B;
+  p.s1 = 1.0f / (a->w1_scale * PSX);
+  p.s2 = 1.0f / (a->w2_scale * PSX);
+  p.stats = a->stats;
+  SDY_TRY(sdy_flags_ptr(&p.flags));
+  if (std::getenv("SDY_PAIR_STAMPS")) {
+    if (!g_pair_stamps) SDY_HIP_TRY(hipMalloc(&g_pair_stamps, 64 * sizeof(unsigned long long)));
+    p.stamps = g_pair_stamps;
+  }
+#define LN(K, P, M) return launch<K, P, M>(p, (hipStream_t)stream)
+  PAIR_DISPATCH(s, LN);
+#undef LN
+  return SDY_ERR_UNSUPPORTED;
+}

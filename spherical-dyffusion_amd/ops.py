@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import SdyConvArgs, SdyMlpArgs, check, current_stream, lib, ptr
+from ._lib import SdyConvArgs, SdyMlpArgs, SdyPairArgs, check, current_stream, lib, ptr
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -239,6 +239,57 @@ def mlp_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Ten
         a.stats = ptr(stats)
     with torch.cuda.device(x.device):
         check(lib.sdy_mlp_h3(C.byref(a), current_stream()), "sdy_mlp_h3")
+    return out
+
+
+def pack_pair_h3(w1: torch.Tensor, w2: torch.Tensor, device):
+    """(hidden, Cin) and (Cout, hidden) weights -> (per-wave fragment stream, scale1, scale2) for `conv_pair`."""
+    a = w1.detach().to("cpu", torch.float32).reshape(w1.shape[0], -1).contiguous()
+    b = w2.detach().to("cpu", torch.float32).reshape(w2.shape[0], -1).contiguous()
+    hidden, Cin = a.shape
+    Cout = b.shape[0]
+    assert b.shape == (Cout, hidden)
+    if not lib.sdy_pair_h3_supported(Cin, hidden, Cout):
+        raise NotImplementedError(f"fused conv pair supports hidden=256 with (Cin<=144, Cout=256) or (Cin<=416, Cout<=64); "
+                                  f"got {Cin}->{hidden}->{Cout}; use conv1x1 twice")
+    buf = torch.empty(lib.sdy_pair_h3_pack_bytes(Cin, hidden, Cout), dtype=torch.uint8, device=device)
+    s1, s2 = C.c_float(), C.c_float()
+    with torch.cuda.device(device):
+        check(lib.sdy_pair_h3_pack(ptr(a), ptr(b), Cin, hidden, Cout, ptr(buf), C.byref(s1), C.byref(s2)), "sdy_pair_h3_pack")
+    return (buf, s1.value, s2.value)
+
+
+def conv_pair(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, *,
+              add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, prepared=None,
+              stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv(w2) . GELU . conv(w1, b1) + add in one launch (include/sdy_amd.h, sdy_pair_h3): the encoder
+    (`src/models/sfno/sfnonet.py:609-618`, add = position embedding of shape (1, Cout, H, W)) and the decoder (`:734-744`)."""
+    x = _f32c(x)
+    B, Cin, H, W = x.shape
+    if prepared is None:
+        prepared = pack_pair_h3(w1, w2, x.device)
+    hidden, Cout = w1.shape[0], w2.shape[0]
+    if out is None:
+        out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    a = SdyPairArgs()
+    a.x, a.x_bstride = ptr(x), Cin * H * W
+    a.w, a.w1_scale, a.w2_scale = ptr(prepared[0]), prepared[1], prepared[2]
+    keep = [x, out, prepared]
+    if b1 is not None:
+        bb1 = _aux(b1, x.device)
+        a.b1 = ptr(bb1)
+        keep.append(bb1)
+    a.out, a.out_bstride = ptr(out), Cout * H * W
+    if add is not None:
+        ad = _aux(add, x.device)
+        a.add, a.add_bstride = ptr(ad), (0 if ad.shape[0] == 1 and B > 1 else Cout * H * W)
+        keep.append(ad)
+    a.B, a.Cin, a.hidden, a.Cout, a.HW = B, Cin, hidden, Cout, H * W
+    if stats is not None:
+        assert stats.dtype == torch.float64 and stats.is_cuda and stats.is_contiguous() and stats.numel() == B * Cout * 2
+        a.stats = ptr(stats)
+    with torch.cuda.device(x.device):
+        check(lib.sdy_pair_h3(C.byref(a), current_stream()), "sdy_pair_h3")
     return out
 
 

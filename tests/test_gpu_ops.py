@@ -323,6 +323,72 @@ def test_mlp_fused_matches_fp64_and_unfused(sdy, B, H, W, drop):
     assert rel_l2(got, ref) < TOL_OP
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 65, 256, 8, 40), (3, 36, 256, 87, 96), (2, 130, 256, 45, 64), (1, 144, 256, 6, 36),
+                                            (2, 321, 63, 8, 40), (3, 292, 34, 87, 96), (2, 386, 63, 45, 64), (1, 416, 64, 6, 36),
+                                            (2, 17, 5, 6, 36)])
+def test_conv_pair_matches_fp64_and_two_launches(sdy, B, Cin, Cout, H, W):
+    """sdy_pair_h3 (encoder: Cin -> 256 -> 256 + position embedding + InstanceNorm statistics; decoder: 256 + Cin -> 256 ->
+    Cout) == conv -> GELU -> conv in fp64, and the two-launch path it replaces; ragged last tiles, several tiles per
+    persistent workgroup (87 x 96), inputs in one and in two parts, every shape class of sdy_pair_h3_supported."""
+    g = _gen(77)
+    F = torch.nn.functional
+    Hd = 256
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.3 + 0.2
+    w1 = torch.randn(Hd, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b1 = 0.1 * torch.randn(Hd, generator=g)
+    w2 = torch.randn(Cout, Hd, 1, 1, generator=g) / np.sqrt(Hd)
+    pos = 0.5 * torch.randn(1, Cout, H, W, generator=g)
+    hid = F.gelu(F.conv2d(x.double(), w1.double(), b1.double()))
+    ref = F.conv2d(hid, w2.double())
+    got = sdy.ops.conv_pair(x.cuda(), w1, b1, w2)
+    assert got.shape == (B, Cout, H, W)
+    err = rel_l2(got, ref)
+    assert err < TOL_OP, f"fused pair vs fp64: {err:.3e}"
+    h = sdy.ops.conv1x1(x.cuda(), w1, b1, gelu=True, h3=True)
+    two = sdy.ops.conv1x1(h, w2, None, h3=True)
+    assert rel_l2(got, two) < 5e-6
+    # addend broadcast over the batch (position embedding) and per image; no bias
+    got = sdy.ops.conv_pair(x.cuda(), w1, None, w2, add=pos.cuda())
+    ref_nb = F.conv2d(F.gelu(F.conv2d(x.double(), w1.double())), w2.double())
+    assert rel_l2(got, ref_nb + pos.double()) < TOL_OP
+    res = torch.randn(B, Cout, H, W, generator=g)
+    got = sdy.ops.conv_pair(x.cuda(), w1, b1, w2, add=res.cuda())
+    assert rel_l2(got, ref + res.double()) < TOL_OP
+    # a view of a wider buffer as input (the decoder reads [block output | inputs] in place) and as output
+    wide = torch.randn(B, Cin + 3, H, W, generator=g).cuda()
+    wide[:, :Cin] = x.cuda()
+    out_wide = torch.zeros(B, Cout + 2, H, W, device="cuda")
+    a = sdy._lib.SdyPairArgs()
+    prep = sdy.ops.pack_pair_h3(w1, w2, "cuda")
+    bb = b1.cuda()
+    a.x, a.x_bstride = wide.data_ptr(), (Cin + 3) * H * W
+    a.w, a.w1_scale, a.w2_scale = prep[0].data_ptr(), prep[1], prep[2]
+    a.b1 = bb.data_ptr()
+    a.out, a.out_bstride = out_wide.data_ptr(), (Cout + 2) * H * W
+    a.B, a.Cin, a.hidden, a.Cout, a.HW = B, Cin, Hd, Cout, H * W
+    import ctypes
+    assert sdy.lib.sdy_pair_h3(ctypes.byref(a), sdy._lib.current_stream()) == 0
+    assert rel_l2(out_wide[:, :Cout], ref) < TOL_OP and float(out_wide[:, Cout:].abs().max()) == 0.0
+    if Cout == 256:   # statistics of the stored output from the epilogue
+        st = torch.zeros(B, Cout, 2, dtype=torch.float64, device="cuda")
+        got_s = sdy.ops.conv_pair(x.cuda(), w1, b1, w2, add=pos.cuda(), stats=st)
+        gd = got_s.double().cpu()
+        want = torch.stack([gd.sum((2, 3)), (gd * gd).sum((2, 3))], -1)
+        assert torch.allclose(st.cpu(), want, rtol=1e-5, atol=1e-6 * H * W)
+    else:
+        with pytest.raises(sdy.SdyError):
+            sdy.ops.conv_pair(x.cuda(), w1, b1, w2, stats=torch.zeros(B, Cout, 2, dtype=torch.float64, device="cuda"))
+
+
+def test_conv_pair_rejects_other_shapes(sdy):
+    for cin, hid, cout in [(145, 256, 256), (65, 128, 256), (417, 256, 63), (65, 256, 128)]:
+        assert sdy.lib.sdy_pair_h3_supported(cin, hid, cout) == 0
+        with pytest.raises(NotImplementedError):
+            sdy.ops.pack_pair_h3(torch.zeros(hid, cin), torch.zeros(cout, hid), "cuda")
+    for cin, hid, cout in [(65, 256, 256), (144, 256, 256), (292, 256, 34), (416, 256, 64), (1, 256, 1)]:
+        assert sdy.lib.sdy_pair_h3_supported(cin, hid, cout) == 1
+
+
 def test_mlp_fused_rejects_other_shapes(sdy):
     x = torch.zeros(1, 64, 8, 16).cuda()
     with pytest.raises(NotImplementedError):
