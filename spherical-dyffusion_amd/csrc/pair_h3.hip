@@ -209,6 +209,9 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
   auto split_x_impl = [&](int part, int n0, bool full, auto plain_t) {
     constexpr bool plain = decltype(plain_t)::value;   // a full tile of real channels: no select per value
     float amax = 0.0f;
+    // The decoder is the one consumer of the last block's output, which meets no InstanceNorm (whose statistics flag non-finite
+    // tensors everywhere else), and the max-based range guard ignores NaNs: here a sum of magnitudes goes NaN / inf with them.
+    float nansum = 0.0f;
     const bool ok = full || (n0 + 4 * q0 < p.HW);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -223,12 +226,17 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
           for (int e = 0; e < 8; ++e)
             v[e] = (plain || (ok && 16 * KSP * part + 8 * o + e < p.Cin)) ? xr[i][e][pp] * PSX : 0.0f;
           sdy_split8(v, vh, vl, amax);
+          if (MO != 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) nansum += __builtin_fabsf(v[e]);
+          }
           *reinterpret_cast<sdy_f16x8*>(Xs_hi + px * XROW + 8 * o) = vh;
           *reinterpret_cast<sdy_f16x8*>(Xs_lo + px * XROW + 8 * o) = vl;
         }
       }
     }
     sdy_flag_range(p.flags, amax);
+    if (MO != 8 && p.flags && !(nansum <= 3.0e38f)) atomicOr(p.flags, (unsigned)SDY_FLAG_NONFINITE);
   };
   auto split_x = [&](int part, int n0, bool full) {
     if (full && 16 * KSP * (part + 1) <= p.Cin) split_x_impl(part, n0, full, std::true_type{});   // (workgroup-uniform)

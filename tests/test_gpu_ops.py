@@ -513,3 +513,34 @@ def test_fp16_range_guard_sets_the_sticky_flag(sdy):
     got = ops.conv1x1(xs.cuda(), ws, None, h3=True)
     assert ops.status_flags(reset=True) == 0
     assert rel_l2(got, F.conv2d(xs.double(), ws.double())) < 5e-6
+
+
+def test_decoder_pair_flags_nonfinite_and_out_of_range_inputs(sdy):
+    """The decoder is the only consumer of the last block's output (no InstanceNorm in between, whose statistics flag
+    non-finite tensors everywhere else) and a max-based range guard ignores NaNs: sdy_pair_h3's decoder shapes set
+    SDY_FLAG_NONFINITE for a NaN / inf input, both pair shapes SDY_FLAG_F16_RANGE for |x| * 16 >= 65504."""
+    ops = sdy.ops
+    g = _gen(5)
+    x = torch.randn(1, 321, 8, 40, generator=g)
+    w1 = torch.randn(256, 321, generator=g) / 18.0
+    b1 = torch.zeros(256)
+    w2 = torch.randn(63, 256, generator=g) / 16.0
+    ops.status_flags(reset=True)
+    assert torch.isfinite(ops.conv_pair(x.cuda(), w1, b1, w2)).all() and ops.status_flags(reset=True) == 0
+    for bad in (float("nan"), float("inf")):
+        xb = x.clone()
+        xb[0, 300, 7, 39] = bad
+        out = ops.conv_pair(xb.cuda(), w1, b1, w2)
+        fl = ops.status_flags(reset=True)
+        assert fl & ops.FLAG_NONFINITE and not torch.isfinite(out).all()
+    xb = x.clone()
+    xb[0, 3, 0, 0] = 5.0e3
+    ops.conv_pair(xb.cuda(), w1, b1, w2)
+    assert ops.status_flags(reset=True) == ops.FLAG_F16_RANGE
+    xe = torch.randn(1, 65, 8, 40, generator=g)
+    we1, we2 = torch.randn(256, 65, generator=g) / 8.0, torch.randn(256, 256, generator=g) / 16.0
+    ops.conv_pair(xe.cuda(), we1, b1, we2)
+    assert ops.status_flags(reset=True) == 0
+    xe[0, 64, 2, 2] = -5.0e3
+    ops.conv_pair(xe.cuda(), we1, b1, we2)
+    assert ops.status_flags(reset=True) == ops.FLAG_F16_RANGE

@@ -3,7 +3,7 @@
 #   1. bench line (default run) + rocprofv3 --kernel-trace --stats of the same command
 #   2. PMC passes over one interpolator + one forecaster forward at B = 25 (tools/pmc_forward25.py), each counter group in its
 #      own pass with --kernel-trace only: FETCH_SIZE, WRITE_SIZE (HBM traffic), matrix-pipe / issue counters
-TAG=${1:-r3a}
+TAG=${1:-r3b}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 export TMPDIR=/tmp
@@ -23,7 +23,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    if any(t in r["Kernel_Name"] for t in ("mlp", "gemm", "fft", "leg_", "dh_h3", "conv_h3")):
+    if any(t in r["Kernel_Name"] for t in ("mlp", "gemm", "fft", "leg_", "dh_h3", "conv_h3", "pair_h3")):
         agg[(r["Kernel_Name"][:64], r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(agg.items()):
     print(f"{k:66s} {c:26s} avg {sum(v)/len(v):16.1f} over {len(v)} dispatches")
