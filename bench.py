@@ -51,8 +51,8 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: BF16/FP16 MFMA dense peak
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E peak (6.3 TB/s measured with a float4 copy)
 # HBM bytes per launch of the dominant kernel at B = 25 from separate rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
 # the guide's gfx950 correction); source file under profiles/
-MLP_TRAFFIC_B25 = 5.285e9      # mlp_h3_kernel<true> inside the interpolator forward: fetch 3.624 GB + write 1.661 GB
-MLP_TRAFFIC_SRC = "profiles/r3a/pmc_summary.txt"
+MLP_TRAFFIC_B25 = 5.281e9      # mlp_h3_kernel<true> inside the interpolator forward: fetch 3.620 GB + write 1.661 GB
+MLP_TRAFFIC_SRC = "profiles/r3b/pmc_summary.txt"
 POLAR_LIVE = 0.77              # share of (order, latitude) pairs the polar cut-off keeps
 NZ_PAIRS, ALL_PAIRS = 16290, 32580   # (l, m) pairs with m <= l / dense
 
@@ -152,11 +152,12 @@ def stage_work(B):
         "decoder.0 conv": (2.0 * E * HW * B * (E + (6 * cin_f + 10 * cin_i) / 16),
                            2 * act + 4.0 * HW * B * (6 * cin_f + 10 * cin_i) / 16, "hbm"),
         "decoder.2 conv": (2.0 * E * STATE_CH * HW * B, act + 4.0 * STATE_CH * HW * B, "hbm"),
-        # encoder / decoder as one launch each: the 256-channel hidden activation is neither written nor read
+        # encoder / decoder as one launch each: the 256-channel hidden activation is neither written nor read, which puts
+        # both above the three-pass machine balance (2500 / 3 TFLOP/s over 8 TB/s = 104 flop/B): 130 flop/B
         "encoder (fused pair)": (2.0 * E * HW * B * (E + (6 * cin_f + 10 * cin_i) / 16),
-                                 act + 4.0 * E * HW + 4.0 * HW * B * (6 * cin_f + 10 * cin_i) / 16, "hbm"),
+                                 act + 4.0 * E * HW + 4.0 * HW * B * (6 * cin_f + 10 * cin_i) / 16, "mfma"),
         "decoder (fused pair)": (2.0 * E * HW * B * (E + STATE_CH + (6 * cin_f + 10 * cin_i) / 16),
-                                 act + 4.0 * HW * B * (STATE_CH + (6 * cin_f + 10 * cin_i) / 16), "hbm"),
+                                 act + 4.0 * HW * B * (STATE_CH + (6 * cin_f + 10 * cin_i) / 16), "mfma"),
     }
     return w
 
