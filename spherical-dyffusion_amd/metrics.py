@@ -10,7 +10,7 @@ the ensemble mean -- in ONE pass over the ensemble on the device (`sdy_ensemble_
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Mapping, Optional, Sequence
 
 import torch
 
@@ -307,3 +307,150 @@ class MeanAggregator:
     def get_logs(self, label: str):
         """`reduced.py:252-266` puts the series into one wandb table under `<label>/series`; here: the arrays themselves."""
         return {f"{label}/series": {k: v.cpu().numpy() for k, v in self.get_series().items()}}
+
+
+# ---- the reference's composite (`src/ace_inference/core/aggregator/inference/main.py`) ----------------------------------
+class Table:
+    """The two members of `wandb.Table` the reference's log plumbing uses (`columns`, `data`, `add_data`): wandb itself is not
+    a dependency of this package."""
+
+    def __init__(self, columns: Sequence[str]):
+        self.columns = list(columns)
+        self.data: List[list] = []
+
+    def add_data(self, *row):
+        if len(row) != len(self.columns):
+            raise ValueError(f"expected {len(self.columns)} values, got {len(row)}")
+        self.data.append(list(row))
+
+
+def data_to_table(data: Mapping[str, Sequence[float]]) -> Table:
+    """`reduced.py:282-293`: 1-D series -> one table with a `forecast_step` column and the keys in sorted order."""
+    keys = sorted(data.keys())
+    table = Table(["forecast_step"] + keys)
+    for i in range(len(data[keys[0]])):
+        table.add_data(i, *[data[k][i] for k in keys])
+    return table
+
+
+def to_inference_logs(log: Mapping[str, object]) -> List[Dict[str, float]]:
+    """`main.py:189-211`: a dict holding tables and scalars -> one dict per table row (the wandb step is the forecast step),
+    columns renamed `<key without its last component>/<column>`; scalars go into the last row's dict."""
+    n_rows = max([len(v.data) for v in log.values() if isinstance(v, Table)], default=0)
+    logs: List[Dict[str, float]] = [{} for _ in range(n_rows)]
+    for key, val in log.items():
+        if isinstance(val, Table):
+            stem = key[: key.rfind("/")]
+            for i, row in enumerate(val.data):
+                for j, col in enumerate(val.columns):
+                    logs[i][f"{stem}/{col}"] = row[j]
+        else:
+            logs[-1][key] = val
+    return logs
+
+
+class OneStepMeanAggregator:
+    """Metrics of ONE forecast step averaged over the windows that contain it (`one_step/reduced.py:35-147`, the reference's
+    `mean_step_20`): `weighted_rmse`, `weighted_bias` (of the ensemble mean), `weighted_mean_gen`, for ensembles
+    `weighted_crps` and `weighted_ssr`, and the mean of the `loss` values handed to `record_batch`.  The reference's
+    `weighted_grad_mag_percent_diff` is not computed (as in `MeanAggregator`)."""
+
+    def __init__(self, area_weights: torch.Tensor, target_time: int = 1, is_ensemble: bool = False, dist=None, device=None):
+        self._area_weights = area_weights
+        self._target_time = int(target_time)
+        self.is_ensemble = is_ensemble
+        self._dist = TorchDistributed() if dist is None else dist
+        self._loss = 0.0
+        self._n_batches = 0
+        self._total: Dict[str, Dict[str, torch.Tensor]] = {}
+
+    @torch.no_grad()
+    def record_batch(self, loss, target_data, gen_data, target_data_norm, gen_data_norm, i_time_start: int = 0):
+        self._loss = self._loss + loss        # (added for every window, as the reference does: reduced.py:103)
+        t = self._target_time - i_time_start
+        any_gen = next(iter(gen_data.values()))
+        if t < 0 or t >= any_gen.shape[2 if self.is_ensemble else 1]:
+            return
+        for name, gen in gen_data.items():
+            pred = gen if self.is_ensemble else gen[None]
+            s = ensemble_series(target_data[name][:, t:t + 1], pred[:, :, t:t + 1], self._area_weights)[:, 0]    # (n_sample, 8)
+            E = pred.shape[0]
+            mse, var, crps, bias, mg = s[:, 0], s[:, 1], s[:, 2], s[:, 3], s[:, 4]
+            vals = {"weighted_rmse": mse.sqrt(), "weighted_bias": bias, "weighted_mean_gen": mg}
+            if self.is_ensemble:
+                vals["weighted_crps"] = crps
+                vals["weighted_ssr"] = var.sqrt() * ((E + 1) / E) ** 0.5 / mse.sqrt()
+            for metric, v in vals.items():
+                per_var = self._total.setdefault(metric, {})
+                per_var[name] = per_var.get(name, 0.0) + v.mean()
+        self._n_batches += 1
+
+    @torch.no_grad()
+    def get_logs(self, label: str) -> Dict[str, float]:
+        if self._n_batches == 0:
+            raise ValueError("No batches have been recorded.")
+        dev = self._area_weights.device
+        logs = {f"{label}/loss": torch.as_tensor(self._loss, dtype=torch.float64, device=dev) / self._n_batches}
+        for metric, per_var in self._total.items():
+            for name, tot in per_var.items():
+                logs[f"{label}/{metric}/{name}"] = tot.double() / self._n_batches
+        return {k: float(self._dist.reduce_mean(logs[k].reshape(1))[0]) for k in sorted(logs)}
+
+
+class InferenceAggregator:
+    """The aggregator `run_inference` is handed by the reference's entry point (`inference/inference.py:247-262`): `mean`
+    (per-step series, denormalised), `mean_norm` (normalised), `time_mean`, and `mean_step_20` when asked for, behind ONE
+    `record_batch` / `get_logs` / `get_inference_logs` (`aggregator/inference/main.py:42-168`).  Same constructor keywords;
+    `sigma_coordinates` and `metadata` are accepted and unused (they feed derived variables and image captions).  The
+    image products of the reference -- snapshots, videos, zonal-mean hovmollers, the time-mean maps as pictures -- are out of
+    scope (DESIGN.md section 8): `log_video` / `log_zonal_mean_images` raise, snapshots are not produced;
+    `get_time_mean_maps()` returns what `get_datasets(["time_mean"])` would hold, as device tensors."""
+
+    accepts_sample_weights = True
+
+    def __init__(self, area_weights: torch.Tensor, sigma_coordinates=None, n_timesteps: Optional[int] = None,
+                 n_ensemble_members: int = 1, record_step_20: bool = False, log_video: bool = False,
+                 enable_extended_videos: bool = False, log_zonal_mean_images: bool = False, dist=None, metadata=None,
+                 device=None):
+        if log_video or enable_extended_videos or log_zonal_mean_images:
+            raise NotImplementedError("video / zonal-mean image logging is out of scope of sdy_amd (DESIGN.md section 8)")
+        if n_timesteps is None:
+            raise ValueError("n_timesteps (forward steps + 1) is needed for the per-step series")
+        self._is_ensemble = n_ensemble_members > 1
+        if device is not None:
+            area_weights = area_weights.to(device)
+        kw = dict(area_weights=area_weights, dist=dist, is_ensemble=self._is_ensemble)
+        self._aggregators = {
+            "mean": MeanAggregator(target="denorm", n_timesteps=n_timesteps, **kw),
+            "mean_norm": MeanAggregator(target="norm", n_timesteps=n_timesteps, **kw),
+            "time_mean": TimeMeanAggregator(area_weights, dist=dist, is_ensemble=self._is_ensemble),
+        }
+        if record_step_20:
+            self._aggregators["mean_step_20"] = OneStepMeanAggregator(target_time=20, **kw)
+
+    @torch.no_grad()
+    def record_batch(self, loss, target_data, gen_data, target_data_norm, gen_data_norm, i_time_start: int = 0,
+                     sample_weights: Optional[Sequence[float]] = None):
+        if len(target_data) == 0:
+            raise ValueError("No data in target_data")
+        if len(gen_data) == 0:
+            raise ValueError("No data in gen_data")
+        for agg in self._aggregators.values():
+            kw = {"sample_weights": sample_weights} if getattr(agg, "accepts_sample_weights", False) else {}
+            agg.record_batch(loss=loss, target_data=target_data, gen_data=gen_data, target_data_norm=target_data_norm,
+                             gen_data_norm=gen_data_norm, i_time_start=i_time_start, **kw)
+
+    @torch.no_grad()
+    def get_logs(self, label: str) -> Dict[str, object]:
+        logs: Dict[str, object] = {}
+        for name, agg in self._aggregators.items():
+            for key, val in agg.get_logs(label=name).items():
+                logs[key] = data_to_table(val) if isinstance(val, Mapping) else val     # a series -> the reference's table
+        return {f"{label}/{key}": val for key, val in logs.items()}
+
+    @torch.no_grad()
+    def get_inference_logs(self, label: str) -> List[Dict[str, float]]:
+        return to_inference_logs(self.get_logs(label=label))
+
+    def get_time_mean_maps(self):
+        return self._aggregators["time_mean"].time_mean_maps()

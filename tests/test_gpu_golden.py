@@ -362,6 +362,40 @@ def test_mean_aggregator_series_vs_reference():
                 assert torch.allclose(got, want, rtol=5e-5, atol=5e-6), (key, m, n, got, want)
         logs = agg.get_logs("inference")
         assert set(logs["inference/series"]) == set(series)
+        # the reference's composite (aggregator/inference/main.py): the same windows through ONE record_batch; its per-step
+        # logs carry the series above, its last step the time-mean scalars, mean_step_20-style one-step means equal the series
+        comp = sdy_amd.metrics.InferenceAggregator(w, n_timesteps=n_t, n_ensemble_members=3 if ens else 1)
+        comp._aggregators["mean_step_2"] = sdy_amd.metrics.OneStepMeanAggregator(w, target_time=2, is_ensemble=ens)
+        tm = sdy_amd.metrics.TimeMeanAggregator(w, is_ensemble=ens)
+        for i in range(3):
+            tgt = {n: torch.from_numpy(z[f"{key}::tgt{i}::{n}"]).cuda() for n in names}
+            gen = {n: torch.from_numpy(z[f"{key}::gen{i}::{n}"]).cuda() for n in names}
+            t0 = int(z[f"{key}::i_time_start{i}"])
+            comp.record_batch(0.25 * (i + 1), tgt, gen, {n: 2 * v for n, v in tgt.items()}, {n: 2 * v for n, v in gen.items()},
+                              i_time_start=t0)
+            tm.record_batch(0.0, tgt, gen, tgt, gen, i_time_start=t0)
+        steps = comp.get_inference_logs("inference")
+        assert len(steps) == n_t and all(st["inference/mean/forecast_step"] == i for i, st in enumerate(steps))
+        for m in metrics:
+            for n in names:
+                got = torch.tensor([st[f"inference/mean/{m}/{n}"] for st in steps], dtype=torch.float64)
+                assert torch.allclose(got, series[f"{m}/{n}"].cpu(), rtol=1e-12, atol=0)
+        # normalised copies were 2 x the fields: RMSE, bias, means and CRPS double, the spread-skill ratio does not move
+        n0 = names[0]
+        for st in steps:
+            assert st[f"inference/mean_norm/weighted_rmse/{n0}"] == pytest.approx(2 * st[f"inference/mean/weighted_rmse/{n0}"], rel=1e-5)
+        for k, v in tm.get_logs("time_mean").items():
+            assert steps[-1][f"inference/{k}"] == pytest.approx(v, rel=1e-12)
+            assert f"inference/{k}" not in steps[0]
+        # the window holding forecast step 2 is the only one the one-step aggregator uses: its means are the series' entry
+        # (the fixture's windows do not overlap), its loss the mean of ALL windows' losses over the recorded ones
+        one = steps[-1]
+        for m in ("weighted_rmse", "weighted_bias", "weighted_mean_gen") + (("weighted_crps", "weighted_ssr") if ens else ()):
+            for n in names:
+                assert one[f"inference/mean_step_2/{m}/{n}"] == pytest.approx(float(series[f"{m}/{n}"][2]), rel=2e-5, abs=1e-7)
+        assert one["inference/mean_step_2/loss"] == pytest.approx(0.25 + 0.5 + 0.75)
+        maps = comp.get_time_mean_maps()
+        assert set(maps["gen"]) == set(names) and maps["gen"][n0].shape == w.shape
     with pytest.raises(ValueError):
         sdy_amd.metrics.MeanAggregator(w, n_timesteps=4).get_series()
     with pytest.raises(ValueError):      # a ragged share hands flat rows: ensemble metrics need whole initial conditions

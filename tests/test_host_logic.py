@@ -396,3 +396,33 @@ def test_packaged_statistics_hold_the_reference_scalars(sdy, tmp_path):
         except SystemExit:
             return
         assert {k: v for k, v in fresh.items() if v == v} == {k: v for k, v in stds.items() if v == v}
+
+
+def test_inference_log_plumbing_follows_the_reference(sdy):
+    """`data_to_table` (`aggregator/inference/reduced.py:282-293`) and `to_inference_logs` (`main.py:189-211`): the series of
+    an aggregator become one table with a `forecast_step` column and sorted keys; tables become one dict per row with the
+    table's own name (the key's last component) dropped; scalars land in the last row's dict."""
+    m = sdy.metrics
+    t = m.data_to_table({"weighted_rmse/b": [1.0, 2.0, 3.0], "weighted_bias/a": [0.1, 0.2, 0.3]})
+    assert t.columns == ["forecast_step", "weighted_bias/a", "weighted_rmse/b"]
+    assert t.data == [[0, 0.1, 1.0], [1, 0.2, 2.0], [2, 0.3, 3.0]]
+    with pytest.raises(ValueError):
+        t.add_data(1, 2)
+    logs = m.to_inference_logs({"inference/mean/series": t, "inference/time_mean/rmse/a": 0.5})
+    assert logs == [
+        {"inference/mean/forecast_step": 0, "inference/mean/weighted_bias/a": 0.1, "inference/mean/weighted_rmse/b": 1.0},
+        {"inference/mean/forecast_step": 1, "inference/mean/weighted_bias/a": 0.2, "inference/mean/weighted_rmse/b": 2.0},
+        {"inference/mean/forecast_step": 2, "inference/mean/weighted_bias/a": 0.3, "inference/mean/weighted_rmse/b": 3.0,
+         "inference/time_mean/rmse/a": 0.5}]
+    # the composite refuses the image products it does not make, and needs the series length
+    w = torch.ones(4, 8)
+    with pytest.raises(NotImplementedError):
+        m.InferenceAggregator(w, n_timesteps=5, log_video=True)
+    with pytest.raises(NotImplementedError):
+        m.InferenceAggregator(w, n_timesteps=5, log_zonal_mean_images=True)
+    with pytest.raises(ValueError):
+        m.InferenceAggregator(w)
+    agg = m.InferenceAggregator(w, sigma_coordinates=object(), n_timesteps=25, n_ensemble_members=3, record_step_20=True)
+    assert list(agg._aggregators) == ["mean", "mean_norm", "time_mean", "mean_step_20"]
+    with pytest.raises(ValueError, match="target_data"):
+        agg.record_batch(0.0, {}, {"a": w}, {}, {"a": w})
