@@ -134,6 +134,18 @@ __device__ __forceinline__ void sdy_st16s(float* ubase, unsigned off_b, f32x4 v)
 #endif
 }
 
+// One fragment (16 bytes per lane) of a per-wave weight stream as (wave-uniform stream base in SGPRs) + (the lane's running
+// 32-bit byte offset) + (an immediate < 4 KB): the SADDR form of global_load, no VALU per load.  The fragment-stream kernels
+// used a per-lane 64-bit pointer; every refill then carried a v_add_co / v_addc pair, and a refill behind an MFMA delayed the
+// next one: tools/micro/mfma_two_roles.hip measures 35.7 cycles per MFMA for the pointer form against 32.9 for this one (38.7
+// when a group's two refills are issued back to back).  `off` is laundered in place (a laundered copy is one more live
+// register); the caller steps it by the group size (one v_add per group).
+__device__ __forceinline__ sdy_f16x8 sdy_ring_ld(const void* ubase, unsigned& off, int imm) {
+  sdy_gcptr_t b = (sdy_gcptr_t)ubase;
+  asm volatile("" : "+s"(b), "+v"(off));
+  return *reinterpret_cast<const sdy_f16x8 __attribute__((address_space(1)))*>(b + off + imm);
+}
+
 // ---- exact-erf GELU (nn.GELU default, src/models/sfno/sfnonet.py:602-603) ------------------------------
 // erfc(z), z >= 0, by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7): one v_rcp_f32, one v_exp_f32 and a
 // 5-term Horner chain instead of ocml's branchy erff (~4x fewer VALU cycles in the GEMM epilogues).  Using the

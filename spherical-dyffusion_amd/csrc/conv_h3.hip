@@ -116,15 +116,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
   const int t_end = (t_begin + t_per < ntiles) ? t_begin + t_per : ntiles;
 
   f16x8 r_hi[CRING], r_lo[CRING];
-  const wptr_t wbase = (wptr_t)(p.w + (size_t)wave * CGPW * CGROUP + lane);
-  wptr_t wp = wbase;
+  // ring loads: (wave-uniform stream base in SGPRs) + (the lane's running offset), sdy_ring_ld in common.h; the stream of a
+  // tile (NWIN windows of CRING groups) is fetched front to back, one window ahead of its use, and wraps
+  constexpr int CGROUP_BYTES = CGROUP * (int)sizeof(f16x8);
+  const char* const wbase = reinterpret_cast<const char*>(p.w) + (size_t)__builtin_amdgcn_readfirstlane(wave) * CGPW * CGROUP_BYTES;
+  unsigned woff = (unsigned)lane * 16u;
 #pragma unroll
   for (int s = 0; s < CRING; ++s) {
-    r_hi[s] = wp[s * CGROUP];
-    r_lo[s] = wp[s * CGROUP + 64];
+    r_hi[s] = sdy_ring_ld(wbase, woff, 0);
+    r_lo[s] = sdy_ring_ld(wbase, woff, CGROUP_BYTES / 2);
+    woff += CGROUP_BYTES;
   }
   constexpr int NWIN = KBLK * CMT;                     // windows of CRING groups per tile
-  wp = NWIN == 1 ? wbase : wbase + CRING * CGROUP;     // refill source while window 0 is consumed
+  if (NWIN == 1) woff -= CRING * CGROUP_BYTES;         // (the ring holds the whole stream: its refills fetch it again)
 
   // bias: pre-divided by out_scale and parked in LDS once; the accumulators START from it (no registers across tiles, no
   // add in the store loop).  Statistics: [256 rows][sum, sum of squares] fp64.
@@ -266,21 +270,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
           for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], acc[mi][j], 0, 0, 0));
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], acc[mi][j], 0, 0, 0);
-          r_hi[s] = wp[s * CGROUP];
-          r_lo[s] = wp[s * CGROUP + 64];
+          r_hi[s] = sdy_ring_ld(wbase, woff, 0);     // group (g + CRING) mod (NWIN CRING) of the stream
+          r_lo[s] = sdy_ring_ld(wbase, woff, CGROUP_BYTES / 2);
+          woff += CGROUP_BYTES;
+          if ((g + CRING + 1) % (NWIN * CRING) == 0) woff -= NWIN * CRING * CGROUP_BYTES;   // wrapped: next fetch is group 0
           __builtin_amdgcn_sched_barrier(0);   // keep the loads here (the scheduler otherwise sinks them next to their use)
-          if (s == CRING - 1) {   // window c = g / CRING is done: point wp at the source of the next window's refills
-            const int c = g / CRING;
-            if (c == NWIN - 2) {
-              wp = wbase;                                             // the last window refills with window 0
-              asm volatile("" : "+v"(wp));   // (laundered: otherwise the refill addresses become loop invariants in VGPRs)
-            } else if (c == NWIN - 1) {
-              wp = NWIN == 1 ? wbase : wbase + CRING * CGROUP;       // next tile, window 0: source is window 1
-              asm volatile("" : "+v"(wp));
-            } else {
-              wp += CRING * CGROUP;
-            }
-          }
         }
       }
     }

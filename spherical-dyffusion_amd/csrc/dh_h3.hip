@@ -92,14 +92,19 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
   if (cur.l < 0) return;
 
   f16x8 r_hi[DRING], r_lo[DRING];
-  auto w_base = [&](int l) { return (wptr_t)(p.w + (size_t)l * DLSTRIDE + (size_t)wave * DGPW * DGROUP + lane); };
-  wptr_t wp = w_base(cur.l);
+  // ring loads: (wave-uniform stream base of the degree in SGPRs) + (the lane's running offset), sdy_ring_ld in common.h
+  constexpr int DGROUP_BYTES = DGROUP * (int)sizeof(f16x8);
+  auto w_base = [&](int l) {
+    return reinterpret_cast<const char*>(p.w) + ((size_t)l * DLSTRIDE + (size_t)wave * DGPW * DGROUP) * sizeof(f16x8);
+  };
+  const char* wbase = w_base(cur.l);
+  unsigned woff = (unsigned)lane * 16u;
 #pragma unroll
   for (int s = 0; s < DRING; ++s) {
-    r_hi[s] = wp[s * DGROUP];
-    r_lo[s] = wp[s * DGROUP + 64];
+    r_hi[s] = sdy_ring_ld(wbase, woff, 0);
+    r_lo[s] = sdy_ring_ld(wbase, woff, DGROUP_BYTES / 2);
+    woff += DGROUP_BYTES;
   }
-  wp += DRING * DGROUP;
 
   // activation rows of a tile: clamped to row 0 of the degree beyond the ragged edge (zeroed when staged)
   f32x4 xr[8][2];
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
     // so one (wr, wi) fragment pair per block of 16 input channels feeds 24 MFMAs -- the real-expanded 512 x 512 matrix
     // [[wr, wi], [-wi, wr]] holds every number twice and streaming it cost 1 MB per tile through the 64 B/clk vector-memory
     // path (ablations in DESIGN.md).  The minus sign is applied to the x_im fragments (sign bits of hi and lo).
-    const wptr_t wnext = w_base(pre.l);
+    const char* const wnext = w_base(pre.l);
     f32x16 acc[2][2];   // [part: re, im][row tile j]
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -174,8 +179,8 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
 #pragma unroll
     for (int kb = 0; kb < DCB / 4; ++kb) {
       if (kb == DCB / 4 - 1) {   // the refills of the last block fetch block 0 of the next tile's stream
-        wp = wnext;
-        asm volatile("" : "+v"(wp));
+        wbase = wnext;
+        woff -= DGPW * DGROUP_BYTES;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -201,8 +206,9 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) mma3(acc[1][j], ah[j], al[j], r_hi[s0], r_lo[s0]);   // im += x_im . wr
-        r_hi[s0] = wp[s0 * DGROUP];
-        r_lo[s0] = wp[s0 * DGROUP + 64];
+        r_hi[s0] = sdy_ring_ld(wbase, woff, 0);
+        r_lo[s0] = sdy_ring_ld(wbase, woff, DGROUP_BYTES / 2);
+        woff += DGROUP_BYTES;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {   // -x_im
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -212,8 +218,9 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) mma3(acc[0][j], ah[j], al[j], r_hi[s1], r_lo[s1]);   // re -= x_im . wi
-        r_hi[s1] = wp[s1 * DGROUP];
-        r_lo[s1] = wp[s1 * DGROUP + 64];
+        r_hi[s1] = sdy_ring_ld(wbase, woff, 0);
+        r_lo[s1] = sdy_ring_ld(wbase, woff, DGROUP_BYTES / 2);
+        woff += DGROUP_BYTES;
 #ifndef DH_NOPREFETCH
         {   // one 16-byte piece of the next tile per channel block, never a burst
           xr[cb >> 1][cb & 1] = *reinterpret_cast<const f32x4*>(x_ptr(pre, cb >> 1) + 4 * (cb & 1));
@@ -221,7 +228,6 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
 #endif
         __builtin_amdgcn_sched_barrier(0);   // keep the loads here (the scheduler otherwise sinks them next to their use)
       }
-      wp += DRING * DGROUP;
     }
 
     stamp(3);

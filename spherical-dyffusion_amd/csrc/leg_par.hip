@@ -87,12 +87,17 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
 
   // ---- table ring (slot = 2 * (k-step % 4) + half)
   f16x8 r_hi[PRING], r_lo[PRING];
-  const f16x8* __restrict__ wp = p.table + (size_t)(z * 3 + wave) * PGPW * PGROUP + lane;
+  // (wave-uniform stream base in SGPRs) + (the lane's running offset): sdy_ring_ld in common.h
+  constexpr int PGROUP_BYTES = PGROUP * (int)sizeof(f16x8);
+  const char* const wbase = reinterpret_cast<const char*>(p.table) +
+                            (size_t)__builtin_amdgcn_readfirstlane(z * 3 + wave) * PGPW * PGROUP_BYTES;
+  unsigned woff = (unsigned)lane * 16u;
   if (!wave_dead) {
 #pragma unroll
     for (int s = 0; s < PRING; ++s) {
-      r_hi[s] = wp[s * PGROUP];
-      r_lo[s] = wp[s * PGROUP + 64];
+      r_hi[s] = sdy_ring_ld(wbase, woff, 0);
+      r_lo[s] = sdy_ring_ld(wbase, woff, PGROUP_BYTES / 2);
+      woff += PGROUP_BYTES;
     }
   }
 
@@ -212,8 +217,9 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int s = 2 * (ks & 3) + hf;
-        r_hi[s] = wp[(PRING + s) * PGROUP];
-        r_lo[s] = wp[(PRING + s) * PGROUP + 64];
+        r_hi[s] = sdy_ring_ld(wbase, woff, 0);     // group PRING + s: the stream front to back
+        r_lo[s] = sdy_ring_ld(wbase, woff, PGROUP_BYTES / 2);
+        woff += PGROUP_BYTES;
       }
     }
     __builtin_amdgcn_sched_barrier(0);

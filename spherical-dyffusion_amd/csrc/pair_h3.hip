@@ -28,7 +28,6 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef const f16x8 __attribute__((address_space(1)))* wptr_t;   // (explicit global address space: see mlp_h3.hip)
 
 namespace {
 
@@ -165,21 +164,23 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
 
   // ---- weight ring
   f16x8 r_hi[PRING], r_lo[PRING];
-  auto wbase_of = [&](int ln) { return (wptr_t)(p.w + (size_t)wave * (NPAD + PRING) * PGROUP + ln); };
-  wptr_t wp = wbase_of(lane);
+  constexpr int GROUP_BYTES = PGROUP * (int)sizeof(f16x8);
+  const char* const wbase = reinterpret_cast<const char*>(p.w) + (size_t)wave * (NPAD + PRING) * GROUP_BYTES;
+  unsigned woff = (unsigned)lane * 16u;   // lane's byte offset of the NEXT position to fetch (sdy_ring_ld, common.h)
 #pragma unroll
   for (int s = 0; s < PRING; ++s) {
-    r_hi[s] = wp[s * PGROUP];
-    r_lo[s] = wp[s * PGROUP + 64];
+    r_hi[s] = sdy_ring_ld(wbase, woff, 0);
+    r_lo[s] = sdy_ring_ld(wbase, woff, GROUP_BYTES / 2);
+    woff += GROUP_BYTES;
   }
-  wp += PRING * PGROUP;   // wp[i * PGROUP] = group i of the 16-block AFTER the one being consumed
-  // behind the last MFMA of position g: its slot takes the group 16 positions on (a hole of the numbering is not loaded)
+  // behind the last MFMA of position g: its slot takes the group 16 positions on (a hole of the numbering is not loaded);
+  // positions are visited in order, each exactly once with which != 0, so the offset just steps on
   auto refill = [&](int g, int which) {   // which: 0 = the lo fragment, 1 = the hi fragment (after lo), 2 = both
     if ((g + PRING) % NPAD < N) {
-      if (which != 1) r_lo[g & 15] = wp[(g & 15) * PGROUP + 64];
-      if (which != 0) r_hi[g & 15] = wp[(g & 15) * PGROUP];
+      if (which != 1) r_lo[g & 15] = sdy_ring_ld(wbase, woff, GROUP_BYTES / 2);
+      if (which != 0) r_hi[g & 15] = sdy_ring_ld(wbase, woff, 0);
     }
-    if ((g & 15) == 15 && which != 0) wp += PRING * PGROUP;
+    if (which != 0) woff += GROUP_BYTES;
   };
 
   // ---- x staging: thread = (pixel quad q0, channel octets o0 + 16 i)
@@ -470,12 +471,7 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
     // the holes of the numbering: their slots take the next tile's first groups
 #pragma unroll
     for (int g = N; g < NPAD; ++g) refill(g, 2);
-    {
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      wp = wbase_of(ln) + PRING * PGROUP;   // the refills above fetched block 0 of the stream's tail = the next tile's
-    }
-    asm volatile("" : "+v"(wp));
+    woff -= NPAD * GROUP_BYTES;   // the refills above fetched the stream's tail = the next tile's first 16 groups
     stamp(8);
 
     // ---- epilogue: accumulators -> LDS [rows][64 px] -> addend + 16-byte row stores (+ statistics)

@@ -14,7 +14,9 @@ typedef const f16x8 __attribute__((address_space(1)))* wptr_t;
 
 constexpr int RING = 8;
 
-template <int MODE>   // bit 0: role C runs, bit 1: role P runs, bit 2: role P raises its priority (s_setprio 3)
+template <int MODE>   // bit 0: role C runs, bit 1: role P runs, bit 2: role P raises its priority (s_setprio 3),
+                      // bit 3: C without its LDS fragment reads, bit 4: C without its weight refills, bit 5: the refills land in registers no MFMA reads, bit 6: refills pinned one behind an MFMA (k = 4, 5),
+                      // bit 7: pinned refills addressed as (SGPR base) + (constant lane offset): no VALU per load
 __global__ __launch_bounds__(512, 1) void kern(const f16x8* w, float* out, unsigned long long* ticks, int iters, int iters_p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   _Float16* Hs = reinterpret_cast<_Float16*>(smem);            // 64 KB: fragments read by C
@@ -26,14 +28,15 @@ __global__ __launch_bounds__(512, 1) void kern(const f16x8* w, float* out, unsig
   float res = 0.f;
   if (wave < 4) {
     if (MODE & 1) {
-      f16x8 r_hi[RING], r_lo[RING];
+      f16x8 r_hi[RING], r_lo[RING], d_hi[RING], d_lo[RING];
       wptr_t wp = (wptr_t)(w + (size_t)wave * 4096 + lane);     // 64 KB of weights per wave, L2 resident, re-read in a cycle
 #pragma unroll
-      for (int s = 0; s < RING; ++s) { r_hi[s] = wp[s * 128]; r_lo[s] = wp[s * 128 + 64]; }
+      for (int s = 0; s < RING; ++s) { r_hi[s] = wp[s * 128]; r_lo[s] = wp[s * 128 + 64]; d_hi[s] = r_hi[s]; d_lo[s] = r_lo[s]; }
       f32x16 acc[2][2];
       for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
       f16x8 bh[2][2], bl[2][2];
       const int l31 = lane & 31, h = lane >> 5;
+      const unsigned lane_off = (unsigned)lane * 16u;
       auto ldb1 = [&](int set, int t, int what) {
         const int j = what & 1;
         const int off = (32 * j + l31) * 128 + (((2 * t + h) ^ (l31 & 15)) & 15) * 8;
@@ -56,17 +59,30 @@ __global__ __launch_bounds__(512, 1) void kern(const f16x8* w, float* out, unsig
               const int j = k & 1;
               acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? a_lo : a_hi, (k >= 2 && k < 4) ? bl[cur][j] : bh[cur][j],
                                                                  acc[mi][j], 0, 0, 0);
-              if (mi == 0 && k < 4) ldb1(cur ^ 1, (t + 1) & 3, k);
+              if (!(MODE & 8) && mi == 0 && k < 4) ldb1(cur ^ 1, (t + 1) & 3, k);
+              if ((MODE & 64) && k == 4) r_lo[s] = wp[base + s * 128 + 64];
+              if ((MODE & 64) && k == 5) r_hi[s] = wp[base + s * 128];
+              if ((MODE & 128) && k >= 4) {
+                typedef const char __attribute__((address_space(1)))* gcp;
+                gcp b = (gcp)(w + (size_t)wave * 4096) + (size_t)(base + s * 128 + (k == 4 ? 64 : 0)) * 16;
+                unsigned lo = lane_off;
+                asm volatile("" : "+s"(b), "+v"(lo));
+                const f16x8 val = *reinterpret_cast<const f16x8 __attribute__((address_space(1)))*>(b + lo);
+                if (k == 4) r_lo[s] = val; else r_hi[s] = val;
+              }
               __builtin_amdgcn_sched_barrier(0);
             }
-            r_hi[s] = wp[base + s * 128];
-            r_lo[s] = wp[base + s * 128 + 64];
+            if (!(MODE & 16) && !(MODE & 64) && !(MODE & 128)) {
+              if (MODE & 32) { d_hi[s] = wp[base + s * 128]; d_lo[s] = wp[base + s * 128 + 64]; }
+              else { r_hi[s] = wp[base + s * 128]; r_lo[s] = wp[base + s * 128 + 64]; }
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
       t1 = __builtin_amdgcn_s_memtime();
       for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) res += acc[a][b][r];
+      for (int s = 0; s < RING; ++s) res += (float)d_hi[s][0] + (float)d_lo[s][1];
     }
   } else {
     if (MODE & 2) {
@@ -135,5 +151,11 @@ int main() {
   run<3>("C + P (P at 1/3 duty)", w, out, ticks, n_cu, 2000, 3000);   // mlp_h3's ratio: ~1 chain piece per 15-20 MFMAs
   run<7>("C + P, P at priority 3", w, out, ticks, n_cu, 2000, 12000);
   run<7>("C + P prio 3, 1/3 duty", w, out, ticks, n_cu, 2000, 3000);
+  run<1 + 8>("C alone, no LDS reads", w, out, ticks, n_cu, 2000, 0);
+  run<1 + 16>("C alone, no refills", w, out, ticks, n_cu, 2000, 0);
+  run<1 + 8 + 16>("C alone, MFMAs only", w, out, ticks, n_cu, 2000, 0);
+  run<1 + 32>("C alone, refills to spare regs", w, out, ticks, n_cu, 2000, 0);
+  run<1 + 64>("C alone, refills pinned", w, out, ticks, n_cu, 2000, 0);
+  run<1 + 128>("C alone, pinned, SGPR base", w, out, ticks, n_cu, 2000, 0);
   return 0;
 }
