@@ -168,10 +168,12 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   n0 = (tile - z * tpi) * TN;
   full = n0 + TN <= p.HW;   // workgroup-uniform
 
-  // ---- phase 0: x tile (already in registers) -> LDS (fp16 hi / lo, [px][k])
-  {
+  // ---- phase 0: x tile (already in registers) -> LDS (fp16 hi / lo, [px][k]); a full tile (all but an image's last) takes
+  //      no select per value
+  auto stage_x = [&](auto full_t) {
+    constexpr bool kFull = decltype(full_t)::value;
     float amax = 0.0f;   // range guard of the fp16 split (flagged per tile: no register lives across the tile loop)
-    const bool ok = full || (n0 + 4 * q0 < p.HW);
+    const bool ok = kFull || (n0 + 4 * q0 < p.HW);
 #pragma unroll
     for (int oc = 0; oc < 2; ++oc) {
       float av[8], dv[8];
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         f16x8 vh, vl;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ok ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
+        for (int e = 0; e < 8; ++e) v[e] = (kFull || ok) ? fmaf(xr[oc][e][pp], av[e], dv[e]) : 0.0f;
         sdy_split8(v, vh, vl, amax);
         const int off = xs_off(px, o0 + 16 * oc);
         *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
@@ -196,7 +198,9 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       }
     }
     sdy_flag_range(p.flags, amax);
-  }
+  };
+  if (full) stage_x(std::true_type{});   // (workgroup-uniform)
+  else stage_x(std::false_type{});
   __syncthreads();
 
   f32x16 oacc[2][2];   // this wave's 64 output rows x 64 px (zeroed right before the first fc2: not live earlier)
