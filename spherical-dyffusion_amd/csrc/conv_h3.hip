@@ -20,9 +20,6 @@
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// explicit global address space: a pointer laundered through an empty asm loses its provenance, and hipcc then emits
-// FLAT loads, which also count in lgkmcnt -- every LDS-fragment wait became lgkmcnt(0), i.e. a wait for the weight refills
-typedef const f16x8 __attribute__((address_space(1)))* wptr_t;
 
 namespace {
 

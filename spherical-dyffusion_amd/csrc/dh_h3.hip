@@ -26,7 +26,6 @@
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef const f16x8 __attribute__((address_space(1)))* wptr_t;   // see conv_h3.hip
 
 namespace {
 
