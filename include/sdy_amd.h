@@ -41,6 +41,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported. */
+#pragma GCC visibility push(default)
 
 #define SDY_OK 0
 #define SDY_ERR_ARG (-1)         /* null pointer / non-positive extent */
@@ -208,6 +210,9 @@ typedef struct sdy_mlp_args {
   double* stats;                       /* dev [B*E*2] or NULL: (sum, sum of squares) over HW of every output plane are
                                           ADDED here (InstanceNorm statistics of the next block, sfnonet.py:292): zero
                                           it before the launch, turn it into coefficients with sdy_instnorm_from_stats */
+  const float* keep_hidden;            /* tests only, dev (B, hidden, HW) and (B, E, HW) 0/1 masks or NULL: with drop_p > 0 the */
+  const float* keep_out;               /* keep decisions come from these (e.g. masks the reference's nn.Dropout drew) instead of
+                                          the Philox stream -- same kernel code, a separate (untimed) instantiation */
 } sdy_mlp_args;
 /* (sum, sumsq) statistics -> the same per-(b,c) affine coefficients as sdy_instnorm_coeffs; clears `stats` for reuse. */
 int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, const float* gamma, const float* beta,
@@ -415,6 +420,7 @@ int sdy_profile_stage_count(void);
 const char* sdy_profile_stage_name(int stage);
 int sdy_profile_read(double* total_ms, long* launches, int n);   /* arrays of n >= sdy_profile_stage_count() */
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

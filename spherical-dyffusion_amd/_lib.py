@@ -61,6 +61,7 @@ class SdyMlpArgs(C.Structure):
         ("rows_per_call", C.c_int),
         ("batch_scale", C.c_void_p),
         ("stats", C.c_void_p),
+        ("keep_hidden", C.c_void_p), ("keep_out", C.c_void_p),
     ]
 
 

@@ -1108,7 +1108,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     const bool scale_residual = pin != pout;  // s2convolutions.py:79-83
     const float pm = (drop && c.dropout_mlp > 0.f) ? c.dropout_mlp : 0.f;
     static const bool no_fused = std::getenv("SDY_NO_FUSED_MLP") != nullptr;
-    const bool fused_mlp = bw.mlp && !no_fused && !(pm > 0.f && a->keep_masks);
+    const bool fused_mlp = bw.mlp && !no_fused;   // (injected masks too: sdy_mlp_args.keep_hidden / keep_out)
     // The block's residual is norm0(x) (or its SHT round trip when the grids differ).  With the fused MLP kernel the
     // normalised tensor is never materialised: its two consumers (inner skip, final residual add) apply a*x + d to `cur`.
     const bool lazy_norm = fused_mlp && !scale_residual;
@@ -1172,6 +1172,10 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       ma.drop_p = pm; ma.seed = a->seed; ma.call = a->call; ma.stream_fc1 = 2u * i; ma.stream_fc2 = 2u * i + 1u;
       ma.batch_offset = a->batch_offset; ma.rows_per_call = rpc;
       if (drop && n->tm.dp_rate[i] > 0.f) ma.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
+      if (pm > 0.f && a->keep_masks) {   // tests: the reference's recorded masks drive the fused kernel's INJECT instantiation
+        ma.keep_hidden = static_cast<const float*>(a->keep_masks[2 * i]);
+        ma.keep_out = static_cast<const float*>(a->keep_masks[2 * i + 1]);
+      }
       static const bool no_stats = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
       if (i < L - 1 && !no_stats) { ma.stats = st0; have_st0 = true; }   // the next block's norm0 statistics
       SDY_STAGE(pm > 0.f ? ST_MLP_FUSED_DROP : ST_MLP_FUSED, sdy_mlp_h3(&ma, stream));

@@ -90,6 +90,13 @@ __device__ __forceinline__ void sdy_split8(const float* v, sdy_f16x8& hi, sdy_f1
   for (int e = 0; e < 8; e += 2) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
   sdy_split8(v, hi, lo);
 }
+// Activation pre-scale of every split-fp16 kernel (x -> SDY_ACT_SX * x before the hi / lo split, undone in the accumulator
+// scale).  fp16 overflows at 65504, so a staged |value| >= 65504 / SDY_ACT_SX sets SDY_FLAG_F16_RANGE; below
+// 2^-3 / SDY_ACT_SX the `lo` part is an fp16 subnormal and the split keeps an ABSOLUTE precision of 2^-25 / SDY_ACT_SX
+// instead of 22 relative bits.  One constant for all kernels (EXTRA=-DSDY_ACT_SX=... builds a variant for A/B runs).
+#ifndef SDY_ACT_SX
+#define SDY_ACT_SX 16.0f
+#endif
 // Sticky status word of a device (include/sdy_amd.h, sdy_status_flags): bits are only ever set by kernels.
 #define SDY_F16_LIMIT 65504.0f
 __device__ __forceinline__ void sdy_flag_range(unsigned* flags, float amax) {
@@ -106,6 +113,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // split-precision product, i.e. single-pass f16 MFMA arithmetic (fp16-class accuracy: ~1e-3) with everything else -- the
 // hi / lo splits, the loads of the lo fragments, the schedules -- unchanged.  Bounds what the three passes cost and gives the
 // "bf16-class" number BASELINE.json's configs[1] label asks about; never the shipped arithmetic.
+// In-kernel phase stamps (s_memtime per phase of one sampled workgroup) and their read-back entry points
+// sdy_*_debug_stamps exist in MEASUREMENT BUILDS ONLY (csrc/Makefile EXTRA=-DSDY_STAMPS, tools/*_stamps.py): the product
+// library carries neither the stamp branches in its tile loops nor the entry points.
+#ifdef SDY_STAMPS
+#define SDY_STAMPS_ON 1
+#else
+#define SDY_STAMPS_ON 0
+#endif
+#define SDY_DEBUG_EXPORT extern "C" __attribute__((visibility("default")))
+
 #ifndef SDY_H3_PASSES
 #define SDY_H3_PASSES 3
 #endif
@@ -195,7 +212,7 @@ __device__ __forceinline__ sdy_gf2 gelu_erf2(sdy_gf2 x) {
 // The table is built once per device in fp64 (pointwise.hip) and copied into LDS by the kernels that use it.
 #define SDY_GELU_NODES 385
 #define SDY_GELU_TAB_BYTES (SDY_GELU_NODES * 16)
-#define SDY_GELU_SX 16.0f       // activation pre-scale of the split-fp16 kernels: the table yields SDY_GELU_SX * gelu
+#define SDY_GELU_SX SDY_ACT_SX       // activation pre-scale of the split-fp16 kernels: the table yields SDY_GELU_SX * gelu
 #define SDY_GELU_WS 8.0f        // w = SDY_GELU_WS * v
 #define SDY_GELU_MAGIC (8388608.0f + 192.0f)
 int sdy_gelu_table_ptr(const float** table_dev);   // device pointer of the current device's table ([385][4] floats)

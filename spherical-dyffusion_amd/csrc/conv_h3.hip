@@ -28,7 +28,7 @@ constexpr int CTN = 64;          // pixels per tile
 constexpr int CKMAX = 384;       // input channels supported
 constexpr int CRING = 4;         // weight groups in flight: one "window" of the stream
 constexpr int CGROUP = 2 * 64;   // f16x8 elements per group (hi | lo)
-constexpr float CSX = 16.0f;
+constexpr float CSX = SDY_ACT_SX;
 constexpr int CSTAT_BYTES = CE * 2 * 8;
 #ifndef SDY_CONV_STAMP_T0
 #define SDY_CONV_STAMP_T0 2      // first of the four tiles of workgroup 3 that SDY_CONV_STAMPS samples
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
     asm volatile("" : "+v"(l31), "+v"(h), "+v"(q0), "+v"(o0));
     const int tile_it = tile - t_begin;
     auto stamp = [&](int i) {
-      if (p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= SDY_CONV_STAMP_T0 && tile_it < SDY_CONV_STAMP_T0 + 4)
+      if (SDY_STAMPS_ON && p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= SDY_CONV_STAMP_T0 && tile_it < SDY_CONV_STAMP_T0 + 4)
         p.stamps[(tile_it - SDY_CONV_STAMP_T0) * 8 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
@@ -355,13 +355,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
 
 }  // namespace
 
+#if SDY_STAMPS_ON
 static unsigned long long* g_cstamps = nullptr;
-extern "C" int sdy_conv256_h3_debug_stamps(unsigned long long* host64) {
+SDY_DEBUG_EXPORT int sdy_conv256_h3_debug_stamps(unsigned long long* host64) {
   if (!g_cstamps || !host64) return SDY_ERR_STATE;
   SDY_HIP_TRY(hipDeviceSynchronize());
   SDY_HIP_TRY(hipMemcpy(host64, g_cstamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SDY_OK;
 }
+#endif
 
 extern "C" int sdy_conv256_h3_supported(int Cin, int Cout) { return (Cin >= 1 && Cin <= CKMAX && Cout == CE) ? 1 : 0; }
 
@@ -443,10 +445,12 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   p.HW = a->HW; p.B = a->B; p.Cin = a->Cin;
   p.out_scale = 1.0f / (a->w_frag_scale * CSX);
   p.stamps = nullptr;
+#if SDY_STAMPS_ON
   if (std::getenv("SDY_CONV_STAMPS")) {
     if (!g_cstamps) SDY_HIP_TRY(hipMalloc(&g_cstamps, 64 * sizeof(unsigned long long)));
     p.stamps = g_cstamps;
   }
+#endif
   int n_cu = 0;
   SDY_TRY(sdy_cu_count(&n_cu));
   const long ntiles = (long)((a->HW + CTN - 1) / CTN) * a->B;

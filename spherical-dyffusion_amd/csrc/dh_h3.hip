@@ -39,7 +39,7 @@ constexpr int DRING = 8;           // groups in flight (4 channel blocks x (wr, 
 constexpr int DGPW = 2 * DCB;      // groups per wave and degree (32)
 constexpr int DGROUP = 2 * 64;     // f16x8 elements per group (hi | lo)
 constexpr long DLSTRIDE = (long)DWAVES * DGPW * DGROUP;   // f16x8 elements per degree (512 KB)
-constexpr float DSX = 16.0f;
+constexpr float DSX = SDY_ACT_SX;
 
 struct DhParams {
   const float* X; long sX;         // Cs_in,  per-degree stride (floats)
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
     asm volatile("" : "+v"(l31), "+v"(h), "+v"(oc), "+v"(r0));
     const int M = dh_rows(p, cur.l);
     auto stamp = [&](int i) {
-      if (p.stamps && blockIdx.x == 11 && lane == 0 && tile_it >= 2 && tile_it < 6)
+      if (SDY_STAMPS_ON && p.stamps && blockIdx.x == 11 && lane == 0 && tile_it >= 2 && tile_it < 6)
         p.stamps[((tile_it - 2) * 8 + wave) * 8 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
@@ -272,14 +272,16 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
 
 }  // namespace
 
+#if SDY_STAMPS_ON
 static unsigned long long* g_dstamps = nullptr;
-extern "C" int sdy_dhconv_frag_debug_stamps(unsigned long long* host256) {
+SDY_DEBUG_EXPORT int sdy_dhconv_frag_debug_stamps(unsigned long long* host256) {
   unsigned long long* host64 = host256;
   if (!g_dstamps || !host64) return SDY_ERR_STATE;
   SDY_HIP_TRY(hipDeviceSynchronize());
   SDY_HIP_TRY(hipMemcpy(host64, g_dstamps, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SDY_OK;
 }
+#endif
 
 extern "C" int sdy_dhconv_frag_supported(int Ci, int Co) { return (Ci == DE && Co == DE) ? 1 : 0; }
 
@@ -334,10 +336,12 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
   p.out_scale = 1.0f / (scale * DSX);
   SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;
+#if SDY_STAMPS_ON
   if (std::getenv("SDY_DH_STAMPS")) {
     if (!g_dstamps) SDY_HIP_TRY(hipMalloc(&g_dstamps, 256 * sizeof(unsigned long long)));
     p.stamps = g_dstamps;
   }
+#endif
   int n_cu = 0;
   SDY_TRY(sdy_cu_count(&n_cu));
   const int smem = 2 * DTN * DK * (int)sizeof(_Float16) + DWAVES * 8 * 64 * (int)sizeof(float);   // x tile + staging

@@ -512,7 +512,7 @@ int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, in
   pk.Kpad = Kpad;
   pk.bstride = bstride;
   SDY_TRY(sdy_flags_ptr(&pk.flags));
-  const float sx = 16.0f;                       // keeps the lo parts of O(1) activations out of the fp16 subnormals
+  const float sx = SDY_ACT_SX;                       // keeps the lo parts of O(1) activations out of the fp16 subnormals
   const float out_scale = 1.0f / (w_scale * sx);
   if (rows_mode) {
     if (!p.A) return SDY_ERR_ARG;

@@ -27,7 +27,7 @@ constexpr int LKS = 12;          // k-steps of 16
 constexpr int LRING = 8;         // groups in flight = one block of 4 k-steps x 2 m-tiles
 constexpr int LGPW = 2 * LKS;    // groups per (m, wave)
 constexpr int LGROUP = 2 * 64;   // f16x8 elements per group
-constexpr float LSX = 16.0f;
+constexpr float LSX = SDY_ACT_SX;
 
 struct LegParams {
   const f16x8* table;            // [nz][3 waves][LGPW groups][hi | lo][64 lanes] (+ LRING groups of padding)

@@ -33,7 +33,7 @@ constexpr int PKS = 6;           // k-steps of 16 per half
 constexpr int PRING = 8;         // groups in flight = 4 k-steps x (E, O)
 constexpr int PGPW = 2 * PKS;    // groups per (m, wave)
 constexpr int PGROUP = 2 * 64;   // f16x8 elements per group
-constexpr float PSX = 16.0f;
+constexpr float PSX = SDY_ACT_SX;
 
 struct ParParams {
   const f16x8* table;            // [nz][3 waves][PGPW groups: (k-step, E | O)][hi | lo][64 lanes]
@@ -302,13 +302,15 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
 
 }  // namespace
 
+#if SDY_STAMPS_ON
 static unsigned long long* g_lstamps = nullptr;
-extern "C" int sdy_leg_par_debug_stamps(unsigned long long* host96) {
+SDY_DEBUG_EXPORT int sdy_leg_par_debug_stamps(unsigned long long* host96) {
   if (!g_lstamps || !host96) return SDY_ERR_STATE;
   SDY_HIP_TRY(hipDeviceSynchronize());
   SDY_HIP_TRY(hipMemcpy(host96, g_lstamps, 96 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SDY_OK;
 }
+#endif
 
 size_t sdy_leg_par_table_bytes(int nz) { return ((size_t)nz * 3 * PGPW + PRING) * PGROUP * sizeof(f16x8); }
 
@@ -380,17 +382,19 @@ int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, l
   p.rows_out = rows_out; p.K = K; p.N = N; p.kdead = kdead;
   p.out_scale = 1.0f / (scale * PSX);
   p.stamps = nullptr;
+  dim3 grid((N + PTN - 1) / PTN, nz);
+#if SDY_STAMPS_ON
   if (std::getenv("SDY_LEG_STAMPS")) {
     if (!g_lstamps) SDY_HIP_TRY(hipMalloc(&g_lstamps, 96 * sizeof(unsigned long long)));
     p.stamps = g_lstamps;
   }
-  dim3 grid((N + PTN - 1) / PTN, nz);
   if (p.stamps) {
     if (fwd) hipLaunchKernelGGL((leg_par_kernel<true, true>), grid, dim3(192), 0, stream, p);
     else hipLaunchKernelGGL((leg_par_kernel<false, true>), grid, dim3(192), 0, stream, p);
-  } else {
-    if (fwd) hipLaunchKernelGGL((leg_par_kernel<true, false>), grid, dim3(192), 0, stream, p);
-    else hipLaunchKernelGGL((leg_par_kernel<false, false>), grid, dim3(192), 0, stream, p);
+    return sdy_launch_status();
   }
+#endif
+  if (fwd) hipLaunchKernelGGL((leg_par_kernel<true, false>), grid, dim3(192), 0, stream, p);
+  else hipLaunchKernelGGL((leg_par_kernel<false, false>), grid, dim3(192), 0, stream, p);
   return sdy_launch_status();
 }

@@ -50,7 +50,7 @@ constexpr int KSC = HC / 16;   // k-steps of fc2 per chunk
 constexpr int RING = 16;                // groups in flight = groups per block (16 fc1 k-steps, 8 x 2 fc2 groups)
 constexpr int NGROUPS = NCH * 2 * RING;      // 128
 static_assert(KS1 == RING && 2 * KSC == RING, "ring slot = index inside a block");
-constexpr float SX = 16.0f;    // activation pre-scale (keeps lo parts out of the fp16 subnormals)
+constexpr float SX = SDY_ACT_SX;    // activation pre-scale (keeps lo parts out of the fp16 subnormals)
 constexpr int GROUP_F8 = 2 * 64;        // f16x8 elements per group (hi fragment, lo fragment)
 
 struct MlpParams {
@@ -68,6 +68,7 @@ struct MlpParams {
   int rows_per_call;                       // >= 1 (sdy_mlp_args.rows_per_call; 0 there = B)
   const float* batch_scale;
   double* stats;                           // optional [B][ME][2]: sum and sum of squares of the stored output rows
+  const float* keep_h; const float* keep_o; // INJECT instantiation only (tests): 0/1 masks (B, MH, HW) / (B, ME, HW)
   unsigned* flags;                         // sticky status word (sdy_status_flags)
   unsigned long long* stamps;              // timing experiments only (SDY_MLP_STAMPS): per-phase s_memtime of one wave
 };
@@ -82,7 +83,10 @@ __device__ __forceinline__ int hs_off(int px, int c) { return px * HC + (((c ^ p
 
 // DROP: dropout on (compile time: a runtime test would split every chain piece into basic blocks and the scheduler
 // interleaves VALU with MFMAs only inside one block)
-template <bool DROP>
+// INJECT (tests only; instantiated in its own translation unit, mlp_h3_inject.hip, so that the two product instantiations
+// keep their register allocation): the keep decisions come from mask tensors -- e.g. the ones the reference's nn.Dropout
+// layers drew, tests/golden -- instead of the Philox stream; everything else is the same code.
+template <bool DROP, bool INJECT = false>
 __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 64 KB x tile + 2 x 32 KB hidden chunk
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
@@ -159,9 +163,19 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   // out of the tile loop (~160 registers of loop invariants, spilled and reloaded from scratch inside the MFMA loops)
   asm volatile("" : "+v"(l31), "+v"(h), "+v"(q0), "+v"(o0));
   const int tile_it = tile - t_begin;
+  // Phase marks.  Measurement builds (-DSDY_STAMPS) record s_memtime of one sampled wave here.  The product build keeps a
+  // BASIC-BLOCK BOUNDARY at every mark (a branch on a kernel argument that is always zero: two scalar instructions): hipcc's
+  // register allocator splits live ranges at block boundaries, and without them the kernel goes over its 512 registers and
+  // spills (176 / 272 bytes of scratch with the marks removed, 272 / 272 with sched_barrier(0) in their place;
+  // tests/test_code_objects.py).
   auto stamp = [&](int i) {
+#if SDY_STAMPS_ON
     if (p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= 2 && tile_it < 6)
       p.stamps[(tile_it - 2) * 16 + i] = __builtin_amdgcn_s_memtime();
+#else
+    (void)i; (void)tile_it;
+    if (p.stamps && tid == 0) asm volatile("s_nop 0");
+#endif
   };
   stamp(0);
   z = tile / tpi;
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         if (k < 4) { if (ks + 1 < KS1) ldb1(c ^ 1, ks + 1, k); }
         else if (k == 4) r_lo[ks] = wp[ks * GROUP_F8 + 64];
         else r_hi[ks] = wp[ks * GROUP_F8];
-        if (DROP && SDY_MLP_PHILOX_AHEAD && ((6 * ks + k) & 1) == 0 && (6 * ks + k) / 2 < 40) philox_ahead(hc_fc1, (6 * ks + k) / 2);
+        if (DROP && !INJECT && SDY_MLP_PHILOX_AHEAD && ((6 * ks + k) & 1) == 0 && (6 * ks + k) / 2 < 40) philox_ahead(hc_fc1, (6 * ks + k) / 2);
         __builtin_amdgcn_sched_barrier(0);
       }
       } else {
@@ -331,6 +345,11 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     uint32_t c0, c1, c2, c3, k0, k1;
   };
   uint32_t pw[4];   // Philox words of the last j == 0 piece: its j == 1 partner (same rows, pixel + 32) takes the high halves
+  // INJECT: keep flag of hidden row `row`, tile pixel `px` of image z from the mask tensor (a global load per value: tests only)
+  auto keep_h_at = [&](int row, int px) {
+    const int pix = (n0 + px < p.HW) ? n0 + px : p.HW - 1;
+    return p.keep_h[((long)z * MH + row) * p.HW + pix] != 0.0f;
+  };
   auto chain_stage = [&](Piece& s, int st, int hc, int j, int g4) {
     const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
     const int px = 32 * j + l31;
@@ -420,8 +439,12 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         if (do_drop) {
           if (!SDY_MLP_PHILOX_AHEAD && j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            s.v[r] = sdy_keep16(SDY_MLP_PHILOX_AHEAD ? mw[g4][r] : pw[r], j, p.drop_thr) ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
+          for (int r = 0; r < 4; ++r) {
+            bool keep;
+            if constexpr (INJECT) keep = keep_h_at(row0 + 8 * g4 + r, px);
+            else keep = sdy_keep16(SDY_MLP_PHILOX_AHEAD ? mw[g4][r] : pw[r], j, p.drop_thr);
+            s.v[r] = keep ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
+          }
         }
         break;
       }
@@ -520,8 +543,12 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         if (do_drop) {
           if (!SDY_MLP_PHILOX_AHEAD && j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            s.v[r] = sdy_keep16(SDY_MLP_PHILOX_AHEAD ? mw[g4][r] : pw[r], j, p.drop_thr) ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
+          for (int r = 0; r < 4; ++r) {
+            bool keep;
+            if constexpr (INJECT) keep = keep_h_at(row0 + 8 * g4 + r, px);
+            else keep = sdy_keep16(SDY_MLP_PHILOX_AHEAD ? mw[g4][r] : pw[r], j, p.drop_thr);
+            s.v[r] = keep ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
+          }
         }
         break;
       case 10: {   // fp16 hi and the fp32 residual (kept in e / t for the last slot; an inline-asm v_fma_mix_f32 here costs
@@ -684,7 +711,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (do_drop) {   // one call per 4 rows x the pixel pair (l31, l31 + 32)
+        if (do_drop && !INJECT) {   // one call per 4 rows x the pixel pair (l31, l31 + 32)
           const philox4 w = philox4x32_10((uint32_t)(n0 + l31), c1_base2 + (uint32_t)((row0 + 8 * g4) >> 2), p.stream2,
                                           call_z, p.seed_lo, p.seed_hi);
           words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
@@ -697,8 +724,14 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
             sdy_gf2 o = sdy_gf2{oacc[mi][j][4 * g4 + r4], oacc[mi][j][4 * g4 + r4 + 1]} * s2e +
                         sdy_gf2{bv[g4][r4], bv[g4][r4 + 1]};
             if (do_drop) {
-              o = sdy_gf2{sdy_keep16(words[r4], j, p.drop_thr) ? o.x : 0.0f,
-                          sdy_keep16(words[r4 + 1], j, p.drop_thr) ? o.y : 0.0f};
+              if constexpr (INJECT) {
+                const int pix = (n0 + px < p.HW) ? n0 + px : p.HW - 1;
+                const float* km = p.keep_o + ((long)z * ME + row0 + 8 * g4 + r4) * p.HW + pix;
+                o = sdy_gf2{km[0] != 0.0f ? o.x : 0.0f, km[p.HW] != 0.0f ? o.y : 0.0f};
+              } else {
+                o = sdy_gf2{sdy_keep16(words[r4], j, p.drop_thr) ? o.x : 0.0f,
+                            sdy_keep16(words[r4 + 1], j, p.drop_thr) ? o.y : 0.0f};
+              }
             }
             o = o * bscale;
             Os[(row0 + 8 * g4 + r4) * TN + px] = o.x;
@@ -784,14 +817,17 @@ void put_group(_Float16* dst, const float* w, int K, int mt, int ks, float s) {
 
 }  // namespace
 
+#ifndef SDY_MLP_INJECT_TU
+#if SDY_STAMPS_ON
 static unsigned long long* g_stamps = nullptr;
 // timing experiments: 4 tiles x 16 phase stamps of wave 0 of workgroup 3 (valid after a launch with SDY_MLP_STAMPS set)
-extern "C" int sdy_mlp_h3_debug_stamps(unsigned long long* host64) {
+SDY_DEBUG_EXPORT int sdy_mlp_h3_debug_stamps(unsigned long long* host64) {
   if (!g_stamps || !host64) return SDY_ERR_STATE;
   SDY_HIP_TRY(hipDeviceSynchronize());
   SDY_HIP_TRY(hipMemcpy(host64, g_stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SDY_OK;
 }
+#endif
 
 extern "C" int sdy_mlp_h3_supported(int E, int hidden) { return (E == ME && hidden == MH) ? 1 : 0; }
 
@@ -832,7 +868,20 @@ extern "C" int sdy_mlp_h3_pack(const float* w1_host, const float* w2_host, int E
   return SDY_OK;
 }
 
+#endif   // !SDY_MLP_INJECT_TU
+
+// (defined by the translation unit mlp_h3_inject.hip: the same launch code around the INJECT instantiation)
+int sdy_mlp_h3_inject(const sdy_mlp_args* a, void* stream);
+
+#ifdef SDY_MLP_INJECT_TU
+int sdy_mlp_h3_inject(const sdy_mlp_args* a, void* stream) {
+#else
 extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
+  if (a && (a->keep_hidden || a->keep_out)) {   // injected masks (tests): both or neither, and only with dropout on
+    if (!a->keep_hidden || !a->keep_out || !(a->drop_p > 0.0f)) return SDY_ERR_ARG;
+    return sdy_mlp_h3_inject(a, stream);
+  }
+#endif
   if (!a || !a->x || !a->w || !a->b1 || !a->b2 || !a->out) return SDY_ERR_ARG;
   if (a->B <= 0 || a->HW <= 0) return SDY_ERR_ARG;
   if (!sdy_mlp_h3_supported(a->E, a->hidden)) return SDY_ERR_UNSUPPORTED;
@@ -861,12 +910,15 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   p.rows_per_call = a->rows_per_call > 0 ? a->rows_per_call : a->B;
   p.batch_scale = a->batch_scale;
   p.stats = a->stats;
+  p.keep_h = a->keep_hidden; p.keep_o = a->keep_out;
   SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;
+#if SDY_STAMPS_ON && !defined(SDY_MLP_INJECT_TU)
   if (std::getenv("SDY_MLP_STAMPS")) {
     if (!g_stamps) SDY_HIP_TRY(hipMalloc(&g_stamps, 64 * sizeof(unsigned long long)));
     p.stamps = g_stamps;
   }
+#endif
   int n_cu = 0;
   SDY_TRY(sdy_cu_count(&n_cu));
   const long ntiles = (long)((a->HW + TN - 1) / TN) * a->B;
@@ -875,6 +927,14 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   static SdyOncePerDevice once;
   std::atomic<bool>* attr_done = nullptr;
   SDY_TRY(once.slot(&attr_done));
+#ifdef SDY_MLP_INJECT_TU
+  if (!*attr_done) {
+    SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel<true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    *attr_done = true;
+  }
+  hipLaunchKernelGGL((mlp_h3_kernel<true, true>), grid, dim3(256), smem, (hipStream_t)stream, p);
+#else
   if (!*attr_done) {
     SDY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_h3_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -886,5 +946,6 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
     hipLaunchKernelGGL(mlp_h3_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(mlp_h3_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, p);
+#endif
   return sdy_launch_status();
 }

@@ -37,7 +37,7 @@ constexpr int PHC = 128;       // hidden channels per chunk
 constexpr int PKSC = PHC / 16; // k-steps of fc2 per chunk
 constexpr int PRING = 16;
 constexpr int PGROUP = 2 * 64; // f16x8 elements per group (hi | lo)
-constexpr float PSX = 16.0f;   // activation pre-scale
+constexpr float PSX = SDY_ACT_SX;   // activation pre-scale
 
 template <int KSP, int NPART, int MO>
 struct PairCfg {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
     const bool full = n0 + PTN <= p.HW;
     const int tile_it = tile - t_begin;
     auto stamp = [&](int i) {
-      if (p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= 2 && tile_it < 6)
+      if (SDY_STAMPS_ON && p.stamps && blockIdx.x == 3 && tid == 0 && tile_it >= 2 && tile_it < 6)
         p.stamps[(tile_it - 2) * 16 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
@@ -649,14 +649,16 @@ int launch(const PairParams& p, hipStream_t stream) {
 
 }  // namespace
 
+#if SDY_STAMPS_ON
 static unsigned long long* g_pair_stamps = nullptr;
 // timing experiments: 4 tiles x 16 phase stamps of wave 0 of workgroup 3 (valid after a launch with SDY_PAIR_STAMPS set)
-extern "C" int sdy_pair_h3_debug_stamps(unsigned long long* host64) {
+SDY_DEBUG_EXPORT int sdy_pair_h3_debug_stamps(unsigned long long* host64) {
   if (!g_pair_stamps || !host64) return SDY_ERR_STATE;
   SDY_HIP_TRY(hipDeviceSynchronize());
   SDY_HIP_TRY(hipMemcpy(host64, g_pair_stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SDY_OK;
 }
+#endif
 
 extern "C" int sdy_pair_h3_supported(int Cin, int hidden, int Cout) {
   Shape s;
@@ -709,10 +711,12 @@ extern "C" int sdy_pair_h3(const sdy_pair_args* a, void* stream) {
   p.s2 = 1.0f / (a->w2_scale * PSX);
   p.stats = a->stats;
   SDY_TRY(sdy_flags_ptr(&p.flags));
+#if SDY_STAMPS_ON
   if (std::getenv("SDY_PAIR_STAMPS")) {
     if (!g_pair_stamps) SDY_HIP_TRY(hipMalloc(&g_pair_stamps, 64 * sizeof(unsigned long long)));
     p.stamps = g_pair_stamps;
   }
+#endif
 #define LN(K, P, M) return launch<K, P, M>(p, (hipStream_t)stream)
   PAIR_DISPATCH(s, LN);
 #undef LN

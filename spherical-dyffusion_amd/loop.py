@@ -111,17 +111,28 @@ class WindowStitcher:
         self._carry_gen: Optional[Dict[str, torch.Tensor]] = None        # name -> (rows, H, W)
 
     def append(self, data: Mapping[str, torch.Tensor], gen_data: Mapping[str, torch.Tensor], batch_times=None,
-               last_state: Optional[Mapping[str, torch.Tensor]] = None, start_sample: int = 0) -> None:
-        """`last_state`: name -> (rows, H, W), the last generated state of every trajectory of the device batch."""
+               last_state: Optional[Mapping[str, torch.Tensor]] = None, start_sample: int = 0,
+               defer_write: bool = False) -> Optional[Callable[[], None]]:
+        """`last_state`: name -> (rows, H, W), the last generated state of every trajectory of the device batch.
+        `defer_write=True`: the carry-over is taken now, the hand-off to the writer is RETURNED as a callable instead of
+        made -- the window driver calls it once the window's status word has come back clean, so a window a kernel flagged
+        (fp16 range / non-finite) never reaches the writer."""
         n_time = next(iter(data.values())).shape[1]
-        self.writer.append_batch(target=data, prediction=gen_data, start_timestep=self.i_time, start_sample=start_sample,
-                                 batch_times=batch_times)
+        writer, i_time = self.writer, self.i_time
+
+        def write():
+            writer.append_batch(target=data, prediction=gen_data, start_timestep=i_time, start_sample=start_sample,
+                                batch_times=batch_times)
+
+        if not defer_write:
+            write()
         self.i_time += n_time
         if self.i_time < self.n_forward_steps:      # only store if needed
             self._carry_target = {k: v[:, -1].detach().clone() for k, v in data.items()}
             src = last_state if last_state is not None else {k: v[..., -1, :, :].reshape(-1, *v.shape[-2:])
                                                              for k, v in gen_data.items()}
             self._carry_gen = {k: v.detach().clone() for k, v in src.items()}
+        return write if defer_write else None
 
     def apply_initial_condition(self, batch: Mapping[str, torch.Tensor], ic_rows: Optional[torch.Tensor] = None) -> None:
         """`batch` tensors are (rows, n_time, H, W), one row per trajectory; `ic_rows[r]` = initial condition (row of the
@@ -203,14 +214,22 @@ class _WindowPrefetcher:
                 v.record_stream(cur)      # allocated on the side stream, used (and released) on the compute stream
             yield window, win
 
-    def close(self):
+    def close(self, timeout: float = 10.0):
+        """Stops the loader thread.  A loader blocked inside `next()` cannot be interrupted: after `timeout` seconds the
+        (daemon) thread is abandoned with a warning, so that an exception pending in the caller still propagates."""
         self._stop = True
+        deadline = time.time() + timeout
         while self.thread.is_alive():
             try:
                 self.q.get_nowait()
             except queue.Empty:
                 pass
             self.thread.join(timeout=0.05)
+            if time.time() > deadline:
+                import warnings
+                warnings.warn("sdy_amd.run_inference: the window loader did not return within "
+                              f"{timeout:.0f} s of the stop request; abandoning its daemon thread")
+                break
 
 
 def _sync_windows(loader, dev: torch.device):
@@ -262,7 +281,11 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
     reference stacks them: `(members, n_sample, time, H, W)`.
 
     `prefetch`: windows pulled ahead of the compute on a background thread (0 = pull each window on the calling thread, after
-    the previous one has been handed to the writer, as the reference's loop does without DataLoader workers).
+    the previous one has been handed to the writer, as the reference's loop does without DataLoader workers).  THREADING
+    CONTRACT of `prefetch > 0` (the default): the loader is iterated from ONE non-main daemon thread -- it must not depend on
+    thread-local or main-thread-only state (torch's default generator, netCDF4 / HDF5 handles opened on the main thread,
+    the current CUDA device); pass `prefetch=0` for such a loader.  Window i is handed to the writer / aggregator while
+    window i + 1 computes, and only once its status word has come back clean: a flagged window raises before it is written.
     `max_batch`: at most this many trajectories per device batch; a larger share runs as consecutive chunks of the same
     window (each with its own `batch_offset`, so every trajectory still draws the stream of its global index) whose outputs
     are concatenated -- bounds the network workspace (about 0.9 GB per trajectory at 180 x 360, E = 256)."""
@@ -289,12 +312,16 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
     pending = None             # the previous window's record_batch, issued once ITS loss has arrived (no drain of this one)
 
     def flush(p):
+        # A window reaches the writer and the aggregator only after its loss terms and the device's sticky status word have
+        # arrived: a window a kernel flagged (fp16 range overflow, non-finite statistics) raises HERE, before either sees it.
         if p is None:
             return
-        out, i_time_agg, weights = p
+        out, i_time_agg, weights, write = p
+        loss = float(out.metrics["loss"])      # waits for the window's read-back; raises SdyError on a flagged window
+        write()
         kw = {"sample_weights": weights} if (weights is not None and getattr(aggregator, "accepts_sample_weights", False)) \
             else {}
-        aggregator.record_batch(loss=float(out.metrics["loss"]), target_data=out.target_data, gen_data=out.gen_data,
+        aggregator.record_batch(loss=loss, target_data=out.target_data, gen_data=out.gen_data,
                                 target_data_norm=out.target_data_norm, gen_data_norm=out.gen_data_norm,
                                 i_time_start=i_time_agg, **kw)
 
@@ -378,9 +405,11 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
                 i_time_agg = i_time + 1
             else:
                 i_time_agg = i_time
-            stitcher.append(out.target_data, out.gen_data, times, last_state=last_state, start_sample=start if flat else 0)
+            # the carry-over for window i + 1 is taken now; the hand-off to the writer waits for the window's status word
+            write = stitcher.append(out.target_data, out.gen_data, times, last_state=last_state,
+                                    start_sample=start if flat else 0, defer_write=True)
             flush(pending)         # window i - 1: its loss arrived long ago; the device is busy with window i meanwhile
-            pending = (out, i_time_agg, weights)
+            pending = (out, i_time_agg, weights, write)
             if prefetch <= 0:
                 flush(pending)
                 pending = None

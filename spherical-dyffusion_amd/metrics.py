@@ -172,6 +172,9 @@ class TimeMeanAggregator:
     def time_mean_maps(self) -> Dict[str, Dict[str, torch.Tensor]]:
         """{"gen": {name: (H, W)}, "target": {...}}: time means so far over every rank's trajectories, on the device."""
         if self._n_batches == 0:
+            # (raised BEFORE any collective: every rank of a job must have recorded at least one window -- a rank without a
+            # share would leave the others waiting in reduce_sum; shard with ensemble.partition, which gives every rank of
+            # world <= trajectories a non-empty share)
             raise ValueError("No data recorded.")
 
         def red(d, rows):

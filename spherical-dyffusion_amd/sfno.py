@@ -154,7 +154,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
 
         self._native: Dict[int, C.c_void_p] = {}   # device index -> sdy_sfno*
         self._native_dirty = True
-        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._ws: Dict[Optional[int], torch.Tensor] = {}     # device index -> workspace (grow-only)
 
     # ---- state_dict with the reference's names ------------------------------------------------------------
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
@@ -307,11 +307,17 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         return self._native[idx]
 
     def _workspace(self, h, device, B):
-        key = (device.index, B)
-        if key not in self._ws:
-            n = lib.sdy_sfno_workspace_floats(h, B)
-            self._ws[key] = torch.empty(n, dtype=torch.float32, device=device)
-        return self._ws[key]
+        """ONE workspace per device, sized for the largest batch seen so far (the native call lays the buffer out for its own
+        B and only needs `ws_floats >= sdy_sfno_workspace_floats(B)`): ragged shards, `max_batch` chunks and the 2B rows of
+        a stacked interpolator pair share it instead of pinning a multi-GB buffer each.  Forwards of one network are issued
+        from one host thread on one stream at a time (the same contract a per-batch cache had for equal batches)."""
+        n = int(lib.sdy_sfno_workspace_floats(h, B))
+        ws = self._ws.get(device.index)
+        if ws is None or ws.numel() < n:
+            self._ws.pop(device.index, None)     # the smaller buffer goes back to the caching allocator first
+            del ws
+            self._ws[device.index] = torch.empty(n, dtype=torch.float32, device=device)
+        return self._ws[device.index]
 
     def __del__(self):
         try:
@@ -375,37 +381,41 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                 raise _lib.SdyError(f"batch {B} > {max_b} rows per native call cannot be split with stacked calls / injected masks")
             n_chunks = -(-B // max_b)
             step = -(-B // n_chunks)
-            call0, off0, outs = self._call, self.batch_offset, []
-            try:
-                for r0 in range(0, B, step):
-                    r1 = min(B, r0 + step)
-                    self._call, self.batch_offset = call0, off0 + r0
-                    outs.append(self.forward(inputs[r0:r1], time=None if tt is None else tt[r0:r1],
-                                             condition=None if condition is None else condition[r0:r1],
-                                             static_condition=None if static_condition is None else static_condition[r0:r1]))
-            finally:
-                self.batch_offset = off0
-            self._call = call0 + 1
-            return torch.cat(outs, dim=0)
-        ws = self._workspace(h, dev, B)
+            out = torch.empty(B, self.out_chans, nlat, nlon, dtype=torch.float32, device=dev)
+            for r0 in range(0, B, step):       # the prepared pieces are sliced: no second pass through the checks above
+                r1 = min(B, r0 + step)
+                self._native_call(h, dev, [t[r0:r1] for t in pieces], None if tt is None else tt[r0:r1], out[r0:r1],
+                                  self._call, self.batch_offset + r0)
+            self._call += 1                    # only once every chunk has been enqueued: a failed chunk leaves the counter alone
+            return out
         out = torch.empty(B, self.out_chans, nlat, nlon, dtype=torch.float32, device=dev)
+        n_calls = 1
+        if rows_per_call is not None:
+            assert rows_per_call >= 1 and B % rows_per_call == 0, f"rows_per_call={rows_per_call} must divide the batch {B}"
+            assert keep_masks is None and drop_path_keep is None and self.mask_injector is None, \
+                "injected masks address one call per forward"
+            n_calls = B // int(rows_per_call)
+        if keep_masks is None and drop_path_keep is None and self.mask_injector is not None and self.inference_dropout:
+            keep_masks, drop_path_keep = self.mask_injector(self._call)
+        self._native_call(h, dev, pieces, tt, out, self._call, self.batch_offset, rows_per_call, keep_masks, drop_path_keep)
+        self._call += n_calls
+        return out
+
+    def _native_call(self, h, dev, pieces, tt, out, call: int, batch_offset: int, rows_per_call: Optional[int] = None,
+                     keep_masks=None, drop_path_keep=None) -> None:
+        """One sdy_sfno_forward on prepared (fp32, contiguous-per-row) inputs; `out` is a (B, out_chans, nlat, nlon) view."""
+        B = out.shape[0]
+        ws = self._workspace(h, dev, B)
         a = SdySfnoFwdArgs()
         for i in range(3):
             a.in_[i] = ptr(pieces[i]) if i < len(pieces) else None
             a.in_chans[i] = pieces[i].shape[1] if i < len(pieces) else 0
         a.time, a.out, a.B = ptr(tt), ptr(out), B
         a.enable_dropout = int(self.inference_dropout)
-        a.seed, a.call, a.batch_offset = self.seed, self._call & 0xFFFFFFFF, self.batch_offset
-        n_calls = 1
+        a.seed, a.call, a.batch_offset = self.seed, call & 0xFFFFFFFF, batch_offset
         if rows_per_call is not None:
-            assert rows_per_call >= 1 and B % rows_per_call == 0, f"rows_per_call={rows_per_call} must divide the batch {B}"
-            assert keep_masks is None and drop_path_keep is None and self.mask_injector is None, \
-                "injected masks address one call per forward"
             a.rows_per_call = int(rows_per_call)
-            n_calls = B // int(rows_per_call)
         keep = []
-        if keep_masks is None and drop_path_keep is None and self.mask_injector is not None and self.inference_dropout:
-            keep_masks, drop_path_keep = self.mask_injector(self._call)
         if keep_masks is not None:
             arr = (C.c_void_p * (2 * self.num_layers))()
             for j, m in enumerate(keep_masks):
@@ -423,8 +433,6 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         a.ws, a.ws_floats = ptr(ws), ws.numel()
         with torch.cuda.device(dev):
             check(lib.sdy_sfno_forward(h, C.byref(a), current_stream()), "sdy_sfno_forward")
-        self._call += n_calls
-        return out
 
     def predict_forward(self, *inputs, metadata=None, **kwargs):      # _base_model.py:265-270
         return self(*inputs, **kwargs)

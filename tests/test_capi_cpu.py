@@ -24,6 +24,13 @@ def test_header_symbols_are_exported_and_bound(sdy):
     lib = C.CDLL(sdy.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/sdy_amd.h but not exported"
+    # ... and nothing else: the product library is built with -fvisibility=hidden behind csrc/exports.map, and the in-kernel
+    # stamp read-backs (sdy_*_debug_stamps) exist in -DSDY_STAMPS measurement builds only
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", sdy.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, f"exported but not declared: {sorted(exported - declared)}; missing: {sorted(declared - exported)}"
     from sdy_amd import _lib
 
     assert declared == set(_lib.SIGNATURES), sorted(declared ^ set(_lib.SIGNATURES))

@@ -74,8 +74,11 @@ HOT = ("mlp_h3_kernel", "conv_h3_kernel", "leg_par_kernel", "dh_h3_kernel", "rff
 
 
 def test_hot_kernels_do_not_spill(kernels):
-    hot = {n: k for n, k in kernels.items() if any(h in n for h in HOT)}
+    # (mlp_h3_kernel<true, true> is the test-only instantiation that reads injected dropout masks, csrc/mlp_h3_inject.hip:
+    #  never on a timed path, allowed to spill)
+    hot = {n: k for n, k in kernels.items() if any(h in n for h in HOT) and "mlp_h3_kernelILb1ELb1E" not in n}
     assert len(hot) >= 12, sorted(hot)
+    assert sum("mlp_h3_kernel" in n for n in hot) == 2, sorted(hot)
     spilled = {n: k[".private_segment_fixed_size"] for n, k in hot.items() if k[".private_segment_fixed_size"] != 0}
     assert not spilled, f"kernels with scratch (register spills): {spilled}"
 

@@ -74,8 +74,7 @@ def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=36
                 wdw.data = {k: v[ic_lo:ic_lo + n_ic] for k, v in wdw.data.items()}
             yield wdw
 
-    if cnt == 0:
-        return {"steps": steps, "members": members, "rows": 0}
+    assert cnt > 0, "every rank has a share (main() rejects world > ics x members)"
     if warmup:   # one untimed window: native objects, weight upload and the workspace are created on first use (~8 s)
         sdy_amd.run_inference(None, stepper, loader(1, 7), window, window, **kw)
     if dist is not None and world > 1:
@@ -142,6 +141,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: all ranks on GPU 0 with the gloo backend (exercises the N>1 path on a 1-GPU box)")
     a = ap.parse_args()
+    if a.gpus > a.ics * a.members:
+        # a rank with an empty share would skip the barrier and the aggregator's reduce_sum collectives the others enter
+        raise SystemExit(f"--gpus {a.gpus} exceeds the job's {a.ics * a.members} trajectories (ics x members): every rank needs a share")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_children(a.gpus))
 
