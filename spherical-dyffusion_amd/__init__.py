@@ -15,6 +15,6 @@ from .sfno import SphericalFourierNeuralOperatorNet  # noqa: F401
 from .sht import InverseRealSHT, RealSHT  # noqa: F401
 from .stepper import MultiStepStepper, Prescriber, SteppedData  # noqa: F401
 from .loop import NullAggregator, NullDataWriter, WindowStitcher, run_inference  # noqa: F401
-from . import checkpoint, ensemble, metrics, normalizer, ops, synthetic  # noqa: F401
+from . import checkpoint, ensemble, interface, metrics, normalizer, ops, synthetic  # noqa: F401
 
 __version__ = "0.1.0"

@@ -110,10 +110,27 @@ def _build_net(model_config: Mapping[str, Any], n_in: int, n_out: int, n_cond: i
     return net
 
 
-def module_from_state(state: Mapping[str, Any], interpolator_state: Mapping[str, Any], spatial_shape: Tuple[int, int],
+def resolve_interpolator_state(state: Mapping[str, Any], interpolator_state: Optional[Mapping[str, Any]] = None):
+    """The interpolator's checkpoint as `DYffusion.__init__` finds it (`src/diffusion/dyffusion.py:612-630` ->
+    `get_checkpoint_from_path_or_wandb`, `src/interface.py:193-222`): an explicit one wins; otherwise the forecaster's
+    `diffusion_config.interpolator_local_checkpoint_path` is loaded from disk.  A wandb run id alone cannot be resolved here
+    (no network on this path): download the file and pass its path or its contents."""
+    if interpolator_state is not None:
+        return interpolator_state
+    dc = _plain(_plain(state["hyper_parameters"]).get("diffusion_config"))
+    path = dc.get("interpolator_local_checkpoint_path")
+    if isinstance(path, str) and path:
+        return torch.load(path, map_location="cpu", weights_only=False)
+    raise ValueError("no interpolator checkpoint: pass `interpolator_state`, or set "
+                     "diffusion_config.interpolator_local_checkpoint_path to the interpolator's .ckpt "
+                     f"(interpolator_run_id={dc.get('interpolator_run_id')!r} needs wandb access, which this path does not have)")
+
+
+def module_from_state(state: Mapping[str, Any], interpolator_state: Optional[Mapping[str, Any]], spatial_shape: Tuple[int, int],
                       use_ema: Optional[bool] = None, interpolator_use_ema: Optional[bool] = None,
                       device="cuda", **net_kwargs) -> MultiHorizonForecastingDYffusion:
     """The sampling module (`module_class(**hyper_parameters)` + `load_state_dict`, stepper_multistep.py:241-245,207-209)."""
+    interpolator_state = resolve_interpolator_state(state, interpolator_state)
     hp, ihp = _plain(state["hyper_parameters"]), _plain(interpolator_state["hyper_parameters"])
     dm, dc = _plain(hp["datamodule_config"]), _plain(hp["diffusion_config"])
     in_names, out_names, forcing = list(dm["in_names"]), list(dm["out_names"]), list(dm.get("forcing_names", []))
@@ -130,10 +147,12 @@ def module_from_state(state: Mapping[str, Any], interpolator_state: Mapping[str,
     diffusion = {k: v for k, v in dc.items() if k not in ("_target_", "interpolator", "interpolator_run_id",
                                                           "interpolator_local_checkpoint_path",
                                                           "interpolator_wandb_ckpt_filename")}
-    return MultiHorizonForecastingDYffusion(fnet, ipol, horizon=horizon, diffusion_config=diffusion)
+    return MultiHorizonForecastingDYffusion(fnet, ipol, horizon=horizon, diffusion_config=diffusion,
+                                            num_predictions=int(hp.get("num_predictions", 1) or 1),
+                                            inputs_noise=float(hp.get("inputs_noise", 0.0) or 0.0))
 
 
-def stepper_from_state(state: Mapping[str, Any], interpolator_state: Mapping[str, Any], means: Mapping[str, float],
+def stepper_from_state(state: Mapping[str, Any], interpolator_state: Optional[Mapping[str, Any]], means: Mapping[str, float],
                        stds: Mapping[str, float], spatial_shape: Tuple[int, int], overrides: Optional[Dict[str, Any]] = None,
                        **kw) -> MultiStepStepper:
     """`MultiStepStepper.from_state` (stepper_multistep.py:228-295): module + packers (names) + prescriber + normaliser."""

@@ -6,6 +6,10 @@ Mirrors what `run_inference.py`'s stepper calls on the module
   * `MultiHorizonForecastingDYffusion.get_preds_at_t_for_batch` (`src/experiment_types/forecasting_multi_horizon.py:331-381`)
   * `BaseExperiment.predict / _predict / predict_packed / ema_scope / inference_dropout_scope`
     (`src/experiment_types/_base_experiment.py:386-423,473-572`)
+and the Lightning-driven entry (`src/interface.py:302-313` -> `trainer.predict`): `predict_step` / `on_predict_epoch_end` /
+`_evaluation_get_preds` (`_base_experiment.py:1083-1102,906-919`) over the autoregressive loop of `_evaluation_step`
+(`src/experiment_types/forecasting_multi_horizon.py:139-320`), for batches that are already packed and normalised;
+`interface.run_inference` drives it without Lightning.
 Same method names, argument meaning, returned keys (`t{h}_preds_normed`), and the same statefulness
 (`_current_preds` cache: not re-entrant).  Un-normalisation/unpacking needs the datamodule's statistics, which are
 outside the hot-path scope: without a datamodule the reference, too, returns only the
@@ -112,7 +116,8 @@ class MultiHorizonForecastingDYffusion(_BaseExperiment):
     inputs_data_key = "dynamics"
 
     def __init__(self, forecaster_net, interpolator: InterpolationExperiment, horizon: int, window: int = 1,
-                 enable_inference_dropout: bool = False, diffusion_config: Optional[dict] = None, **kw):
+                 enable_inference_dropout: bool = False, diffusion_config: Optional[dict] = None,
+                 inputs_noise: float = 0.0, **kw):
         diffusion_config = dict(diffusion_config or {})
         diffusion_config.setdefault("timesteps", horizon)
         sampler = DYffusion(model=forecaster_net, interpolator=interpolator, **diffusion_config)
@@ -123,6 +128,8 @@ class MultiHorizonForecastingDYffusion(_BaseExperiment):
         forecaster_net.set_min_max_time(min_time=rng[0], max_time=rng[-1])
         self._prediction_timesteps = None
         self._current_preds: Optional[Dict[str, Tensor]] = None
+        self._predict_step_outputs: List[Dict[str, np.ndarray]] = []
+        self.inputs_noise = float(inputs_noise)      # _base_experiment.py:66: std of the members' input perturbation
 
     @property
     def horizon_range(self) -> List[int]:
@@ -158,19 +165,133 @@ class MultiHorizonForecastingDYffusion(_BaseExperiment):
     def set_dropout_calls(self, state) -> None:
         self.model.model._call, self.model.interpolator.model._call = int(state[0]), int(state[1])
 
+    # ---- Lightning predict surface (src/interface.py:302-313 -> trainer.predict -> predict_step) -------------------------
+    def use_ensemble_predictions(self, split: str = "predict") -> bool:       # _base_experiment.py:845-846
+        return self.num_predictions > 1 and split in ("val", "test", "predict")
+
+    def get_ensemble_inputs(self, inputs_raw: Optional[Tensor], split: str = "predict", add_noise: bool = True):
+        """`_base_experiment.py:851-890` for tensors: the batch of `num_predictions` copies, member-major `(N B) ...`; with
+        `inputs_noise` > 0 every copy gets its own Gaussian perturbation (drawn by torch on the device: plumbing)."""
+        if inputs_raw is None or not self.use_ensemble_predictions(split):
+            return inputs_raw
+        n = self.num_predictions
+        if add_noise and self.inputs_noise > 0:
+            copies = [inputs_raw + self.inputs_noise * torch.randn_like(inputs_raw) for _ in range(n)]
+        else:
+            copies = [inputs_raw] * n
+        return torch.stack(copies, dim=0).flatten(0, 1)
+
+    def get_inputs_and_extra_kwargs(self, batch: Dict[str, Tensor], split: str = "predict", ensemble: bool = False,
+                                    is_autoregressive: bool = False):
+        """`forecasting_multi_horizon.py:383-455` for PACKED, NORMALISED tensors (the datamodule's packing and statistics are
+        outside the path): the first `window` steps of `dynamics` stacked on the channel axis, replicated
+        per member unless the batch already is the members' autoregressive state; `static_condition` replicated;
+        `dynamical_condition` passed whole (the sampler picks the times, :494-498) and replicated."""
+        dyn = batch[self.inputs_data_key]
+        inputs = dyn[:, : self.window].flatten(1, 2)
+        if ensemble and not is_autoregressive:
+            inputs = self.get_ensemble_inputs(inputs, split)
+        extra = {}
+        for k, v in batch.items():
+            if k == self.inputs_data_key or k == "metadata":
+                continue
+            if k in ("static_condition", "dynamical_condition"):
+                extra[k] = self.get_ensemble_inputs(v, split, add_noise=False) if ensemble else v
+            else:
+                raise ValueError(f"Unsupported key {k} in batch")
+        return inputs, extra
+
+    def predict_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, dataloader_idx: Optional[int] = None,
+                     prediction_horizon: Optional[int] = None, return_outputs: str = "all") -> Dict[str, np.ndarray]:
+        """`BaseExperiment.predict_step` (`_base_experiment.py:1083-1096`) -> `evaluation_step` (:807-832: EMA and
+        inference-dropout scopes) -> `_evaluation_step` (`forecasting_multi_horizon.py:139-320`): the autoregressive loop
+        over `prediction_horizon` steps in chunks of the training horizon, `num_predictions` ensemble members batched on the
+        device.  `batch`: `dynamics` (B, >= window + prediction_horizon, C, H, W) ALREADY packed and normalised (targets are
+        read from it), optional `dynamical_condition` (B, >= prediction_horizon + 1, Cc, H, W) / `static_condition`.
+        Returns numpy arrays like the reference: `t{k}_preds_normed` (N, B, C, H, W) for an ensemble, (B, C, H, W)
+        otherwise, and `t{k}_targets_normed` (B, C, H, W); `on_predict_epoch_end` concatenates the batches."""
+        split = "predict"
+        if self.window != 1:
+            raise NotImplementedError("predict_step: window > 1 is not on the sampling path (shipped configs: window 1)")
+        batch = dict(batch)
+        dyn_full = batch[self.inputs_data_key]
+        if not dyn_full.is_cuda:
+            raise RuntimeError("sdy_amd predict_step runs on the GPU only (no CPU fallback); move the batch to cuda")
+        H = self.true_horizon
+        if prediction_horizon is None:
+            prediction_horizon = getattr(self.hparams, "prediction_horizon", None) or H
+        if dyn_full.shape[1] < prediction_horizon:
+            raise ValueError(f"Prediction horizon {prediction_horizon} is larger than {tuple(dyn_full.shape)}[1]")
+        dynamic_conds = batch.pop("dynamical_condition", None)
+        n_outer = -(-int(prediction_horizon) // H)          # num_autoregressive_steps_for_horizon(...) + 1
+        batch[self.inputs_data_key] = dyn_full[:, : self.window + H]
+        ens = self.use_ensemble_predictions(split)
+        out: Dict[str, np.ndarray] = {}
+        to_np = lambda t: None if t is None else t.detach().cpu().numpy()   # noqa: E731
+        with self.ema_scope(), self.inference_dropout_scope():
+            for ar_step in range(n_outer):
+                ar_window_steps = []
+                for t_step in self.prediction_timesteps:
+                    total = ar_step * H + t_step
+                    if total > prediction_horizon:
+                        break
+                    if dynamic_conds is not None:     # ar_step 0 -> slice(0, H + 1), 1 -> slice(H, 2 H + 1), ...
+                        batch["dynamical_condition"] = dynamic_conds[:, ar_step * H:(ar_step + 1) * H + 1]
+                    res = self.get_preds_at_t_for_batch(batch, t_step, split, is_autoregressive=ar_step > 0, ensemble=True)
+                    preds = res.pop(f"t{t_step}_preds_normed")
+                    target_time = self.window + int(total) - 1
+                    target = dyn_full[:, target_time] if target_time < dyn_full.shape[1] else None
+                    if return_outputs in (True, "all"):
+                        out[f"t{total}_targets_normed"] = to_np(target)
+                    out[f"t{total}_preds_normed"] = to_np(preds)
+                    if t_step == self.horizon_range[-1]:
+                        ar_init = res.pop("preds_autoregressive_init_normed", preds)
+                        if ens:
+                            ar_init = ar_init.flatten(0, 1)
+                        ar_window_steps.append(ar_init)
+                if ar_step < n_outer - 1:
+                    batch[self.inputs_data_key] = torch.stack(ar_window_steps, dim=1)
+        self._current_preds = None
+        self._predict_step_outputs.append(out)
+        return out
+
+    def _evaluation_get_preds(self, outputs, split: str = "predict") -> Dict[str, np.ndarray]:
+        """`_base_experiment.py:906-919`: the batches' results concatenated along the batch axis (axis 1 for ensemble
+        predictions, whose leading axis is the member)."""
+        if isinstance(outputs, list) and len(outputs) == 1 and isinstance(outputs[0], list):
+            outputs = outputs[0]
+        ens = self.use_ensemble_predictions(split)
+        res = {}
+        for key in outputs[0].keys():
+            axis = 1 if (ens and "targets" not in key and "true" not in key) else 0
+            vals = [o[key] for o in outputs]
+            res[key] = None if any(v is None for v in vals) else np.concatenate(vals, axis=axis)
+        return res
+
+    def on_predict_epoch_end(self) -> Dict[str, np.ndarray]:                 # _base_experiment.py:1098-1102
+        results = self._evaluation_get_preds(self._predict_step_outputs, split="predict")
+        self._predict_step_outputs = []
+        return results
+
     def get_preds_at_t_for_batch(self, batch: Dict[str, Tensor], horizon, split: str = "predict", ensemble: bool = False,
                                  is_autoregressive: bool = False, prepare_inputs: bool = True, **kwargs):
         """forecasting_multi_horizon.py:331-381 (cache_preds branch: DYffusion predicts all horizons at once)."""
         assert 0 < horizon <= self.true_horizon, f"horizon={horizon} must be in [1, {self.true_horizon}]"
         if horizon == self.prediction_timesteps[0]:
-            if prepare_inputs:
-                raise NotImplementedError("prepare_inputs=True needs the datamodule (out of scope); the stepper "
-                                          "calls with prepare_inputs=False (stepper_multistep.py:389-397)")
-            batch = dict(batch)
-            inputs = batch.pop(self.inputs_data_key)
+            if prepare_inputs:     # packed, normalised tensors (the datamodule's packing is outside the path)
+                inputs, extra = self.get_inputs_and_extra_kwargs(batch, split=split, ensemble=ensemble,
+                                                                 is_autoregressive=is_autoregressive)
+            else:                  # what the stepper does (stepper_multistep.py:389-397)
+                extra = dict(batch)
+                inputs = extra.pop(self.inputs_data_key)
             kwargs.pop("num_predictions", None)
             with torch.inference_mode():
-                self._current_preds = self.predict(inputs, **batch, **kwargs)
+                self._current_preds = self.predict(inputs, **extra, **kwargs)
+                if prepare_inputs and self.use_ensemble_predictions(split):
+                    # reshape_predictions (_base_experiment.py:892-904): (N B) ... -> N B ...
+                    n = self.num_predictions
+                    self._current_preds = {k: v.reshape(n, v.shape[0] // n, *v.shape[1:])
+                                           for k, v in self._current_preds.items()}
         assert self._current_preds is not None, "call with horizon == prediction_timesteps[0] first"
         preds_key = f"t{horizon}_preds"
         results = {k: self._current_preds.pop(k) for k in list(self._current_preds.keys()) if preds_key in k}

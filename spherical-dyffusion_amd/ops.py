@@ -197,10 +197,12 @@ def mlp_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Ten
               pre_affine=None, add: Optional[torch.Tensor] = None, drop_p: float = 0.0, seed: int = 0, call: int = 0,
               stream_fc1: int = 0, stream_fc2: int = 1, batch_offset: int = 0,
               batch_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              prepared=None, add_affine=None, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+              prepared=None, add_affine=None, stats: Optional[torch.Tensor] = None,
+              keep_masks=None) -> torch.Tensor:
     """The block's MLP (`src/models/sfno/layers.py:73-80`) with the norm affine, both dropouts, DropPath scale and the
     residual add in one launch (include/sdy_amd.h, sdy_mlp_h3).  Same arithmetic and dropout stream as
-    conv1x1(fc1, gelu, stream_fc1) -> conv1x1(fc2, stream_fc2, add_mode=2)."""
+    conv1x1(fc1, gelu, stream_fc1) -> conv1x1(fc2, stream_fc2, add_mode=2).  `keep_masks=(hidden mask (B, hidden, H, W),
+    output mask (B, E, H, W))` (tests): 0/1 keep decisions replace the Philox stream, as `keep_mask` does in conv1x1."""
     x = _f32c(x)
     B, E, H, W = x.shape
     if prepared is None:
@@ -237,6 +239,11 @@ def mlp_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Ten
     if stats is not None:       # (B, E, 2) float64 on the device, zeroed by the caller: (sum, sumsq) of `out` are added
         assert stats.dtype == torch.float64 and stats.is_cuda and stats.is_contiguous() and stats.numel() == B * E * 2
         a.stats = ptr(stats)
+    if keep_masks is not None:
+        kh, ko = _aux(keep_masks[0], x.device), _aux(keep_masks[1], x.device)
+        assert kh.numel() == B * hidden * H * W and ko.numel() == B * E * H * W
+        a.keep_hidden, a.keep_out = ptr(kh), ptr(ko)
+        keep += [kh, ko]
     with torch.cuda.device(x.device):
         check(lib.sdy_mlp_h3(C.byref(a), current_stream()), "sdy_mlp_h3")
     return out

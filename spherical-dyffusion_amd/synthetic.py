@@ -83,7 +83,8 @@ def build_network(n_in: int, n_out: int, n_cond: int, *, nlat: int = 180, nlon: 
 
 def build_sampler(device, *, state_chans: int = 63, forcing_chans: int = 2, nlat: int = 180, nlon: int = 360, embed: int = 256,
                   layers: int = 8, horizon: int = 6, carried_input_only_channel: bool = False,
-                  forecaster_seed: int = 4321, interpolator_seed: int = 4322, dropout_seed: int = 1000):
+                  forecaster_seed: int = 4321, interpolator_seed: int = 4322, dropout_seed: int = 1000,
+                  gemm_mode: Optional[str] = None):
     """Forecaster + interpolator + DYffusion sampler of the shipped configuration (`src/configs/diffusion/dyffusion.yaml`,
     `experiment/fv3gfs_interpolation.yaml:18-23`: interpolator dropout 0.1 / drop path 0.1 ON at inference, forecaster
     without).  `carried_input_only_channel`: the published checkpoints' layout, one input-only variable (HGTsfc) in front of
@@ -91,10 +92,10 @@ def build_sampler(device, *, state_chans: int = 63, forcing_chans: int = 2, nlat
     cs = state_chans + (1 if carried_input_only_channel else 0)
     with torch.cuda.device(device):
         fnet = build_network(cs, state_chans, forcing_chans, nlat=nlat, nlon=nlon, embed=embed, layers=layers,
-                             time_range=(0.0, horizon - 1.0), weight_seed=forecaster_seed)
+                             time_range=(0.0, horizon - 1.0), weight_seed=forecaster_seed, gemm_mode=gemm_mode)
         inet = build_network(2 * cs, state_chans, forcing_chans, nlat=nlat, nlon=nlon, embed=embed, layers=layers,
                              dropout_mlp=0.1, drop_path_rate=0.1, time_range=(1.0, horizon - 1.0),
-                             weight_seed=interpolator_seed, dropout_seed=dropout_seed)
+                             weight_seed=interpolator_seed, dropout_seed=dropout_seed, gemm_mode=gemm_mode)
     cfg = dict(hack_for_imprecise_interpolation=True) if carried_input_only_channel else None
     exp = MultiHorizonForecastingDYffusion(fnet, InterpolationExperiment(inet, horizon=horizon), horizon=horizon,
                                            diffusion_config=cfg)

@@ -65,3 +65,25 @@ def mask_fn_from(d):
             return None
         return m.reshape(-1, 1, 1, 1) if kind == "drop_path" else m
     return fn
+
+
+def seeded_case(z):
+    """Fixtures that store SEEDS instead of weights / inputs (the full-width ones: fx_sfno_full, fx_sfno_wide_masks):
+    -> (cfg, n_in, n_cond, state_dict, x, cond, time), rebuilt with the generators tools/gen_golden.py used and checked
+    against the checksums the generating run stored, so a drift of torch's CPU generator cannot pass as a parity failure."""
+    import numpy as np
+
+    from oracle.sfno import make_state_dict
+
+    cfg, n_in, n_cond = cfg_from(z)
+    sd = make_state_dict(cfg, seed=int(z["seed_w"]))
+    dig = np.array([float(sum(v.double().abs().sum() for v in sd.values())),
+                    float(sum((v.double() ** 2).sum() for v in sd.values()))])
+    assert np.allclose(dig, z["weights_digest"], rtol=1e-9), "make_state_dict(seed) no longer reproduces the fixture's weights"
+    B = z["y"].shape[0]
+    g = torch.Generator(device="cpu").manual_seed(int(z["seed_x"]))
+    x = torch.randn(B, n_in, cfg.nlat, cfg.nlon, generator=g)
+    cond = torch.randn(B, n_cond, cfg.nlat, cfg.nlon, generator=g)
+    idig = np.array([float(x.double().abs().sum()), float(cond.double().abs().sum())])
+    assert np.allclose(idig, z["inputs_digest"], rtol=1e-9), "the seeded inputs no longer reproduce the fixture's"
+    return cfg, n_in, n_cond, sd, x, cond, torch.from_numpy(z["time"])

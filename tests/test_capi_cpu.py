@@ -120,3 +120,38 @@ def test_element_dropout_stream_definition():
         assert mask.reshape(B, C, H * W)[b, c, pix] == (1.0 if half >= thr else 0.0)
     # the two pixels of a pair come from the same call: flipping bit 5 changes only the half-word
     assert 0.05 < 1.0 - mask.mean() < 0.25
+
+
+def test_dropout_streams_are_independent_across_members_kinds_calls_and_layers():
+    """The documented stream (include/sdy_amd.h), as the device replays it bit for bit (tests/test_gpu_sfno.py): keep rates
+    match p, and the decisions of different trajectories, of the hidden / output dropout of one layer, of consecutive calls
+    and of different layers are uncorrelated (|r| < 4 / sqrt(n)) -- what 25 ensemble members sharing one (seed, call) need in
+    order to be independent samples (reference: independent draws of torch's generator, layers.py:76-78, drop_path.py:19)."""
+    from oracle.philox import drop_path_keep, element_keep_mask
+
+    seed, p, C, H, W = 0x5EED_1234, 0.1, 32, 16, 64
+    n = C * H * W
+    mem = element_keep_mask(seed, 3, 2, 0, p, 25, C, H, W, batch_offset=0).reshape(25, -1)      # 25 members, one call
+    assert np.all(np.abs(mem.mean(1) - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n))
+    r = np.corrcoef(mem)
+    off = r[~np.eye(25, dtype=bool)]
+    assert np.abs(off).max() < 4.5 / np.sqrt(n), f"members correlate: max |r| {np.abs(off).max():.4f}"
+    # a rank's rows draw the streams of their GLOBAL trajectory index: rows 7.. of a whole-job batch == batch_offset = 7
+    part = element_keep_mask(seed, 3, 2, 0, p, 5, C, H, W, batch_offset=7).reshape(5, -1)
+    assert np.array_equal(part, mem[7:12])
+
+    def corr(a, b):
+        return abs(float(np.corrcoef(a.reshape(-1), b.reshape(-1))[0, 1]))
+
+    base = element_keep_mask(seed, 3, 2, 0, p, 2, C, H, W)
+    for other in (element_keep_mask(seed, 3, 2, 1, p, 2, C, H, W),      # output dropout of the same layer
+                  element_keep_mask(seed, 4, 2, 0, p, 2, C, H, W),      # next call
+                  element_keep_mask(seed, 3, 3, 0, p, 2, C, H, W),      # next layer
+                  element_keep_mask(seed + 1, 3, 2, 0, p, 2, C, H, W)):  # another seed
+        assert corr(base, other) < 4.5 / np.sqrt(2 * n)
+        assert not np.array_equal(base, other)
+    # drop path: per-trajectory flags at the documented rate, independent of the layer / call
+    dp = np.stack([drop_path_keep(seed, c, l, 0.3, 4096) for c in range(2) for l in range(2)])
+    assert np.all(np.abs(dp.mean(1) - 0.7) < 4 * np.sqrt(0.21 / 4096))
+    rr = np.corrcoef(dp)
+    assert np.abs(rr[~np.eye(4, dtype=bool)]).max() < 4.5 / np.sqrt(4096)

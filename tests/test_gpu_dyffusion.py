@@ -454,3 +454,131 @@ def test_stepper_autoregressive_init_handoff():
         {k: v.cuda() for k, v in data.items()}, None, n_forward_steps=T1 - 1)
     assert rel_l2(out2.gen_data["v0"][:, :7], gen["v0"][:, :7]) < TOL
     assert rel_l2(out2.gen_data["v0"][:, 7:], gen["v0"][:, 7:]) > 1e-3
+
+
+def test_ensemble_statistics_match_torch_drawn_dropout():
+    """Distributional parity of the stochastic interpolator: the product draws its dropout / drop-path
+    decisions from its own Philox stream, the reference from torch's generator (src/models/sfno/layers.py:76-78,
+    src/models/modules/drop_path.py:15-22, enabled at inference by src/diffusion/dyffusion.py:226-235) -- the two can only
+    agree in distribution.  One horizon-6 sampling pass, 25 members of ONE initial condition:
+      product : 25 rows, dropout stream of trajectory b = row b (batch_offset 0), the HIP path;
+      oracle  : the same pass with Bernoulli(1 - p) masks drawn by torch's CPU generator, independently per member.
+    Per (lead time, channel, pixel) the two 25-member ensembles give a mean and a spread; if both sample the same
+    distribution,  z = (mean_p - mean_o) / sqrt((s_p^2 + s_o^2) / 25)  is ~ N(0, 1) and log(s_p^2 / s_o^2) has mean ~ 0 and
+    standard deviation ~ sqrt(4 / 24) = 0.41.  Bounds (pixels are spatially correlated, so they are loose, but a keep rate of
+    0.8 instead of 0.9, a missing 1 / (1 - p), members sharing a stream, or a dead drop path all violate them -- checked
+    below by running the statistics on deliberately wrong ensembles)."""
+    M, horizon = 25, 6
+    exp, oracle, cs, n_forc = _build(hack=True, dropout=True)
+    g = torch.Generator(device="cpu").manual_seed(321)
+    x0 = torch.randn(1, cs, 32, 64, generator=g).expand(M, -1, -1, -1).contiguous()
+    forc = torch.randn(1, n_forc, 32, 64, generator=g).expand(M, -1, -1, -1).contiguous()
+    exp.set_batch_offset(0)
+    got = exp.model.sample(x0.cuda(), static_condition=forc.cuda())
+
+    icfg = oracle._masks.cfg
+    tg = torch.Generator(device="cpu").manual_seed(2024)
+
+    def torch_masks(kind, layer, shape):          # what nn.Dropout / DropPath draw: independent Bernoulli keeps
+        if kind == "drop_path":
+            rate = icfg.drop_path_rates[layer]
+            return (torch.rand(shape[0], generator=tg) >= rate).float().reshape(-1, 1, 1, 1)
+        return (torch.rand(shape, generator=tg) >= icfg.dropout_mlp).float()
+
+    _, fora, _ = make_pair(SFNOConfig(in_chans=cs + n_forc, out_chans=6, nlat=32, nlon=64, embed_dim=16, num_layers=2,
+                                      with_time_emb=True, min_time=0.0, max_time=5.0), cs, n_forc, seed=11)
+    _, iora, _ = make_pair(icfg, 2 * cs, n_forc, seed=22)
+
+    def sample_with(mask_fn):
+        o = OracleDYffusion(lambda x, time, condition=None, static_condition=None: fora(
+            x, time=time, condition=condition, static_condition=static_condition),
+            lambda x, time, condition=None, static_condition=None: iora(
+                x, time=time, condition=condition, static_condition=static_condition, mask_fn=mask_fn),
+            timesteps=horizon, hack_for_imprecise_interpolation=True)
+        return o.sample(x0, static_condition=forc)
+
+    ref = sample_with(torch_masks)
+
+    def stats(a, b):
+        """a, b: (M, C, H, W) ensembles -> (mean z, std z, share of |z| > 3, mean log variance ratio)"""
+        a, b = a.double().cpu(), b.double().cpu()
+        va, vb = a.var(0, unbiased=True), b.var(0, unbiased=True)
+        z = (a.mean(0) - b.mean(0)) / ((va + vb) / M).sqrt().clamp_min(1e-30)
+        lr = (va.clamp_min(1e-30) / vb.clamp_min(1e-30)).log()
+        return float(z.mean()), float(z.std()), float((z.abs() > 3).double().mean()), float(lr.mean())
+
+    for k in ("t1_preds", "t3_preds", "t6_preds"):
+        zm, zs, tail, lr = stats(got[k], ref[k])
+        spread = float(got[k].double().std(0).mean())
+        assert spread > 1e-3, f"{k}: the members do not diverge (spread {spread:.2e})"
+        assert abs(zm) < 0.15, f"{k}: ensemble means differ, mean z {zm:.3f}"
+        assert 0.75 < zs < 1.3, f"{k}: z-scores not unit-width, std {zs:.3f}"
+        assert tail < 0.03, f"{k}: {tail:.3%} of the z-scores beyond 3 sigma"
+        assert abs(lr) < 0.15, f"{k}: ensemble spreads differ, mean log variance ratio {lr:.3f}"
+
+    # the statistic has teeth: ensembles that are wrong in the ways an implementation can be wrong fail the same bounds
+    def wrong_keep(kind, layer, shape):           # keep rate 0.8 instead of 0.9 (element dropout only)
+        if kind == "drop_path":
+            return torch_masks(kind, layer, shape)
+        return (torch.rand(shape, generator=tg) >= 0.2).float()
+
+    def shared_stream(kind, layer, shape):        # every member draws the SAME element masks
+        if kind == "drop_path":
+            return torch_masks(kind, layer, shape)
+        m = (torch.rand((1,) + tuple(shape[1:]), generator=tg) >= icfg.dropout_mlp).float()
+        return m.expand(shape).contiguous()
+
+    zm, zs, tail, lr = stats(sample_with(wrong_keep)["t6_preds"], ref["t6_preds"])
+    assert abs(lr) > 0.15 or abs(zm) > 0.15 or not (0.75 < zs < 1.3), ("a wrong keep rate passes the bounds", zm, zs, lr)
+    zm, zs, tail, lr = stats(sample_with(shared_stream)["t6_preds"], ref["t6_preds"])
+    assert abs(lr) > 0.15, ("members sharing their element masks pass the spread bound", lr)
+
+
+def test_predict_step_and_interface_run_inference():
+    """The Lightning-driven entry without Lightning (reference: src/interface.py:302-313 -> trainer.predict ->
+    _base_experiment.py:1083-1102 -> forecasting_multi_horizon.py:139-320): `predict_step` over two autoregressive windows
+    equals the oracle's sampler chained by hand; with `num_predictions` = 3 the members are batched on the device, come back
+    as (N, B, ...) and differ through their dropout streams; `interface.run_inference` drives a datamodule's batches and
+    concatenates them along the batch axis."""
+    import numpy as np
+
+    import sdy_amd
+
+    exp, oracle, cs, n_forc = _build(hack=False, dropout=False)
+    g = torch.Generator(device="cpu").manual_seed(77)
+    B, H, PH = 2, 6, 12
+    dynamics = torch.randn(B, 1 + PH, cs, 32, 64, generator=g)
+    dcond = torch.randn(B, PH + 1, n_forc, 32, 64, generator=g)
+    out = exp.predict_step({"dynamics": dynamics.cuda(), "dynamical_condition": dcond.cuda()}, 0, prediction_horizon=PH)
+    assert sorted(k for k in out if "preds" in k) == sorted(f"t{k}_preds_normed" for k in range(1, PH + 1))
+    first = oracle.sample(dynamics[:, 0], dynamical_condition=dcond[:, :H + 1])
+    second = oracle.sample(first[f"t{H}_preds"], dynamical_condition=dcond[:, H:2 * H + 1])
+    for k in range(1, PH + 1):
+        ref = first[f"t{k}_preds"] if k <= H else second[f"t{k - H}_preds"]
+        assert isinstance(out[f"t{k}_preds_normed"], np.ndarray) and out[f"t{k}_preds_normed"].shape == (B, 6, 32, 64)
+        assert rel_l2(torch.from_numpy(out[f"t{k}_preds_normed"]), ref) < 2e-5, f"t{k}"
+        assert np.array_equal(out[f"t{k}_targets_normed"], dynamics[:, k].numpy())
+    exp.on_predict_epoch_end()
+
+    # ensemble: members batched, (N, B, ...) results, dropout streams per trajectory
+    exp, _, cs, n_forc = _build(hack=False, dropout=True)
+    exp.num_predictions = 3
+    res = exp.predict_step({"dynamics": dynamics.cuda(), "dynamical_condition": dcond.cuda()}, 0, prediction_horizon=PH)
+    p = res["t12_preds_normed"]
+    assert p.shape == (3, B, 6, 32, 64) and np.isfinite(p).all()
+    assert np.abs(p[0] - p[1]).max() > 1e-3 and res["t12_targets_normed"].shape == (B, 6, 32, 64)
+    exp.on_predict_epoch_end()
+
+    class DM:          # what run_inference needs of a LightningDataModule
+        def setup(self, stage):
+            self.stage = stage
+
+        def predict_dataloader(self):
+            for i in range(2):
+                yield {"dynamics": dynamics[i:i + 1, :1 + H], "dynamical_condition": dcond[i:i + 1, :H + 1]}
+
+    exp.set_dropout_calls((0, 0))
+    merged = sdy_amd.interface.run_inference(exp, DM())
+    assert merged["t6_preds_normed"].shape == (3, 2, 6, 32, 64)          # batches concatenated on axis 1 (members lead)
+    assert merged["t6_targets_normed"].shape == (2, 6, 32, 64)
+    assert exp._predict_step_outputs == []

@@ -32,11 +32,15 @@ def _build(layers, seed_i=1000):
     return exp, fnet, inet, fora, iora, icfg
 
 
-def test_c3_full_size_sampling_pass_with_dropout_vs_oracle():
+@pytest.mark.parametrize("layers", [2, 8])
+def test_c3_full_size_sampling_pass_with_dropout_vs_oracle(layers):
     """BASELINE.json configs[2]: one horizon-6 DYffusion sampling pass, 180x360, E = 256, B = 1, interpolator dropout and
-    drop path ON.  2 blocks (first + last: both grid changes) keep the CPU oracle at about two minutes; width, grid and
-    every kernel variant are the production ones.  Bound: north_star's 1e-4 relative L2, and the 2e-5 fp32 expectation."""
-    exp, fnet, inet, fora, iora, icfg = _build(layers=2)
+    drop path ON, against the oracle replaying the same Philox stream.  layers = 8: the production depth -- sixteen chained
+    8-block forwards (6 forecaster + 10 interpolator), i.e. the error growth of the whole sampling pass is bounded against
+    the oracle, not only a single forward's (the oracle needs about 5 s per forward on the GPU box's host cores).
+    layers = 2 (first + last block: both grid changes) is the quick version.  Bound: north_star's 1e-4 relative L2, and
+    the 2e-5 fp32 expectation."""
+    exp, fnet, inet, fora, iora, icfg = _build(layers=layers)
     masks = PhiloxMasks(icfg, seed=1000)
     n = {"i": 0}
 

@@ -81,6 +81,43 @@ def test_network_vs_reference_with_recorded_dropout():
     assert err < TOL_TIGHT, f"rel L2 {err:.3e}"
 
 
+def test_full_size_network_vs_reference():
+    """The HIP path against the REFERENCE network's own output at production size -- 180 x 360, E = 256, hidden 512, all 8
+    blocks, 68 + 2 -> 34 channels (BASELINE.json configs[1]; tests/golden/fx_sfno_full.npz, written by tools/gen_golden.py
+    from src/models/sfno/sfnonet.py:797-841 run on CPU).  No oracle in between: reference vectors on `mlp_h3`, `conv_h3`,
+    `dh_h3`, `leg_par`, `fft360` and `pair_h3`."""
+    z = gu.load("fx_sfno_full")
+    cfg, n_in, n_cond, sd, x, cond, t = gu.seeded_case(z)
+    net = _net(cfg, n_in, n_cond, sd)
+    y = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
+    assert torch.isfinite(y).all()
+    err = rel_l2(y, _t(z, "y"))
+    assert err < TOL, f"full size vs reference: rel L2 {err:.3e} (north_star bound 1e-4)"
+    assert err < TOL_TIGHT, f"full size vs reference: rel L2 {err:.3e} (fp32 expectation)"
+    # and per output channel: no field hides behind the others' norm
+    ref = _t(z, "y")
+    worst = max(rel_l2(y[:, c], ref[:, c]) for c in range(ref.shape[1]))
+    assert worst < TOL, f"worst output channel rel L2 {worst:.3e}"
+
+
+def test_wide_network_vs_reference_with_recorded_dropout():
+    """E = 256 / hidden 512 (the fused MLP kernel's shape; small grid) with the masks the REFERENCE's nn.Dropout / DropPath
+    layers drew (src/models/sfno/layers.py:76-78, src/models/modules/drop_path.py:15-22) injected: they drive the fused
+    `mlp_h3` kernel (its INJECT instantiation: same code, mask tensors instead of the Philox stream) -- reference-generated
+    vectors on the dropout path of the production MLP kernel, no builder-defined stream on either side."""
+    z = gu.load("fx_sfno_wide_masks")
+    cfg, n_in, n_cond, sd, x, cond, t = gu.seeded_case(z)
+    net = _net(cfg, n_in, n_cond, sd)
+    y = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
+    assert rel_l2(y, _t(z, "y")) < TOL_TIGHT
+    net.mask_injector = _injector(gu.masks_per_forward(gu.recorded_masks(z), cfg), cfg)
+    net.enable_inference_dropout()
+    yd = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
+    err = rel_l2(yd, _t(z, "y_dropout"))
+    assert err < TOL_TIGHT, f"recorded masks through the fused MLP: rel L2 {err:.3e}"
+    assert rel_l2(_t(z, "y_dropout"), _t(z, "y")) > 1e-2      # the masks matter
+
+
 @pytest.mark.parametrize("name", ["fx_sample_tiny", "fx_sample_tiny_hack", "fx_sample_tiny_masks", "fx_sample_tiny_refine"])
 def test_sampler_vs_reference(name):
     import sdy_amd

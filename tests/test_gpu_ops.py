@@ -323,6 +323,38 @@ def test_mlp_fused_matches_fp64_and_unfused(sdy, B, H, W, drop):
     assert rel_l2(got, ref) < TOL_OP
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 8, 40), (1, 45, 64)])
+def test_mlp_fused_with_injected_masks(sdy, B, H, W):
+    """The fused MLP driven by INJECTED keep masks (sdy_mlp_args.keep_hidden / keep_out), drawn here by torch's own
+    `nn.functional.dropout` the way the reference's layers draw them (src/models/sfno/layers.py:76-78) -- no Philox anywhere:
+    the fused kernel's dropout plumbing (chain beside fc2, hidden tile in LDS, output dropout in the epilogue, 1 / (1 - p)
+    folded into the accumulator scales) against fp64, on full and ragged tiles."""
+    E, Hd, drop = 256, 512, 0.1
+    g = _gen(23)
+    F = torch.nn.functional
+    x = torch.randn(B, E, H, W, generator=g) * 1.3 + 0.2
+    w1 = torch.randn(Hd, E, 1, 1, generator=g) / np.sqrt(E)
+    b1 = 0.1 * torch.randn(Hd, generator=g)
+    w2 = torch.randn(E, Hd, 1, 1, generator=g) / np.sqrt(Hd)
+    b2 = 0.1 * torch.randn(E, generator=g)
+    res = torch.randn(B, E, H, W, generator=g)
+    torch.manual_seed(5)
+    k1 = (F.dropout(torch.ones(B, Hd, H, W), p=drop, training=True) != 0).float()
+    k2 = (F.dropout(torch.ones(B, E, H, W), p=drop, training=True) != 0).float()
+    assert 0.05 < 1 - float(k1.mean()) < 0.15
+    hid = F.gelu(F.conv2d(x.double(), w1.double(), b1.double())) * k1.double() / (1.0 - drop)
+    ref = F.conv2d(hid, w2.double(), b2.double()) * k2.double() / (1.0 - drop) + res.double()
+    got = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2, add=res.cuda(), drop_p=drop, keep_masks=(k1.cuda(), k2.cuda()))
+    err = rel_l2(got, ref)
+    assert err < TOL_OP, f"fused MLP with injected masks vs fp64: {err:.3e}"
+    # exactly the injected output mask: without the residual the zeros of the result are the zeros of k2
+    f0 = sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2, drop_p=drop, keep_masks=(k1.cuda(), k2.cuda())).cpu()
+    assert torch.equal(f0 == 0, k2 == 0)
+    # one mask without the other, or masks without dropout, is an argument error
+    with pytest.raises(sdy.SdyError):
+        sdy.ops.mlp_fused(x.cuda(), w1, b1, w2, b2, drop_p=0.0, keep_masks=(k1.cuda(), k2.cuda()))
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 65, 256, 8, 40), (3, 36, 256, 87, 96), (2, 130, 256, 45, 64), (1, 144, 256, 6, 36),
                                             (2, 321, 63, 8, 40), (3, 292, 34, 87, 96), (2, 386, 63, 45, 64), (1, 416, 64, 6, 36),
                                             (2, 17, 5, 6, 36)])

@@ -54,6 +54,30 @@ def test_network_with_recorded_dropout_masks():
     assert rel_l2(_t(z, "y_dropout"), _t(z, "y")) > 1e-2   # the masks matter
 
 
+def test_full_size_network_matches_reference():
+    """The oracle against the REFERENCE network's own output at production size: 180 x 360, E = 256, all 8 blocks,
+    68 + 2 -> 34 channels (tests/golden/fx_sfno_full.npz; weights and inputs from seeds, checksummed)."""
+    z = gu.load("fx_sfno_full")
+    cfg, n_in, n_cond, sd, x, cond, t = gu.seeded_case(z)
+    assert (cfg.nlat, cfg.nlon, cfg.embed_dim, cfg.num_layers) == (180, 360, 256, 8)
+    y = OracleSFNO(cfg, sd)(x, time=t, condition=cond)
+    err = rel_l2(y, _t(z, "y"))
+    assert err < 5e-6, f"full size: rel L2 {err:.3e}"
+
+
+def test_wide_network_with_recorded_dropout_masks():
+    """E = 256 / hidden 512 on the small grid with the masks the reference's nn.Dropout / DropPath layers drew."""
+    z = gu.load("fx_sfno_wide_masks")
+    cfg, n_in, n_cond, sd, x, cond, t = gu.seeded_case(z)
+    net = OracleSFNO(cfg, sd)
+    assert rel_l2(net(x, time=t, condition=cond), _t(z, "y")) < 5e-6
+    fwd = gu.masks_per_forward(gu.recorded_masks(z), cfg)
+    assert len(fwd) == 1 and ("drop_path", 2) in fwd[0]
+    y = net(x, time=t, condition=cond, mask_fn=gu.mask_fn_from(fwd[0]))
+    err = rel_l2(y, _t(z, "y_dropout"))
+    assert err < 5e-6, f"dropout: rel L2 {err:.3e}"
+
+
 def _sampler(z, masks=None):
     fcfg = SFNOConfig(**json.loads(str(z["fcfg"])))
     icfg = SFNOConfig(**json.loads(str(z["icfg"])))

@@ -128,6 +128,69 @@ def gen_sfno(tag, cfg, n_in, n_cond, B, times, seed, with_masks):
     print(f"{tag}: y std {float(y.std()):.4f}, saved")
 
 
+def _weights_digest(sd):
+    """Checksum of a seeded state_dict (the full-width fixtures store the SEED, not 100+ MB of weights): the test refuses
+    to compare if its own make_state_dict(seed) does not reproduce these numbers."""
+    return np.array([float(sum(v.double().abs().sum() for v in sd.values())),
+                     float(sum((v.double() ** 2).sum() for v in sd.values()))])
+
+
+def gen_sfno_full(tag="fx_sfno_full"):
+    """The REFERENCE network at production width on the production grid: 180 x 360, E = 256, hidden 512, 68 + 2 -> 34
+    channels, ALL 8 blocks (BASELINE.json configs[1] = the interpolator, whole): the first (equiangular -> Legendre-Gauss), six inner
+    (LG -> LG) and the last (LG -> equiangular), time embedding, B = 1, dropout off.  These
+    sizes reach every production kernel (`mlp_h3`, `conv_h3`, `dh_h3`, `leg_par`, `fft360`, `pair_h3`); the small fixtures
+    above only reach the generic tile kernels.  Stored: seeds, checksums of the seeded weights / inputs, and the
+    34 x 180 x 360 output of the reference (8.8 MB)."""
+    cfg = SFNOConfig(in_chans=70, out_chans=34, nlat=180, nlon=360, embed_dim=256, num_layers=8, with_time_emb=True,
+                     min_time=1.0, max_time=5.0)
+    seed_w, seed_x = 4321, 1234
+    net, sd = ref_net(cfg, 68, 2, seed_w)
+    g = torch.Generator(device="cpu").manual_seed(seed_x)
+    x = torch.randn(1, 68, cfg.nlat, cfg.nlon, generator=g)
+    cond = torch.randn(1, 2, cfg.nlat, cfg.nlon, generator=g)
+    t = torch.tensor([3.0])
+    with torch.no_grad():
+        y = net(x, time=t, condition=cond)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), y=y.numpy(), time=t.numpy(), seed_w=np.array(seed_w),
+                        seed_x=np.array(seed_x), weights_digest=_weights_digest(sd),
+                        inputs_digest=np.array([float(x.double().abs().sum()), float(cond.double().abs().sum())]),
+                        cfg=json.dumps({**cfg.__dict__, "n_in": 68, "n_cond": 2}))
+    print(f"{tag}: y std {float(y.std()):.4f}, |y| max {float(y.abs().max()):.3f}, saved")
+
+
+def gen_sfno_wide_masks(tag="fx_sfno_wide_masks"):
+    """The reference network at production WIDTH (E = 256, hidden 512: the fused MLP kernel's shape) on the small grid, with
+    dropout and drop path ON and the masks its nn.Dropout / DropPath layers drew recorded -- injected into the product, they
+    drive the fused `mlp_h3` kernel with the reference's own random decisions (no Philox on either side).  3 blocks, B = 2."""
+    cfg = SFNOConfig(in_chans=10, out_chans=6, nlat=32, nlon=64, embed_dim=256, num_layers=3, with_time_emb=True,
+                     dropout_mlp=0.1, drop_path_rate=0.3, min_time=0.0, max_time=5.0)
+    seed_w, seed_x = 4321, 1234
+    net, sd = ref_net(cfg, 8, 2, seed_w)
+    g = torch.Generator(device="cpu").manual_seed(seed_x)
+    x = torch.randn(2, 8, cfg.nlat, cfg.nlon, generator=g)
+    cond = torch.randn(2, 2, cfg.nlat, cfg.nlon, generator=g)
+    t = torch.tensor([1.0, 4.0])
+    with torch.no_grad():
+        y = net(x, time=t, condition=cond)
+    net.enable_inference_dropout()
+    rec = MaskRecorder(net)
+    torch.manual_seed(777)
+    with torch.no_grad():
+        yd = net(x, time=t, condition=cond)
+    rec.remove()
+    out = dict(y=y.numpy(), y_dropout=yd.numpy(), time=t.numpy(), seed_w=np.array(seed_w), seed_x=np.array(seed_x),
+               weights_digest=_weights_digest(sd),
+               inputs_digest=np.array([float(x.double().abs().sum()), float(cond.double().abs().sum())]),
+               cfg=json.dumps({**cfg.__dict__, "n_in": 8, "n_cond": 2}), mask_names=json.dumps([n for n, _ in rec.records]))
+    for i, (_, m) in enumerate(rec.records):
+        out[f"mask{i}"] = pack(m)
+        out[f"mask{i}_shape"] = np.array(m.shape)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"{tag}: y std {float(y.std()):.4f}, dropout changes y by {float((yd - y).norm() / y.norm()):.3f}, "
+          f"{len(rec.records)} masks, saved")
+
+
 def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i, extra=None):
     import src.experiment_types._base_experiment as be
     from src.experiment_types.forecasting_multi_horizon import MultiHorizonForecastingDYffusion
@@ -517,5 +580,7 @@ if __name__ == "__main__":
     gen_metrics()
     gen_time_mean()
     gen_mean_series()
+    gen_sfno_wide_masks()
+    gen_sfno_full()
     sizes = {n: os.path.getsize(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT))}
     print(sizes)
