@@ -294,7 +294,8 @@ extern "C" int sdy_irfft_lon(const sdy_sht_plan* p, const float* Yf, const float
   return sdy_fft_launch_inv(p->fft, Yf, bias, y, B, C, p->nlat, p->mtr, 0, nullptr, (hipStream_t)stream);
 }
 
-static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream);
+static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream,
+                             bool tiled = false);
 extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, void* stream) {
   return legendre_fwd_impl(p, Xf, Cs, B, C, false, stream);
 }
@@ -305,7 +306,16 @@ static bool plan_polar_ok(const sdy_sht_plan* p, int C) {
                           std::getenv("SDY_NO_LEG_FRAG");
   return !off && p->d_kdead && p->d_wq_par && p->fft.n == 180 && C % 16 == 0;
 }
-static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream) {
+// Tile-major grid-frequency tensor (fft.h, ilv == 2): like the polar cut-off a contract between fft360 and leg_par only --
+// the plane of one order is stored as whole 64-column tiles, so a Legendre workgroup's activation tile is one contiguous
+// block.  SDY_NO_XF_TILED=1 keeps the row-major planes (A/B measurements).
+static bool plan_tiled_ok(const sdy_sht_plan* p, int C, int ilv) {
+  static const bool off = std::getenv("SDY_NO_XF_TILED") || std::getenv("SDY_NO_FFT360") || std::getenv("SDY_NO_LEG_PAR") ||
+                          std::getenv("SDY_NO_LEG_FRAG");
+  return !off && ilv == 1 && p->d_wq_par && p->d_pct_par && p->fft.n == 180 && C % 32 == 0;
+}
+static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream,
+                             bool tiled) {
   if (!p || !Xf || !Cs || B <= 0 || C <= 0) return SDY_ERR_ARG;
   if (C & 1) return SDY_ERR_ALIGN;
   const int N = 2 * B * C;
@@ -318,8 +328,10 @@ static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, 
   static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
   static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
   if (p->d_wq_par && !no_frag && !no_par)
-    return sdy_leg_par_launch(p->d_wq_par, p->s_wq_par, p->mtr, Xf, N, (long)p->nlat * N, Cs, (long)p->mtr * N, N, p->lmax,
-                              p->nlat, N, 1, polar ? p->d_kdead : nullptr, (hipStream_t)stream);
+    return sdy_leg_par_launch(p->d_wq_par, p->s_wq_par, p->mtr, Xf, tiled ? 64 : N, (long)p->nlat * N, Cs, (long)p->mtr * N, N,
+                              p->lmax, p->nlat, N, 1, polar ? p->d_kdead : nullptr, (hipStream_t)stream,
+                              tiled ? 64L * p->nlat : 0L, 0L);
+  if (tiled) return SDY_ERR_UNSUPPORTED;
   if (p->d_wq_frag && !no_frag)
     return sdy_leg_h3_launch(p->d_wq_frag, p->s_wq_frag, p->mtr, Xf, N, (long)p->nlat * N, Cs, (long)p->mtr * N, N, p->lmax,
                              p->nlat, N, SDY_TRI_LEG_FWD, (hipStream_t)stream);
@@ -329,11 +341,13 @@ static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, 
   return sdy_gemm_launch(g, (hipStream_t)stream);
 }
 
-static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, bool polar, void* stream);
+static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, bool polar, void* stream,
+                             bool tiled = false);
 extern "C" int sdy_legendre_inv(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, void* stream) {
   return legendre_inv_impl(p, Cs, Yf, B, C, false, stream);
 }
-static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, bool polar, void* stream) {
+static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, bool polar, void* stream,
+                             bool tiled) {
   if (!p || !Cs || !Yf || B <= 0 || C <= 0) return SDY_ERR_ARG;
   if (C & 1) return SDY_ERR_ALIGN;
   const int N = 2 * B * C;
@@ -346,8 +360,10 @@ static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, 
   static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
   static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
   if (p->d_pct_par && !no_frag && !no_par)
-    return sdy_leg_par_launch(p->d_pct_par, p->s_pct_par, p->mtr, Cs, (long)p->mtr * N, N, Yf, N, (long)p->nlat * N, p->nlat,
-                              p->lmax, N, 0, polar ? p->d_kdead : nullptr, (hipStream_t)stream);
+    return sdy_leg_par_launch(p->d_pct_par, p->s_pct_par, p->mtr, Cs, (long)p->mtr * N, N, Yf, tiled ? 64 : N,
+                              (long)p->nlat * N, p->nlat, p->lmax, N, 0, polar ? p->d_kdead : nullptr, (hipStream_t)stream,
+                              0L, tiled ? 64L * p->nlat : 0L);
+  if (tiled) return SDY_ERR_UNSUPPORTED;
   if (p->d_pct_frag && !no_frag)
     return sdy_leg_h3_launch(p->d_pct_frag, p->s_pct_frag, p->mtr, Cs, (long)p->mtr * N, N, Yf, N, (long)p->nlat * N, p->nlat,
                              p->lmax, N, SDY_TRI_LEG_INV, (hipStream_t)stream);
@@ -1124,12 +1140,13 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     have_st0 = false;
     // SpectralConvS2.forward (s2convolutions.py:158-193)
     const bool polar_in = plan_polar_ok(pin, E), polar_out = plan_polar_ok(pout, E);
+    const bool tiled_in = plan_tiled_ok(pin, E, ilv), tiled_out = plan_tiled_ok(pout, E, ilv);   // Xf / Yf tile-major (fft.h)
     SDY_STAGE(ST_FFT_FWD, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, B, E,
-                                             pin->nlat, pin->mtr, ilv, polar_in ? pin->d_mcut : nullptr, stream));
-    SDY_STAGE(ST_LEG_FWD, legendre_fwd_impl(pin, Xf, Cs, B, E, polar_in, stream));
+                                             pin->nlat, pin->mtr, tiled_in ? 2 : ilv, polar_in ? pin->d_mcut : nullptr, stream));
+    SDY_STAGE(ST_LEG_FWD, legendre_fwd_impl(pin, Xf, Cs, B, E, polar_in, stream, tiled_in));
     if (scale_residual) {  // residual = inverse_transform(forward_transform(x))
-      SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream));
-      SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, ilv,
+      SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream, tiled_out));
+      SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
                                                polar_out ? pout->d_mcut : nullptr, stream));
     }
     if (bw.fw.frag)
@@ -1138,8 +1155,8 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       SDY_STAGE(ST_DHCONV, sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     else
       SDY_STAGE(ST_DHCONV, sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
-    SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs2, Xf, B, E, polar_out, stream));
-    SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, ilv,
+    SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs2, Xf, B, E, polar_out, stream, tiled_out));
+    SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
                                              polar_out ? pout->d_mcut : nullptr, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
     conv_reset();

@@ -329,7 +329,7 @@ int sdy_leg_par_supported(int nlat, int lmax);
 size_t sdy_leg_par_table_bytes(int nz);
 int sdy_leg_par_pack(int nz, int nlat, int lmax, int fwd, sdy_leg_value_fn value, void* ctx, void* dev, float* scale);
 int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, long ldx, long sX, float* C, long ldc,
-                       long sC, int rows_out, int K, int N, int fwd, const int* kdead, hipStream_t stream);
+                       long sC, int rows_out, int K, int N, int fwd, const int* kdead, hipStream_t stream, long tsx = 0, long tsc = 0);
 int sdy_leg_h3_launch(const void* table, float scale, int nz, const float* X, long ldx, long sX, float* C, long ldc, long sC,
                       int M_store, int K, int N, int tri, hipStream_t stream);
 

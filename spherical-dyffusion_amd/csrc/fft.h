@@ -24,6 +24,10 @@ int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, 
 //   1: [c / 16][ri][16]   -- a workgroup's 16 channels x (re, im) form ONE 128-byte line instead of two 64-byte half
 //                            lines 4*C bytes apart (C % 16 == 0).  The Legendre stages are agnostic (flat columns); the
 //                            dhconv weights are packed for the same order (capi.hip).  Used inside the fused forward.
+//   2: TILE-MAJOR (fft360 + leg_par only): the channel order of 1, and the plane of one order m cut into column tiles of 64
+//      (two channel blocks x (re, im) x 16) that are stored whole, [m][tile j][k][64] instead of [m][k][2 B C] -- the
+//      Legendre kernel's activation tile (all latitudes x 64 columns of one order) is then ONE contiguous 46 KB block instead
+//      of 180 runs of 256 bytes 2 B C floats apart.  C % 32 == 0.  The generic kernels refuse it.
 // nlon = 360 specialisation (fft360.hip); SDY_ERR_UNSUPPORTED when the shape does not fit
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                           int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream);

@@ -436,7 +436,7 @@ int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, cons
     const int rc = sdy_fft360_launch_fwd(f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut, stream);
     if (rc != SDY_ERR_UNSUPPORTED) return rc;
   }
-  if (mcut) return SDY_ERR_UNSUPPORTED;   // the polar cut-off is a contract between fft360 and leg_par only
+  if (mcut || ilv == 2) return SDY_ERR_UNSUPPORTED;   // polar cut-off / tile-major layout: contracts between fft360 and leg_par only
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = 4;   // latitude rings per workgroup on the pipelined (compile-time size) paths
@@ -459,7 +459,7 @@ int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, 
     const int rc = sdy_fft360_launch_inv(f, Yf, bias, y, B, C, K, mtr, ilv, mcut, stream);
     if (rc != SDY_ERR_UNSUPPORTED) return rc;
   }
-  if (mcut) return SDY_ERR_UNSUPPORTED;
+  if (mcut || ilv == 2) return SDY_ERR_UNSUPPORTED;
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = 4;

@@ -243,6 +243,9 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
   const c2* zn2 = Z + c4 * P + max(NH - 128 - mg, 0);
   const long mstride = (long)K * B * 2 * C;
   const int re_off = (ilv ? 2 * c0 : c0) + 4 * c4, im_off = ilv ? 16 : C;   // see fft.h
+  // ilv == 2 (tile-major, fft.h): this workgroup's 128-byte line of ring k, order m sits at
+  //   m * mstride + (column tile j = (b * C/16 + c0/16) / 2) * K * 64 + k * 64 + (odd channel block ? 32 : 0)
+  const long tile_base = (long)((b * (C / ROWS) + id.x) >> 1) * K * 64 + (id.x & 1) * 32 + 4 * c4;
 
   f32x4 regs[8];
   auto gload = [&](int k) {
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
     __syncthreads();
 
     // ---- split step + m-major stores: X[m] = h (A + conj B) + W (A - conj B), A = Z[m], B = Z[n - m]
-    float* Xk = Xf + ((long)k * B + b) * 2 * C + re_off;
+    float* Xk = ilv == 2 ? Xf + tile_base + (long)k * 64 : Xf + ((long)k * B + b) * 2 * C + re_off;
     const int mlive = mcut ? min(mtr, mcut[k]) : mtr;   // polar cut-off: orders beyond it are never read downstream
 #pragma unroll
     for (int it = 0; it < MIT; ++it) {
@@ -339,9 +342,10 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
   const int c4 = threadIdx.x & 3, mg = threadIdx.x >> 2;
   const long mstride = (long)K * B * 2 * C;
   const int re_off = (ilv ? 2 * c0 : c0) + 4 * c4, im_off = ilv ? 16 : C;   // see fft.h
+  const long tile_base = (long)((b * (C / ROWS) + id.x) >> 1) * K * 64 + (id.x & 1) * 32 + 4 * c4;   // ilv == 2, as in the forward
   f32x4 rr[MIT], ri[MIT];
   auto gload = [&](int k) {
-    const float* Yk = Yf + ((long)k * B + b) * 2 * C + re_off;
+    const float* Yk = ilv == 2 ? Yf + tile_base + (long)k * 64 : Yf + ((long)k * B + b) * 2 * C + re_off;
     const int mlive = mcut ? min(mtr, mcut[k]) : mtr;   // polar cut-off: orders beyond it were never written (zero)
 #pragma unroll
     for (int it = 0; it < MIT; ++it) {
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                           int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
+  if (ilv == 2 && (C % (2 * ROWS) != 0 || ROWS != 16)) return SDY_ERR_UNSUPPORTED;   // a 64-column tile = two channel blocks
   constexpr int KPW = SDY_FFT_KPW;
   dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
   hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut);
@@ -422,6 +427,7 @@ int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, c
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
                           int mtr, int ilv, const int* mcut, hipStream_t stream) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
+  if (ilv == 2 && (C % (2 * ROWS) != 0 || ROWS != 16)) return SDY_ERR_UNSUPPORTED;   // a 64-column tile = two channel blocks
   constexpr int KPW = SDY_FFT_KPW;
   dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
   hipLaunchKernelGGL((irfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, Yf, bias, y, B, C, K, mtr, ilv, mcut);

@@ -39,6 +39,8 @@ struct ParParams {
   const f16x8* table;            // [nz][3 waves][PGPW groups: (k-step, E | O)][hi | lo][64 lanes]
   const float* X; long ldx, sX;  // input rows (latitudes / degrees) at X + z * sX + row * ldx, columns contiguous
   float* C; long ldc, sC;        // output rows at C + z * sC + row * ldc
+  long tsx, tsc;                 // != 0: that side is TILE-MAJOR (fft.h, ilv == 2): the workgroup's 64 columns start at
+                                 // blockIdx.x * ts instead of at column n0, and its rows are ld = 64 floats apart
   int rows_out, K, N;            // output rows stored, input rows, columns
   const int* kdead;              // polar cut-off per order (rows k' < kdead[m] and their mirrors are skipped) or nullptr
   float out_scale;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
   {
     const int q = tid & 15, o = tid >> 4;
     const bool ok = full || (n0 + 4 * q < p.N);
-    const float* xz = p.X + (long)z * p.sX;   // uniform
+    const float* xz = p.X + (long)z * p.sX + (p.tsx ? (long)blockIdx.x * p.tsx : (long)n0);   // uniform; column 0 of the tile
     f32x4 xa[8], xb[8];
     bool va[8], vb[8];   // lane masks (one SGPR pair each), computed once and used for the four pixels of the quad
     // analysis : xa = latitude 8 o + e, xb = its mirror K - 1 - (8 o + e) = (K - 8 - 8 o) + (7 - e)
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
     // the dead ones (uninitialised memory) are masked by SELECTS, never by a multiplication.
     const bool oct_live = FWD ? (8 * o + 7 >= kd && 8 * o < Kh) : (16 * o + 15 >= z && 16 * o < p.K);
     const bool oct_full = FWD ? true : (16 * o + 15 < p.K);   // synthesis: the last octet may reach past lmax
-    const unsigned colc = ok ? n0 + 4 * q : 0;
+    const unsigned colc = ok ? 4 * q : 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       xa[e] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
   // arithmetic on the wave index, running pointers) + a lane part that depends on h only.  Groups of four registers
   // (r >> 2) that lie inside the stored range take plain stores; a group that touches the edge (rows below m, the last
   // degrees / latitudes, a ragged column tile) is predicated with lane masks built from scalar compares.
-  float* cz = p.C + (long)z * p.sC + n0;   // uniform
+  float* cz = p.C + (long)z * p.sC + (p.tsc ? (long)blockIdx.x * p.tsc : (long)n0);   // uniform
   constexpr unsigned long long MH0 = 0x00000000FFFFFFFFull, MH1 = 0xFFFFFFFF00000000ull;   // lanes with h = 0 / h = 1
   unsigned long long colm[2];
 #pragma unroll
@@ -368,8 +370,9 @@ int sdy_leg_par_pack(int nz, int nlat, int lmax, int fwd, sdy_leg_value_fn value
 }
 
 int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, long ldx, long sX, float* C, long ldc,
-                       long sC, int rows_out, int K, int N, int fwd, const int* kdead, hipStream_t stream) {
+                       long sC, int rows_out, int K, int N, int fwd, const int* kdead, hipStream_t stream, long tsx, long tsc) {
   if (!table || !X || !C || nz <= 0 || N <= 0) return SDY_ERR_ARG;
+  if ((tsx || tsc) && N % PTN) return SDY_ERR_UNSUPPORTED;   // tile-major sides hold whole 64-column tiles
   if (rows_out > PM || K > PM || nz > PM) return SDY_ERR_UNSUPPORTED;
   if ((fwd ? K : rows_out) & 1) return SDY_ERR_UNSUPPORTED;
   if ((N & 3) || (ldx & 3) || (sX & 3) || (ldc & 3) || (sC & 3)) return SDY_ERR_ALIGN;
@@ -377,6 +380,7 @@ int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, l
   p.table = reinterpret_cast<const f16x8*>(table);
   p.X = X; p.ldx = ldx; p.sX = sX;
   p.C = C; p.ldc = ldc; p.sC = sC;
+  p.tsx = tsx; p.tsc = tsc;
   // 32-bit lane offsets: 96 input rows / 8 output rows of lane-dependent distance
   if ((long)PM * ldx * 4 + (long)N * 4 >= (1L << 32) || (long)8 * ldc * 4 + (long)N * 4 >= (1L << 32)) return SDY_ERR_UNSUPPORTED;
   p.rows_out = rows_out; p.K = K; p.N = N; p.kdead = kdead;

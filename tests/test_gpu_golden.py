@@ -110,7 +110,7 @@ def test_wide_network_vs_reference_with_recorded_dropout():
     net = _net(cfg, n_in, n_cond, sd)
     y = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
     assert rel_l2(y, _t(z, "y")) < TOL_TIGHT
-    net.mask_injector = _injector(gu.masks_per_forward(gu.recorded_masks(z), cfg), cfg)
+    net.mask_injector = _injector(gu.masks_per_forward(gu.recorded_masks(z), cfg), cfg, first_call=net._call)
     net.enable_inference_dropout()
     yd = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
     err = rel_l2(yd, _t(z, "y_dropout"))
