@@ -57,21 +57,6 @@ __device__ __forceinline__ void st4s(float* ubase, unsigned off_b, float v) {
   *reinterpret_cast<float __attribute__((address_space(1)))*>(b + off_b) = v;
 }
 
-// sdy_ld16s for the persistent kernel: its row bases are computed for the NEXT tile inside lane-dependent control flow, where
-// hipcc carries them around the tile loop in vector registers; v_readfirstlane returns the (wave-uniform) halves to the scalar
-// registers the SADDR form needs (without it: "illegal VGPR to SGPR copy", one per row base).
-__device__ __forceinline__ f32x4 ld16s_rf(const float* ubase, unsigned off_b) {
-  const unsigned long long a = (unsigned long long)ubase;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  return sdy_ld16s(reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo), off_b);
-}
-
-__device__ __forceinline__ void st4s_rf(float* ubase, unsigned off_b, float v) {   // (the same for the stores' row pointers)
-  const unsigned long long a = (unsigned long long)ubase;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  st4s(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), off_b, v);
-}
-
 // The kernel is bound by instruction ISSUE, not by HBM latency (tools/leg_stamps.py: with three workgroups per CU every
 // phase of a workgroup takes 2-3x its instruction count; two workgroups per CU: 1.3x slower, one: 2.3x).  So: the direction
 // is a template parameter, every global access is (uniform row base) + (one lane offset) -- no 64-bit lane arithmetic, no
@@ -317,271 +302,6 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
   stamp(5);
 }
 
-// PERSISTENT form (SDY_LEG_PERSIST=1; round 4 experiment): three workgroups per CU for the whole launch,
-// each walking the tiles t = blockIdx.x, + gridDim.x, ... (z-major numbering: a workgroup samples all orders, so the triangular
-// cost profile balances); the NEXT tile's 32 row loads are issued right after the MFMA loop -- when the table ring's registers
-// are dead -- and fly under the tile's 64 stores; the table ring of the next tile is requested once the accumulators have been
-// stored.  One more barrier per tile (the image is rewritten by the next split).
-template <bool FWD, int WGS>   // WGS workgroups per CU: 3 (168 registers: the prefetch spills) or 2 (256 registers)
-__global__ __launch_bounds__(192, WGS) void leg_par_persist_kernel(const ParParams p, const int ntx, const int ntiles, const int dz, const int dbx) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PTN * PKP * 2];   // 48 KB
-  _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
-  _Float16* Xs_lo = Xs_hi + PTN * PKP;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: row bases of the epilogue are scalar arithmetic
-  const int h = lane >> 5, l31 = lane & 31;
-  const int Kh = (FWD ? p.K : p.rows_out) >> 1;   // latitudes per hemisphere
-  const int q = tid & 15, o = tid >> 4;           // load / split roles: column quad q, octet o of the half
-  constexpr int PGROUP_BYTES = PGROUP * (int)sizeof(f16x8);
-
-  f32x4 xa[8], xb[8];
-  // the 16 + 16 row loads of tile (z, bx): exactly the addressing of leg_par_kernel
-  auto load_x = [&](int z, int bx) {
-    const int n0 = bx * PTN;
-    const bool ok = (n0 + PTN <= p.N) || (n0 + 4 * q < p.N);
-    // (inside the tile loop the cut-off table is read by a VECTOR load -- stores to C precede it, so hipcc cannot use the scalar
-    //  cache -- and its value must be returned to a scalar register by hand)
-    const int kd = p.kdead ? __builtin_amdgcn_readfirstlane(p.kdead[z]) : 0;
-    const int cE = z & 1, cO = cE ^ 1;
-    const float* xz = p.X + (long)z * p.sX + (p.tsx ? (long)bx * p.tsx : (long)n0);   // uniform; column 0 of the tile
-    const bool oct_live = FWD ? (8 * o + 7 >= kd && 8 * o < Kh) : (16 * o + 15 >= z && 16 * o < p.K);
-    const bool oct_full = FWD ? true : (16 * o + 15 < p.K);
-    const unsigned colc = ok ? 4 * q : 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      xa[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-      xb[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (oct_live) {
-      if (FWD) {
-        const unsigned offA = (unsigned)((long)(8 * o) * p.ldx + colc) * 4u;
-        const unsigned offB = (unsigned)((long)(p.K - 8 - 8 * o) * p.ldx + colc) * 4u;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xa[e] = ld16s_rf(xz + (long)e * p.ldx, offA);
-          xb[e] = ld16s_rf(xz + (long)(7 - e) * p.ldx, offB);
-        }
-      } else {
-        const unsigned off = (unsigned)((long)(16 * o) * p.ldx + colc) * 4u;
-        if (oct_full) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            xa[e] = ld16s_rf(xz + (long)(2 * e + cE) * p.ldx, off);
-            xb[e] = ld16s_rf(xz + (long)(2 * e + cO) * p.ldx, off);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            if (16 * o + 2 * e + cE < p.K) xa[e] = ld16s_rf(xz + (long)(2 * e + cE) * p.ldx, off);
-            if (16 * o + 2 * e + cO < p.K) xb[e] = ld16s_rf(xz + (long)(2 * e + cO) * p.ldx, off);
-          }
-        }
-      }
-    }
-  };
-
-  // Tile t = blockIdx.x + i * gridDim.x, as (order z, column tile bx) = (t / ntx, t % ntx) carried along in scalar registers:
-  // an integer division would run on the vector ALU and leave its result where the uniform row bases cannot take it from
-  // (hipcc: "illegal VGPR to SGPR copy"), so the step (dz, dbx) = (gridDim.x / ntx, gridDim.x % ntx) comes from the host.
-  int t = blockIdx.x;
-  if (t >= ntiles) return;   // (workgroup-uniform, before any barrier)
-  int z = 0, bx = t;
-  while (bx >= ntx) { bx -= ntx; ++z; }
-  load_x(z, bx);
-  for (; t < ntiles; t += (int)gridDim.x) {
-  const int n0 = bx * PTN;
-  const bool full = n0 + PTN <= p.N;
-  const int cE = z & 1, cO = cE ^ 1;            // degree l = 2 r + cE is an "E" degree (l + m even), 2 r + cO an "O" degree
-  const int kd = p.kdead ? __builtin_amdgcn_readfirstlane(p.kdead[z]) : 0;   // polar rows of this order (table < 1e-12 of its maximum there)
-  const bool wave_dead = FWD ? (64 * wave + 63 < z)       // analysis: all degrees of this wave are below m
-                             : (32 * wave + 31 < kd);     // synthesis: all latitudes of this wave are polar
-  const int ks0 = FWD ? kd >> 4 : z >> 5;                 // k-steps that contribute nothing: polar latitudes / degrees below m
-
-  // ---- table ring of this tile (slot = 2 * (k-step % 4) + half): requested behind the previous tile's stores
-  f16x8 r_hi[PRING], r_lo[PRING];
-  const char* const wbase = reinterpret_cast<const char*>(p.table) +
-                            (size_t)__builtin_amdgcn_readfirstlane(z * 3 + wave) * PGPW * PGROUP_BYTES;
-  unsigned woff = (unsigned)lane * 16u;
-  if (!wave_dead) {
-#pragma unroll
-    for (int s = 0; s < PRING; ++s) {
-      r_hi[s] = sdy_ring_ld(wbase, woff, 0);
-      r_lo[s] = sdy_ring_ld(wbase, woff, PGROUP_BYTES / 2);
-      woff += PGROUP_BYTES;
-    }
-  }
-
-  // ---- phase 0: the tile's rows (requested one tile ago) -> LDS halves; lane masks as in leg_par_kernel
-  {
-    // (laundered copies of the thread's roles: hipcc otherwise shares these comparisons with the ones load_x made for this tile
-    //  one iteration ago and carries them around the loop as lane-mask phis, which its i1 lowering cannot place: "illegal
-    //  VGPR to SGPR copy")
-    int qs = q, os = o;
-    asm volatile("" : "+v"(qs), "+v"(os));
-    const bool ok = full || (n0 + 4 * qs < p.N);
-    bool va[8], vb[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int r = 8 * os + e;
-      if (FWD) {
-        va[e] = vb[e] = ok && r < Kh && r >= kd;
-      } else {
-        va[e] = ok && 2 * r + cE < p.K && 2 * r + cE >= z;   // degrees below m were never written
-        vb[e] = ok && 2 * r + cO < p.K && 2 * r + cO >= z;
-      }
-    }
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {
-        f16x8 vh, vl;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (FWD) {
-            const float a = xa[e][pp], b = xb[e][pp];
-            v[e] = va[e] ? (hf == 0 ? a + b : a - b) * PSX : 0.0f;
-          } else {
-            v[e] = (hf == 0 ? va[e] : vb[e]) ? (hf == 0 ? xa[e][pp] : xb[e][pp]) * PSX : 0.0f;
-          }
-        }
-        sdy_split8(v, vh, vl);
-        const int off = pr_off(4 * q + pp, o + 12 * hf);
-        *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
-        *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
-      }
-    }
-  }
-  __syncthreads();
-  f32x16 acc[2][2];   // [half: E, O][column tile]
-  if (!wave_dead) {
-#pragma unroll
-  for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[hf][j][r] = 0.0f;
-
-#pragma unroll
-  for (int ks = 0; ks < PKS; ++ks) {
-    if (ks >= ks0) {
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        f16x8 bh[2], bl[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int off = pr_off(32 * j + l31, 12 * hf + 2 * ks + h);
-          bh[j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
-          bl[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
-        }
-        const int s = 2 * (ks & 3) + hf;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_lo[s], bh[j], acc[hf][j], 0, 0, 0));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) SDY_CROSS_TERM(acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bl[j], acc[hf][j], 0, 0, 0));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r_hi[s], bh[j], acc[hf][j], 0, 0, 0);
-      }
-    }
-    if (ks + 4 < PKS) {   // the ring holds 4 k-steps: refill the two slots just used with k-step ks + 4
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int s = 2 * (ks & 3) + hf;
-        r_hi[s] = sdy_ring_ld(wbase, woff, 0);     // group PRING + s: the stream front to back
-        r_lo[s] = sdy_ring_ld(wbase, woff, PGROUP_BYTES / 2);
-        woff += PGROUP_BYTES;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  }   // !wave_dead
-  __syncthreads();   // every wave has read the image for the last time: the next tile's split may overwrite it
-  {
-    const int tn = t + (int)gridDim.x;   // the next tile's rows: in flight under this tile's stores
-    int zn = z + dz, bxn = bx + dbx;
-    if (bxn >= ntx) { bxn -= ntx; ++zn; }
-    if (tn < ntiles) load_x(zn, bxn);
-  }
-  if (!wave_dead) {
-
-  // ---- epilogue: accumulators -> global.  Register r of a tile is row 8 (r >> 2) + 4 h + (r & 3) of the wave's 32, lanes
-  // l31 are 32 consecutive columns: one store instruction writes two 128-byte row segments.  Row = uniform part (SGPR
-  // arithmetic on the wave index, running pointers) + a lane part that depends on h only.  Groups of four registers
-  // (r >> 2) that lie inside the stored range take plain stores; a group that touches the edge (rows below m, the last
-  // degrees / latitudes, a ragged column tile) is predicated with lane masks built from scalar compares.
-  float* cz = p.C + (long)z * p.sC + (p.tsc ? (long)bx * p.tsc : (long)n0);   // uniform
-  constexpr unsigned long long MH0 = 0x00000000FFFFFFFFull, MH1 = 0xFFFFFFFF00000000ull;   // lanes with h = 0 / h = 1
-  unsigned long long colm[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) colm[j] = __builtin_amdgcn_ballot_w64(n0 + 32 * j + l31 < p.N);
-  if (FWD) {
-    // degree l = 2 rt + c = [64 wave + 16 r4 + 2 r2 + c] + 8 h, c = cE for the E tile, cO for the O tile
-    const unsigned offl = (unsigned)((long)(8 * h) * p.ldc + l31) * 4u;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int base = 64 * wave + 16 * r4 + (hf == 0 ? cE : cO);   // uniform; the group holds degrees base .. base + 14
-        if (base + 14 < z || base >= p.rows_out) continue;            // uniform: all below m / past lmax
-        float* rowp = cz + (long)base * p.ldc;
-        if (full && base >= z && base + 14 < p.rows_out) {
-#pragma unroll
-          for (int r2 = 0; r2 < 4; ++r2, rowp += 2 * p.ldc)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) st4s_rf(rowp + 32 * j, offl, acc[hf][j][4 * r4 + r2] * p.out_scale);
-        } else {
-#pragma unroll
-          for (int r2 = 0; r2 < 4; ++r2, rowp += 2 * p.ldc) {
-            const int lu = base + 2 * r2;
-            const unsigned long long m = ((lu >= z && lu < p.rows_out) ? MH0 : 0ull) | ((lu + 8 >= z && lu + 8 < p.rows_out) ? MH1 : 0ull);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              if (__builtin_amdgcn_inverse_ballot_w64(m & colm[j])) st4s_rf(rowp + 32 * j, offl, acc[hf][j][4 * r4 + r2] * p.out_scale);
-          }
-        }
-      }
-  } else {
-    // latitude rt = [32 wave + 8 r4 + r2] + 4 h and its mirror rows_out - 1 - rt = [rows_out - 5 - (32 wave + 8 r4 + r2)] + 4 (1 - h)
-    const unsigned off1 = (unsigned)((long)(4 * h) * p.ldc + l31) * 4u;
-    const unsigned off2 = (unsigned)((long)(4 * (1 - h)) * p.ldc + l31) * 4u;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int base = 32 * wave + 8 * r4;                 // uniform; the group holds latitudes base .. base + 7
-      if (base + 7 < kd || base >= Kh) continue;           // uniform: polar rows / past the equator
-      float* row1 = cz + (long)base * p.ldc;
-      float* row2 = cz + (long)(p.rows_out - 5 - base) * p.ldc;
-      if (full && base >= kd && base + 7 < Kh) {
-#pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2, row1 += p.ldc, row2 -= p.ldc)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float e = acc[0][j][4 * r4 + r2], od = acc[1][j][4 * r4 + r2];
-            st4s_rf(row1 + 32 * j, off1, (e + od) * p.out_scale);
-            st4s_rf(row2 + 32 * j, off2, (e - od) * p.out_scale);
-          }
-      } else {
-#pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2, row1 += p.ldc, row2 -= p.ldc) {
-          const int ru = base + r2;
-          const unsigned long long m = ((ru >= kd && ru < Kh) ? MH0 : 0ull) | ((ru + 4 >= kd && ru + 4 < Kh) ? MH1 : 0ull);
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            if (__builtin_amdgcn_inverse_ballot_w64(m & colm[j])) {
-              const float e = acc[0][j][4 * r4 + r2], od = acc[1][j][4 * r4 + r2];
-              st4s_rf(row1 + 32 * j, off1, (e + od) * p.out_scale);
-              st4s_rf(row2 + 32 * j, off2, (e - od) * p.out_scale);
-            }
-        }
-      }
-    }
-  }
-  }   // !wave_dead
-  z += dz; bx += dbx;
-  if (bx >= ntx) { bx -= ntx; ++z; }
-  }   // tile loop
-}
-
 }  // namespace
 
 #if SDY_STAMPS_ON
@@ -678,22 +398,6 @@ int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, l
     return sdy_launch_status();
   }
 #endif
-  static const char* persist_env = std::getenv("SDY_LEG_PERSIST");   // round-4 experiment (A/B): "2" or "3" workgroups per CU
-  if (persist_env) {
-    const int wgs = persist_env[0] == '2' ? 2 : 3;
-    int n_cu = 0;
-    SDY_TRY(sdy_cu_count(&n_cu));
-    const int ntx = (int)grid.x, ntiles = ntx * nz;
-    const int g = ntiles < wgs * n_cu ? ntiles : wgs * n_cu;
-    if (wgs == 3) {
-      if (fwd) hipLaunchKernelGGL((leg_par_persist_kernel<true, 3>), dim3(g), dim3(192), 0, stream, p, ntx, ntiles, g / ntx, g % ntx);
-      else hipLaunchKernelGGL((leg_par_persist_kernel<false, 3>), dim3(g), dim3(192), 0, stream, p, ntx, ntiles, g / ntx, g % ntx);
-    } else {
-      if (fwd) hipLaunchKernelGGL((leg_par_persist_kernel<true, 2>), dim3(g), dim3(192), 0, stream, p, ntx, ntiles, g / ntx, g % ntx);
-      else hipLaunchKernelGGL((leg_par_persist_kernel<false, 2>), dim3(g), dim3(192), 0, stream, p, ntx, ntiles, g / ntx, g % ntx);
-    }
-    return sdy_launch_status();
-  }
   if (fwd) hipLaunchKernelGGL((leg_par_kernel<true, false>), grid, dim3(192), 0, stream, p);
   else hipLaunchKernelGGL((leg_par_kernel<false, false>), grid, dim3(192), 0, stream, p);
   return sdy_launch_status();
