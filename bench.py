@@ -76,6 +76,9 @@ def launch_children(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("SDY_BENCH_CU_SPLIT"):     # EXPERIMENT (--share-gpu): disjoint CU sets for the ranks of one GPU
+            n_cu, per = 256, 256 // n
+            env["HSA_CU_MASK"] = "0:%d-%d" % (r * per, (r + 1) * per - 1)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = list(procs)

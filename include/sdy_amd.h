@@ -172,6 +172,10 @@ typedef struct sdy_conv_args {
   double* stats;                     /* dev [B*Cout*2] or NULL, w_frag path only: (sum, sum of squares) over HW of every
                                         output plane are ADDED here (zero it first; sdy_instnorm_from_stats turns them into
                                         the next InstanceNorm's coefficients) */
+  int out_tiled;                     /* w_frag path only: write `out` TILE-MAJOR, [b][tile of 64 pixels][Cout][64] (an image's last
+                                        tile padded to 64; out_bstride >= ceil(HW / 64) * Cout * 64), the layout sdy_mlp_args.x_tiled
+                                        reads: a tile of the intermediate tensor between the two persistent kernels is then one
+                                        contiguous 64 KB block for its producer and its consumer.  `out` must not alias `add`. */
 } sdy_conv_args;
 int sdy_conv1x1(const sdy_conv_args* args, void* stream);
 
@@ -210,6 +214,7 @@ typedef struct sdy_mlp_args {
   double* stats;                       /* dev [B*E*2] or NULL: (sum, sum of squares) over HW of every output plane are
                                           ADDED here (InstanceNorm statistics of the next block, sfnonet.py:292): zero
                                           it before the launch, turn it into coefficients with sdy_instnorm_from_stats */
+  int x_tiled;                         /* x is TILE-MAJOR (sdy_conv_args.out_tiled; x_bstride = floats per image); needs `add` */
   const float* keep_hidden;            /* tests only, dev (B, hidden, HW) and (B, E, HW) 0/1 masks or NULL: with drop_p > 0 the */
   const float* keep_out;               /* keep decisions come from these (e.g. masks the reference's nn.Dropout drew) instead of
                                           the Philox stream -- same kernel code, a separate (untimed) instantiation */

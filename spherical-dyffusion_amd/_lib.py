@@ -42,6 +42,7 @@ class SdyConvArgs(C.Structure):
         ("w_frag", C.c_void_p),
         ("w_frag_scale", C.c_float),
         ("stats", C.c_void_p),
+        ("out_tiled", C.c_int),
     ]
 
 
@@ -61,6 +62,7 @@ class SdyMlpArgs(C.Structure):
         ("rows_per_call", C.c_int),
         ("batch_scale", C.c_void_p),
         ("stats", C.c_void_p),
+        ("x_tiled", C.c_int),
         ("keep_hidden", C.c_void_p), ("keep_out", C.c_void_p),
     ]
 

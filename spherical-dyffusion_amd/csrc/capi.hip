@@ -891,7 +891,7 @@ extern "C" const char* sdy_sfno_missing(const sdy_sfno* n) { return n ? n->missi
 
 namespace {
 struct WsLayout {
-  size_t cat, xa, xb, xn, y, hid, xf, cs, cs2, ca, cd, ca1, cd1, st0, st1, ss, dp, trep, total;
+  size_t cat, xa, xb, xn, y, zt, hid, xf, cs, cs2, ca, cd, ca1, cd1, st0, st1, ss, dp, trep, total;
 };
 WsLayout ws_layout(const sdy_sfno* n, int B) {
   const sdy_sfno_config& c = n->cfg;
@@ -904,6 +904,7 @@ WsLayout ws_layout(const sdy_sfno* n, int B) {
   w.xb = take((size_t)B * E * HW);
   w.xn = take((size_t)B * E * HW);
   w.y = take((size_t)B * E * HW);
+  w.zt = take((size_t)B * ((HW + 63) / 64) * E * 64);   // inner-skip output, tile-major (conv_h3 -> mlp_h3), tiles padded
   w.hid = take((size_t)B * c.mlp_hidden * HW);
   w.xf = take(xf_floats(n->plan_data, B, (int)E));
   w.cs = take(cs_floats(n->plan_data, B, (int)E));
@@ -1167,6 +1168,12 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     static const bool no_stats1 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
     const bool stats1 = cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats1;
     if (stats1) cv.stats = st1;
+    // The tensor between the inner skip and the fused MLP has exactly one producer and one consumer, both walking 64-pixel
+    // tiles: it is stored TILE-MAJOR (a tile = one contiguous 64 KB block for the stores of one and the loads of the other).
+    static const bool no_ztile = std::getenv("SDY_NO_Z_TILED") != nullptr;
+    const bool z_tiled = stats1 && fused_mlp && !no_ztile;
+    const long zt_bs = (long)((HW + 63) / 64) * E * 64;
+    if (z_tiled) { cv.out = ws + w.zt; cv.out_bstride = zt_bs; cv.out_tiled = 1; }
     SDY_STAGE(ST_SKIP_CONV, sdy_conv1x1(&cv, stream));
     // norm1 (sfnonet.py:313-320) folded into the fc1 prologue; its statistics come from the convolution's epilogue
     if (stats1)
@@ -1181,6 +1188,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       sdy_mlp_args ma;
       std::memset(&ma, 0, sizeof(ma));
       ma.x = y; ma.x_bstride = (long)E * HW; ma.pa = ca1; ma.pd = cd1;
+      if (z_tiled) { ma.x = ws + w.zt; ma.x_bstride = zt_bs; ma.x_tiled = 1; }
       ma.w = bw.mlp; ma.w1_scale = bw.mlp_s1; ma.w2_scale = bw.mlp_s2; ma.b1 = bw.b1.p; ma.b2 = bw.b2.p;
       ma.out = dst; ma.out_bstride = dst_bs;
       if (lazy_norm) { ma.add = cur; ma.add_bstride = (long)E * HW; ma.add_a = ca; ma.add_d = cd; }

@@ -64,6 +64,7 @@ struct ConvParams {
   const float* add; long add_bs; int add_mode;   // 1: before the activation, 2: after it
   int act;
   float* out; long out_bs;
+  int out_tiled;                   // output TILE-MAJOR: [b][64-pixel tile][256 rows][64] (sdy_conv_args.out_tiled), out_bs per image
   double* stats;
   int HW, B;
   int Cin;                         // input channels (the weight stream is zero-padded to KBLK * 64)
@@ -227,6 +228,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
     const int col = n0 + 4 * q0;
     const bool c_ok = full || col < p.HW;
     const unsigned ro = (unsigned)(o0 * p.HW + (c_ok ? col : 0)) * 4u;   // this tile: addend / output rows o0 + CRS i
+    // tile-major output: the tile is one contiguous [256 rows][64 px] block, rows 64 floats apart
+    const unsigned ro_out = p.out_tiled ? (unsigned)(o0 * CTN + 4 * q0) * 4u : ro;
+    const int out_rs = p.out_tiled ? CTN : p.HW;
     const int tnext = (tile + 1 < t_end) ? tile + 1 : tile;   // past the end: a harmless re-read
     const float* xz_next = img(p.x, p.x_bs, tnext);
     const unsigned xo_next = (unsigned)(8 * o0 * p.HW + lane_col(tnext)) * 4u;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
     __syncthreads();
     stamp(5);
     {
-      float* oz = p.out + (long)z * p.out_bs;   // uniform
+      float* oz = p.out + (long)z * p.out_bs + (p.out_tiled ? (long)(tile - z * tpi) * (CE * CTN) : 0L);   // uniform
 #pragma unroll
       for (int i = 0; i < CRPT; ++i) {
         f32x4 v = *reinterpret_cast<const f32x4*>(Os + (o0 + CRS * i) * CTN + 4 * q0);
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
         }
         }
         if (p.add_mode == 2) v += addv[i];
-        if (c_ok) sdy_st16s(oz + (long)(CRS * i) * p.HW, ro, v);
+        if (c_ok) sdy_st16s(oz + (long)(CRS * i) * out_rs, ro_out, v);
         // next tile's pixels, a piece (or two) per step (every lane: a lane beyond a ragged tile's edge still owns pixels of
         // the next tile)
 #pragma unroll
@@ -438,7 +442,8 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   p.bias = a->bias;
   p.add = a->add_mode ? a->add : nullptr; p.add_bs = a->add_bstride; p.add_mode = a->add_mode;
   p.act = a->act;
-  p.out = a->out; p.out_bs = a->out_bstride;
+  p.out = a->out; p.out_bs = a->out_bstride; p.out_tiled = a->out_tiled;
+  if (a->out_tiled && a->add_mode && a->add == a->out) return SDY_ERR_ARG;   // a tile-major output cannot alias the NCHW addend
   p.stats = a->stats;
   SDY_TRY(sdy_flags_ptr(&p.flags));
   SDY_TRY(sdy_gelu_table_ptr(&p.gelu_tab));

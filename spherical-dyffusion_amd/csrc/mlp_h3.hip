@@ -55,6 +55,7 @@ constexpr int GROUP_F8 = 2 * 64;        // f16x8 elements per group (hi fragment
 
 struct MlpParams {
   const float* x; long x_bs;
+  int x_tiled;                             // x TILE-MAJOR: [b][64-pixel tile][256 rows][64] (sdy_mlp_args.x_tiled), x_bs per image
   const float* pa; const float* pd;
   const f16x8* w;                          // [4 waves][NGROUPS + RING groups][hi | lo][64 lanes]
   const float* b1; const float* b2;
@@ -131,12 +132,14 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     // ragged last slice of an image: clamp the address (branch-free loads keep exact vmcnt counts), zero at conversion
     const bool ok = nn + 4 * q0 < p.HW;
     // (wave-uniform row base in SGPRs) + (one 32-bit lane offset): see sdy_ld16s in common.h
-    const float* xz = p.x + (long)zz * p.x_bs;
-    const unsigned xo = (unsigned)(8 * o0 * p.HW + (ok ? nn + 4 * q0 : 0)) * 4u;
+    // (tile-major x: the tile is one contiguous [256 rows][64 px] block -- the producer pads an image's ragged last tile)
+    const float* xz = p.x + (long)zz * p.x_bs + (p.x_tiled ? (long)(t - zz * tpi) * (ME * TN) : 0L);
+    const int rs = p.x_tiled ? TN : p.HW;
+    const unsigned xo = p.x_tiled ? (unsigned)(8 * o0 * TN + 4 * q0) * 4u : (unsigned)(8 * o0 * p.HW + (ok ? nn + 4 * q0 : 0)) * 4u;
 #pragma unroll
     for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xr[oc][e] = sdy_ld16s(xz + (long)(8 * 16 * oc + e) * p.HW, xo);
+      for (int e = 0; e < 8; ++e) xr[oc][e] = sdy_ld16s(xz + (long)(8 * 16 * oc + e) * rs, xo);
   };
   // per-image coefficient table in LDS (norm affine of x, affine of the residual): rewritten only when the image changes
   auto load_coeffs = [&](int zz) {
@@ -891,7 +894,8 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   if (a->drop_p < 0.0f || a->drop_p >= 1.0f) return SDY_ERR_ARG;
   if (a->B > 65535) return SDY_ERR_UNSUPPORTED;
   MlpParams p{};
-  p.x = a->x; p.x_bs = a->x_bstride; p.pa = a->pa; p.pd = a->pd;
+  p.x = a->x; p.x_bs = a->x_bstride; p.x_tiled = a->x_tiled; p.pa = a->pa; p.pd = a->pd;
+  if (a->x_tiled && !a->add) return SDY_ERR_ARG;   // (without `add` the residual is x itself, read in NCHW order)
   p.w = reinterpret_cast<const f16x8*>(a->w);
   p.b1 = a->b1; p.b2 = a->b2;
   p.out = a->out; p.out_bs = a->out_bstride; p.add = a->add; p.add_bs = a->add_bstride;
