@@ -305,6 +305,11 @@ typedef struct sdy_sfno_fwd_args {
                                             (hidden, out) per layer, or NULL */
   const float* drop_path_keep;           /* optional injected drop-path keep flags, dev [num_layers][B], or NULL */
   float* ws; size_t ws_floats;
+  int reuse_encoder;       /* 1: every `in` tensor holds the same values as in the PREVIOUS forward of this network on this
+                              workspace with the same B (the two interpolations of a cold-sampling step share their inputs,
+                              src/diffusion/dyffusion.py:497,515): the input concat and the encoder are skipped and the forward
+                              restarts from the stored encoder output -- bit-identical results (time, dropout call number and
+                              masks may differ: they enter after the encoder).  SDY_ERR_STATE if there is no such forward. */
 } sdy_sfno_fwd_args;
 int sdy_sfno_forward(sdy_sfno* net, const sdy_sfno_fwd_args* args, void* stream);
 

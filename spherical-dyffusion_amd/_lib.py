@@ -129,6 +129,7 @@ class SdySfnoFwdArgs(C.Structure):
         ("keep_masks", C.POINTER(C.c_void_p)),
         ("drop_path_keep", C.c_void_p),
         ("ws", C.c_void_p), ("ws_floats", C.c_size_t),
+        ("reuse_encoder", C.c_int),
     ]
 
 

@@ -599,6 +599,10 @@ struct sdy_sfno {
   std::vector<BlockW> blk;
   SdyTimeMlp tm;
   std::string missing;
+  // sdy_sfno_fwd_args.reuse_encoder: where (and for which batch) the last forward left its encoder output
+  const float* enc_ws = nullptr;
+  int enc_B = 0;
+  bool enc_has_stats = false;
 };
 
 static int dev_alloc(DevBuf& b, size_t n) {
@@ -891,7 +895,7 @@ extern "C" const char* sdy_sfno_missing(const sdy_sfno* n) { return n ? n->missi
 
 namespace {
 struct WsLayout {
-  size_t cat, xa, xb, xn, y, zt, hid, xf, cs, cs2, ca, cd, ca1, cd1, st0, st1, ss, dp, trep, total;
+  size_t cat, xa, xb, xe, xn, y, zt, hid, xf, cs, cs2, ca, cd, ca1, cd1, st0, st1, ste, ss, dp, trep, total;
 };
 WsLayout ws_layout(const sdy_sfno* n, int B) {
   const sdy_sfno_config& c = n->cfg;
@@ -902,6 +906,7 @@ WsLayout ws_layout(const sdy_sfno* n, int B) {
   w.cat = take((size_t)B * n->catC * HW);
   w.xa = take((size_t)B * E * HW);
   w.xb = take((size_t)B * E * HW);
+  w.xe = take((size_t)B * E * HW);    // encoder output: block 0 reads it, nothing overwrites it (sdy_sfno_fwd_args.reuse_encoder)
   w.xn = take((size_t)B * E * HW);
   w.y = take((size_t)B * E * HW);
   w.zt = take((size_t)B * ((HW + 63) / 64) * E * 64);   // inner-skip output, tile-major (conv_h3 -> mlp_h3), tiles padded
@@ -915,6 +920,7 @@ WsLayout ws_layout(const sdy_sfno* n, int B) {
   w.cd1 = take((size_t)B * E);
   w.st1 = take((size_t)B * E * 4);   // same for norm1, filled by the inner-skip convolution's epilogue
   w.st0 = take((size_t)B * E * 4);   // (sum, sumsq) doubles of the next block's norm0, filled by the fused MLP epilogue
+  w.ste = take((size_t)B * E * 4);   // the encoder output's statistics (block 0's norm0), kept for reuse_encoder
   w.ss = take((size_t)B * c.num_layers * 2 * E);
   w.dp = take((size_t)B * c.num_layers);
   w.trep = take((size_t)B * (c.with_time_emb ? c.time_dim : 1));
@@ -1056,6 +1062,10 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   bool have_st0 = false;                                  // statistics of `cur` are waiting in st0
   SDY_HIP_TRY(hipMemsetAsync(st0, 0, (size_t)B * E * 2 * sizeof(double), stream));
   float *ss = ws + w.ss, *dp = ws + w.dp, *trep = ws + w.trep;
+  float* xe = ws + w.xe;
+  double* ste = reinterpret_cast<double*>(ws + w.ste);
+  const bool reuse = a->reuse_encoder != 0;
+  if (reuse && (n->enc_ws != ws || n->enc_B != B)) return SDY_ERR_STATE;   // no previous forward on this workspace / batch
 
   // ---- input concat (BaseModel.concat_condition_if_needed, _base_model.py:166-192) into the tail of the big-skip
   //      buffer: cat = [ block output (E) | inputs (Cin) ]  (sfnonet.py:804-805,831-832)
@@ -1067,7 +1077,8 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   if (ns == 0 || ctot != Cin) return SDY_ERR_SHAPE;
   const long cat_bs = (long)n->catC * HW;
   float* cat_in = cat + (size_t)(n->catC - Cin) * HW;
-  SDY_STAGE(ST_CONCAT, sdy_concat_launch(srcs, chans, ns, cat_in, cat_bs, B, HW, stream));
+  // (reuse_encoder: the inputs already sit in the tail of `cat` -- no block writes there -- and the encoder output in xe)
+  if (!reuse) SDY_STAGE(ST_CONCAT, sdy_concat_launch(srcs, chans, ns, cat_in, cat_bs, B, HW, stream));
 
   // ---- time embedding + per-layer (scale|shift) + drop-path scales
   const bool drop = a->enable_dropout != 0;
@@ -1093,13 +1104,21 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   // ---- encoder (sfnonet.py:609-618,810,824): conv+bias -> GELU -> conv (no bias) -> + pos_embed
   static const bool no_pair = std::getenv("SDY_NO_PAIR") != nullptr;   // A/B: the two-launch encoder / decoder
   static const bool no_stats0 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
-  if (n->enc.w && !no_pair) {   // one launch (pair_h3.hip), block 0's norm0 statistics from its epilogue
+  // The encoder writes to a buffer of its own (xe) and its statistics to `ste`; block 0 works on a copy of the statistics
+  // (sdy_instnorm_from_stats clears what it reads), so that a following forward on the same inputs can restart here.
+  bool have_ste = false;
+  if (reuse) {
+    have_ste = n->enc_has_stats;
+  } else if (n->enc.w && !no_pair) {   // one launch (pair_h3.hip), block 0's norm0 statistics from its epilogue
     sdy_pair_args pa{};
     pa.x = cat_in; pa.x_bstride = cat_bs; pa.w = n->enc.w; pa.w1_scale = n->enc.s1; pa.w2_scale = n->enc.s2;
-    pa.b1 = n->e0b.p; pa.out = xb; pa.out_bstride = (long)E * HW;
+    pa.b1 = n->e0b.p; pa.out = xe; pa.out_bstride = (long)E * HW;
     if (c.pos_embed) { pa.add = n->pos.p; pa.add_bstride = 0; }
     pa.B = B; pa.Cin = Cin; pa.hidden = E; pa.Cout = E; pa.HW = HW;
-    if (!no_stats0) { pa.stats = st0; have_st0 = true; }
+    if (!no_stats0) {
+      SDY_HIP_TRY(hipMemsetAsync(ste, 0, (size_t)B * E * 2 * sizeof(double), stream));
+      pa.stats = ste; have_ste = true;
+    }
     SDY_STAGE(ST_ENC_PAIR, sdy_pair_h3(&pa, stream));
   } else {
   conv_reset();
@@ -1107,15 +1126,23 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   cv.Cin = Cin; cv.Cout = E; cv.bias = n->e0b.p; cv.act = 1;
   SDY_STAGE(ST_ENC0, sdy_conv1x1(&cv, stream));
   conv_reset();
-  cv.x = xa; cv.x_bstride = (long)E * HW; use_w(n->e2w); cv.ldw = E; cv.out = xb; cv.out_bstride = (long)E * HW;
+  cv.x = xa; cv.x_bstride = (long)E * HW; use_w(n->e2w); cv.ldw = E; cv.out = xe; cv.out_bstride = (long)E * HW;
   cv.Cin = E; cv.Cout = E;
   if (c.pos_embed) { cv.add = n->pos.p; cv.add_bstride = 0; cv.add_mode = 2; }
   // block 0's norm0 statistics from this convolution's epilogue (persistent kernel only): no pass over its output
-  if (cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats0) { cv.stats = st0; have_st0 = true; }
+  if (cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats0) {
+    SDY_HIP_TRY(hipMemsetAsync(ste, 0, (size_t)B * E * 2 * sizeof(double), stream));
+    cv.stats = ste; have_ste = true;
+  }
   SDY_STAGE(ST_ENC2, sdy_conv1x1(&cv, stream));
   }
+  n->enc_ws = ws; n->enc_B = B; n->enc_has_stats = have_ste;
+  if (have_ste) {
+    SDY_HIP_TRY(hipMemcpyAsync(st0, ste, (size_t)B * E * 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    have_st0 = true;
+  }
 
-  float* cur = xb;
+  float* cur = xe;
   float* nxt = xa;
   const int ilv = spec_ilv(c);   // channel order of Xf / Cs / Cs2 inside this forward
   for (int i = 0; i < L; ++i) {

@@ -47,6 +47,7 @@ class DYffusion(torch.nn.Module):
         log_every_t: Union[str, int, None] = None,
         hack_for_imprecise_interpolation: bool = False,
         fuse_interpolator_pair_max_batch: int = 8,
+        reuse_interpolator_encoder: bool = True,
         **unused,
     ):
         super().__init__()
@@ -90,6 +91,11 @@ class DYffusion(torch.nn.Module):
         # two calls run as ONE forward of 2B rows (per-row time, per-row dropout call number: identical results); larger
         # batches already fill the GPU and would only pay for the stacked copy of the inputs.
         self.fuse_interpolator_pair_max_batch = int(fuse_interpolator_pair_max_batch)
+        # Beyond that batch size the pair runs as two forwards, the second one restarting from the first one's encoder output
+        # (same inputs: sdy_sfno_fwd_args.reuse_encoder); False = two full forwards (A/B, tests)
+        import os
+        self.reuse_interpolator_encoder = bool(reuse_interpolator_encoder) and os.environ.get("SDY_NO_ENCODER_REUSE") is None
+        self._last_packed_inputs = None
         self.full_sampling_schedule = list(range(0, self.num_timesteps))
         self.sampling_schedule = sampling_schedule or self.full_sampling_schedule
         # DYffusion.__init__ consistency check (dyffusion.py:632-640)
@@ -197,18 +203,40 @@ class DYffusion(torch.nn.Module):
             return self._interpolate(initial_condition=x_end, x_last=x0, t=time, t_host=i_n, **kwargs)
 
     def _interpolate(self, initial_condition: Tensor, x_last: Tensor, t: Tensor, t_host=None, num_predictions: int = 1,
-                     **kwargs) -> Tensor:
-        """dyffusion.py:642-662."""
+                     _packed_inputs: Optional[Tensor] = None, **kwargs) -> Tensor:
+        """dyffusion.py:642-662.  `_packed_inputs`: the channel concat of a previous call on the same (x_end, x0)."""
         if t_host is not None:
             assert 0 < t_host < self.interpolator_horizon, \
                 f"interpolate time must be in (0, {self.interpolator_horizon}), got {t_host}"
         hack = self.hparams.hack_for_imprecise_interpolation
-        pieces = [initial_condition] + ([initial_condition[:, :1]] if hack else []) + [x_last]
-        inputs = ops.concat_channels(pieces)
+        if _packed_inputs is None:
+            pieces = [initial_condition] + ([initial_condition[:, :1]] if hack else []) + [x_last]
+            inputs = ops.concat_channels(pieces)
+        else:
+            inputs = _packed_inputs
+        self._last_packed_inputs = inputs
         out = self.interpolator.predict_packed(inputs, time=t, **kwargs)["preds"]
         if hack:
             out = ops.concat_channels([initial_condition[:, :1], out])
         return out
+
+    def _can_reuse_encoder(self, kwargs) -> bool:
+        """The second interpolation of a cold-sampling step can restart from the first one's encoder output when the two
+        calls see the same inputs: same (x_0, forecast) by construction, and no time-dependent condition."""
+        net = getattr(self.interpolator, "model", None)
+        return (self.reuse_interpolator_encoder and kwargs.get("dynamical_condition") is None
+                and hasattr(net, "batch_offset") and getattr(net, "mask_injector", None) is None)
+
+    def q_sample_two(self, x0, x_end, t_first, t_second, is_artificial_step: bool = True, **kwargs):
+        """`(q_sample(t=t_first), q_sample(t=t_second))` as two interpolator forwards that share ONE input concat and ONE
+        encoder pass (`reuse_encoder`): the encoder sees only (x_end, x0, static condition), which are the same for both
+        calls; time embedding and dropout enter behind it.  Bit-identical to the two plain calls."""
+        first = self.q_sample(x0=x0, x_end=x_end, t=t_first, is_artificial_step=is_artificial_step, **dict(kwargs))
+        packed = self._last_packed_inputs
+        second = self.q_sample(x0=x0, x_end=x_end, t=t_second, is_artificial_step=is_artificial_step,
+                               _packed_inputs=packed, reuse_encoder=True, **dict(kwargs))
+        self._last_packed_inputs = None
+        return first, second
 
     def _can_stack_calls(self) -> bool:
         """Stacked calls need a network that numbers its dropout calls per row (`rows_per_call`); injected masks (tests that
@@ -301,6 +329,10 @@ class DYffusion(torch.nn.Module):
                     # the step's two interpolations (to s_next, then to s: the reference's call order) as one 2B forward
                     x_next, x_at_s = self.q_sample_pair(x_hat, initial_condition, s_next, s,
                                                         is_artificial_step=not lands_on_data, **dict(kwargs))
+                elif cold and s > 0 and self._can_reuse_encoder(kwargs):
+                    # larger batches: two forwards, the second restarting behind the first one's encoder
+                    x_next, x_at_s = self.q_sample_two(x_hat, initial_condition, s_next, s,
+                                                       is_artificial_step=not lands_on_data, **dict(kwargs))
                 else:
                     x_next = self.q_sample(**ipol, t=s_next, **dict(kwargs))
             if not cold:

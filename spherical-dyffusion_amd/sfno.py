@@ -328,8 +328,13 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def forward(self, inputs, time=None, condition=None, static_condition=None, return_time_emb: bool = False,
-                keep_masks=None, drop_path_keep=None, rows_per_call: Optional[int] = None, **kwargs):
-        """`rows_per_call=n` (n divides the batch): the batch stacks B / n CALLS of n trajectories each -- row b draws the
+                keep_masks=None, drop_path_keep=None, rows_per_call: Optional[int] = None, reuse_encoder: bool = False,
+                **kwargs):
+        """`reuse_encoder=True`: the caller guarantees that `inputs` / `condition` / `static_condition` hold the same values
+        as in the previous forward of this network (same batch): the input concat and the encoder are skipped and the
+        forward restarts from the stored encoder output -- bit-identical results; `time` and the dropout call number may
+        differ (the two interpolations of a cold-sampling step, reference dyffusion.py:497,515).
+        `rows_per_call=n` (n divides the batch): the batch stacks B / n CALLS of n trajectories each -- row b draws the
         dropout stream of call number `_call + b // n`, trajectory `batch_offset + b % n`, exactly as if the calls had
         been issued one after the other, and the call counter advances by B / n.  (The two interpolator calls of a DYffusion
         sampling step share their inputs, reference dyffusion.py:497,515.)"""
@@ -397,12 +402,13 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             n_calls = B // int(rows_per_call)
         if keep_masks is None and drop_path_keep is None and self.mask_injector is not None and self.inference_dropout:
             keep_masks, drop_path_keep = self.mask_injector(self._call)
-        self._native_call(h, dev, pieces, tt, out, self._call, self.batch_offset, rows_per_call, keep_masks, drop_path_keep)
+        self._native_call(h, dev, pieces, tt, out, self._call, self.batch_offset, rows_per_call, keep_masks, drop_path_keep,
+                          reuse_encoder=bool(reuse_encoder))
         self._call += n_calls
         return out
 
     def _native_call(self, h, dev, pieces, tt, out, call: int, batch_offset: int, rows_per_call: Optional[int] = None,
-                     keep_masks=None, drop_path_keep=None) -> None:
+                     keep_masks=None, drop_path_keep=None, reuse_encoder: bool = False) -> None:
         """One sdy_sfno_forward on prepared (fp32, contiguous-per-row) inputs; `out` is a (B, out_chans, nlat, nlon) view."""
         B = out.shape[0]
         ws = self._workspace(h, dev, B)
@@ -431,6 +437,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             keep.append(dk)
             a.drop_path_keep = ptr(dk)
         a.ws, a.ws_floats = ptr(ws), ws.numel()
+        a.reuse_encoder = int(reuse_encoder)
         with torch.cuda.device(dev):
             check(lib.sdy_sfno_forward(h, C.byref(a), current_stream()), "sdy_sfno_forward")
 

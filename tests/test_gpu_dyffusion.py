@@ -582,3 +582,59 @@ def test_predict_step_and_interface_run_inference():
     assert merged["t6_preds_normed"].shape == (3, 2, 6, 32, 64)          # batches concatenated on axis 1 (members lead)
     assert merged["t6_targets_normed"].shape == (2, 6, 32, 64)
     assert exp._predict_step_outputs == []
+
+
+@pytest.mark.parametrize("hack", [False, True])
+def test_interpolator_pair_with_shared_encoder_equals_two_full_forwards(hack):
+    """Beyond `fuse_interpolator_pair_max_batch` the two interpolations of a cold-sampling step (reference
+    src/diffusion/dyffusion.py:497,515: same x_0 and forecast, times s' and s) run as two forwards, the second restarting
+    from the first one's encoder output (`sdy_sfno_fwd_args.reuse_encoder`): bit-identical to two full forwards, 10
+    interpolator calls either way; a time-dependent condition switches the sharing off; restarting without a previous
+    forward is an error."""
+    import sdy_amd
+
+    exp, oracle, cs, n_forc = _build(hack=hack, dropout=True)
+    smp = exp.model
+    smp.fuse_interpolator_pair_max_batch = 0          # force the two-forward path at this small batch
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B = 3
+    x0 = torch.randn(B, cs, 32, 64, generator=g).cuda()
+    kw = {"static_condition": torch.randn(B, n_forc, 32, 64, generator=g).cuda()}
+    inet = smp.interpolator.model
+    seen = []
+    orig = inet._native_call
+
+    def spy(*a, reuse_encoder=False, **k):
+        seen.append(bool(reuse_encoder))
+        return orig(*a, reuse_encoder=reuse_encoder, **k)
+
+    inet._native_call = spy
+    smp.reuse_interpolator_encoder = True
+    shared = smp.sample(x0, **kw)
+    assert len(seen) == 10
+    n_shared = sum(seen)                              # every cold step with s > 0 shares: the second call of each pair
+    assert all(not a or not b for a, b in zip(seen, seen[1:])), "a restart follows a full forward"
+    exp.set_dropout_calls((0, 0))
+    seen.clear()
+    smp.reuse_interpolator_encoder = False
+    plain = smp.sample(x0, **kw)
+    assert len(seen) == 10 and not any(seen)
+    assert n_shared >= 4
+    for k in plain:
+        assert torch.equal(shared[k], plain[k]), k
+    ref = oracle.sample(x0.cpu(), **{k: v.cpu() for k, v in kw.items()})
+    for k in ref:
+        assert rel_l2(shared[k], ref[k]) < 2e-5
+    # a time-dependent condition differs between the two calls: no sharing
+    if not hack:
+        exp.set_dropout_calls((0, 0))
+        seen.clear()
+        smp.reuse_interpolator_encoder = True
+        dyn = torch.randn(B, 7, n_forc, 32, 64, generator=g).cuda()
+        smp.sample(x0, dynamical_condition=dyn)
+        assert len(seen) == 10 and not any(seen)
+    # the native call refuses to restart when there is nothing to restart from
+    net2, _, _ = make_pair(SFNOConfig(in_chans=4, out_chans=4, nlat=32, nlon=64, embed_dim=16, num_layers=1,
+                                      with_time_emb=False), 4, 0)
+    with pytest.raises(sdy_amd.SdyError):
+        net2(torch.zeros(1, 4, 32, 64).cuda(), reuse_encoder=True)
