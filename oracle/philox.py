@@ -21,6 +21,8 @@ tests can compare the device masks bit for bit.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 M0 = np.uint64(0xD2511F53)
@@ -81,17 +83,33 @@ def element_keep_mask(seed: int, call: int, layer: int, kind: int, p: float,
     with bit 5 clear, high half-word for its partner (include/sdy_amd.h)."""
     assert C % 4 == 0
     thr = np.uint32(drop_threshold16(p))
-    npix = np.arange(H * W, dtype=np.uint32)
-    pix = (npix & np.uint32(0xFFFFFFDF))[None, None, :]
-    half = ((npix >> np.uint32(5)) & np.uint32(1))[None, None, None, :]
+    HW = H * W
+    npix = np.arange(HW, dtype=np.uint32)
+    base = npix[(npix & np.uint32(32)) == 0]          # one generator call per pixel PAIR: the pixel with bit 5 clear ...
+    partner = base | np.uint32(32)                    # ... serves its partner from the high half-words
+    has_partner = partner < HW
     b = _global_rows(B, batch_offset, rows)[:, None, None]
-    g = np.arange(C // 4, dtype=np.uint64)[None, :, None]
-    c1 = ((b * np.uint64(C // 4) + g) & MASK32).astype(np.uint32)
-    words = philox4x32_10(pix, c1, np.uint32(2 * layer + kind), np.uint32(call & 0xFFFFFFFF),
-                          seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    w = np.stack(words, axis=2)  # (B, C/4, 4, HW)
-    w = np.where(half == 1, w >> np.uint32(16), w & np.uint32(0xFFFF))
-    keep = (w >= thr).astype(np.float32)
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    keep = np.empty((B, C // 4, 4, HW), dtype=np.float32)
+
+    def fill(g0, g1):   # channel groups g0 .. g1 - 1 (numpy releases the GIL inside its loops: the chunks run in parallel)
+        g = np.arange(g0, g1, dtype=np.uint64)[None, :, None]
+        c1 = ((b * np.uint64(C // 4) + g) & MASK32).astype(np.uint32)
+        words = philox4x32_10(base[None, None, :], c1, np.uint32(2 * layer + kind), np.uint32(call & 0xFFFFFFFF), k0, k1)
+        w = np.stack(words, axis=2)                   # (B, g1 - g0, 4, pairs)
+        keep[:, g0:g1, :, base] = (w & np.uint32(0xFFFF)) >= thr
+        keep[:, g0:g1, :, partner[has_partner]] = ((w >> np.uint32(16)) >= thr)[..., has_partner]
+
+    ngroups = C // 4
+    nthreads = min(ngroups, max(1, min(32, (os.cpu_count() or 1))))
+    if nthreads == 1 or B * C * HW < (1 << 22):
+        fill(0, ngroups)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        edges = np.linspace(0, ngroups, nthreads + 1).astype(int)
+        with ThreadPoolExecutor(max_workers=nthreads) as pool:
+            list(pool.map(lambda i: fill(int(edges[i]), int(edges[i + 1])), range(nthreads)))
     return keep.reshape(B, C, H, W)
 
 

@@ -93,22 +93,26 @@ def sinusoidal_pos_emb(t: torch.Tensor, dim: int) -> torch.Tensor:
 class OracleSFNO:
     """Functional restatement; `sd` maps reference state_dict names to CPU fp32 tensors."""
 
-    def __init__(self, cfg: SFNOConfig, sd: Dict[str, torch.Tensor]):
+    def __init__(self, cfg: SFNOConfig, sd: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float32):
+        """`dtype=torch.float64`: the same op sequence in double precision -- the yardstick that tells how much of a
+        difference between two fp32 implementations is either one's rounding (tools/chain_error_probe.py); the reference,
+        and every parity test, run fp32."""
         self.cfg = cfg
-        self.sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
+        self.dtype = dtype
+        self.sd = {k: v.detach().to(dtype).cpu() for k, v in sd.items()}
         c = cfg
         kw = dict(lmax=c.modes_lat, mmax=c.modes_lon)
-        self.trans_down = RealSHT(c.nlat, c.nlon, grid=c.data_grid, **kw).float()
-        self.itrans_up = InverseRealSHT(c.nlat, c.nlon, grid=c.data_grid, **kw).float()
-        self.trans = RealSHT(c.h, c.w, grid="legendre-gauss", **kw).float()
-        self.itrans = InverseRealSHT(c.h, c.w, grid="legendre-gauss", **kw).float()
+        self.trans_down = RealSHT(c.nlat, c.nlon, grid=c.data_grid, **kw).to(dtype)
+        self.itrans_up = InverseRealSHT(c.nlat, c.nlon, grid=c.data_grid, **kw).to(dtype)
+        self.trans = RealSHT(c.h, c.w, grid="legendre-gauss", **kw).to(dtype)
+        self.itrans = InverseRealSHT(c.h, c.w, grid="legendre-gauss", **kw).to(dtype)
 
     # ---- pieces ---------------------------------------------------------------------------
     def time_repr(self, time: torch.Tensor) -> torch.Tensor:
         sd, c = self.sd, self.cfg
         if c.min_time is not None:
             assert (c.min_time <= time).all() and (time <= c.max_time).all(), f"time out of range: {time}"
-        e = sinusoidal_pos_emb(time.to(torch.float32), c.embed_dim)
+        e = sinusoidal_pos_emb(time.to(self.dtype), c.embed_dim)
         h = F.linear(e, sd["time_emb_mlp.1.weight"], sd["time_emb_mlp.1.bias"])
         h = F.gelu(h)
         return F.linear(h, sd["time_emb_mlp.3.weight"], sd["time_emb_mlp.3.bias"])
@@ -167,8 +171,8 @@ class OracleSFNO:
     # ---- full network ---------------------------------------------------------------------
     def forward(self, inputs, time=None, condition=None, static_condition=None, mask_fn: Optional[MaskFn] = None):
         c, sd = self.cfg, self.sd
-        parts = [inputs] + [t for t in (condition, static_condition) if t is not None]
-        x = torch.cat(parts, dim=1) if len(parts) > 1 else inputs
+        parts = [t.to(self.dtype) for t in (inputs, condition, static_condition) if t is not None]
+        x = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
         assert x.shape[1] == c.in_chans, f"expected {c.in_chans} channels, got {x.shape[1]}"
         residual = x
         x = F.conv2d(x, sd["encoder.0.weight"], sd["encoder.0.bias"])
