@@ -120,3 +120,48 @@ def drop_path_keep(seed: int, call: int, layer: int, p: float, B: int, batch_off
     w0, _, _, _ = philox4x32_10(b, np.uint32(0xFFFFFFFF), np.uint32(0x1000 + layer),
                                 np.uint32(call & 0xFFFFFFFF), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     return (w0 >= thr).astype(np.float32)
+
+
+def _mulhilo32_torch(m: int, c):
+    """(hi32, lo32) of m * c for an int64 tensor c holding uint32 values: 16-bit limbs keep every product below 2^63."""
+    cl, ch = c & 0xFFFF, c >> 16
+    p, q = cl * m, ch * m
+    s = p + ((q & 0xFFFF) << 16)
+    return (q >> 16) + (s >> 32), s & 0xFFFFFFFF
+
+
+def element_keep_mask_torch(seed: int, call: int, layer: int, kind: int, p: float, B: int, C: int, H: int, W: int,
+                            batch_offset: int = 0, rows=None, device="cpu"):
+    """`element_keep_mask` restated on torch int64 tensors (same stream definition, same result bit for bit:
+    tests/test_capi_cpu.py) -- the full-depth, full-size parity tests need 160 masks of 33 M decisions each, minutes of numpy;
+    on `device="cuda"` torch evaluates the same arithmetic in milliseconds.  Still test infrastructure: plain torch integer
+    ops, nothing of the product.  Returns a float32 CPU tensor (B, C, H, W)."""
+    import torch
+
+    assert C % 4 == 0
+    thr = int(drop_threshold16(p))
+    HW = H * W
+    dev = torch.device(device)
+    npix = torch.arange(HW, dtype=torch.int64, device=dev)
+    base = npix[(npix & 32) == 0]
+    partner = base | 32
+    has_partner = partner < HW
+    b = torch.as_tensor(_global_rows(B, batch_offset, rows).astype(np.int64), device=dev)[:, None, None]
+    g = torch.arange(C // 4, dtype=torch.int64, device=dev)[None, :, None]
+    c0 = base[None, None, :].expand(B, C // 4, -1).clone()
+    c1 = ((b * (C // 4) + g) & 0xFFFFFFFF).expand(-1, -1, base.numel()).clone()
+    c2 = torch.full_like(c0, (2 * layer + kind) & 0xFFFFFFFF)
+    c3 = torch.full_like(c0, call & 0xFFFFFFFF)
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for r in range(10):
+        hi0, lo0 = _mulhilo32_torch(int(M0), c0)
+        hi1, lo1 = _mulhilo32_torch(int(M1), c2)
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        if r < 9:
+            k0 = (k0 + int(W0)) & 0xFFFFFFFF
+            k1 = (k1 + int(W1)) & 0xFFFFFFFF
+    w = torch.stack((c0, c1, c2, c3), dim=2)                  # (B, C/4, 4, pairs)
+    keep = torch.empty(B, C // 4, 4, HW, dtype=torch.float32, device=dev)
+    keep[..., base] = ((w & 0xFFFF) >= thr).to(torch.float32)
+    keep[..., partner[has_partner]] = ((w >> 16) >= thr)[..., has_partner].to(torch.float32)
+    return keep.reshape(B, C, H, W).cpu()

@@ -295,7 +295,7 @@ extern "C" int sdy_irfft_lon(const sdy_sht_plan* p, const float* Yf, const float
 }
 
 static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream,
-                             bool tiled = false);
+                             bool tiled = false, bool cs_tiled = false);
 extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, void* stream) {
   return legendre_fwd_impl(p, Xf, Cs, B, C, false, stream);
 }
@@ -315,7 +315,7 @@ static bool plan_tiled_ok(const sdy_sht_plan* p, int C, int ilv) {
   return !off && ilv == 1 && p->d_wq_par && p->d_pct_par && p->fft.n == 180 && C % 32 == 0;
 }
 static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream,
-                             bool tiled) {
+                             bool tiled, bool cs_tiled) {
   if (!p || !Xf || !Cs || B <= 0 || C <= 0) return SDY_ERR_ARG;
   if (C & 1) return SDY_ERR_ALIGN;
   const int N = 2 * B * C;
@@ -328,10 +328,12 @@ static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, 
   static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
   static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
   if (p->d_wq_par && !no_frag && !no_par)
-    return sdy_leg_par_launch(p->d_wq_par, p->s_wq_par, p->mtr, Xf, tiled ? 64 : N, (long)p->nlat * N, Cs, (long)p->mtr * N, N,
+    // cs_tiled: the coefficients TILE-MAJOR by order, [m][column tile][l][64] (dh_h3.hip, DhParams::tiled)
+    return sdy_leg_par_launch(p->d_wq_par, p->s_wq_par, p->mtr, Xf, tiled ? 64 : N, (long)p->nlat * N, Cs,
+                              cs_tiled ? 64L : (long)p->mtr * N, cs_tiled ? (long)(N / 64) * p->lmax * 64 : (long)N,
                               p->lmax, p->nlat, N, 1, polar ? p->d_kdead : nullptr, (hipStream_t)stream,
-                              tiled ? 64L * p->nlat : 0L, 0L);
-  if (tiled) return SDY_ERR_UNSUPPORTED;
+                              tiled ? 64L * p->nlat : 0L, cs_tiled ? 64L * p->lmax : 0L);
+  if (tiled || cs_tiled) return SDY_ERR_UNSUPPORTED;
   if (p->d_wq_frag && !no_frag)
     return sdy_leg_h3_launch(p->d_wq_frag, p->s_wq_frag, p->mtr, Xf, N, (long)p->nlat * N, Cs, (long)p->mtr * N, N, p->lmax,
                              p->nlat, N, SDY_TRI_LEG_FWD, (hipStream_t)stream);
@@ -342,12 +344,12 @@ static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, 
 }
 
 static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, bool polar, void* stream,
-                             bool tiled = false);
+                             bool tiled = false, bool cs_tiled = false);
 extern "C" int sdy_legendre_inv(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, void* stream) {
   return legendre_inv_impl(p, Cs, Yf, B, C, false, stream);
 }
 static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, int B, int C, bool polar, void* stream,
-                             bool tiled) {
+                             bool tiled, bool cs_tiled) {
   if (!p || !Cs || !Yf || B <= 0 || C <= 0) return SDY_ERR_ARG;
   if (C & 1) return SDY_ERR_ALIGN;
   const int N = 2 * B * C;
@@ -360,10 +362,11 @@ static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, 
   static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
   static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
   if (p->d_pct_par && !no_frag && !no_par)
-    return sdy_leg_par_launch(p->d_pct_par, p->s_pct_par, p->mtr, Cs, (long)p->mtr * N, N, Yf, tiled ? 64 : N,
+    return sdy_leg_par_launch(p->d_pct_par, p->s_pct_par, p->mtr, Cs, cs_tiled ? 64L : (long)p->mtr * N,
+                              cs_tiled ? (long)(N / 64) * p->lmax * 64 : (long)N, Yf, tiled ? 64 : N,
                               (long)p->nlat * N, p->nlat, p->lmax, N, 0, polar ? p->d_kdead : nullptr, (hipStream_t)stream,
-                              0L, tiled ? 64L * p->nlat : 0L);
-  if (tiled) return SDY_ERR_UNSUPPORTED;
+                              cs_tiled ? 64L * p->lmax : 0L, tiled ? 64L * p->nlat : 0L);
+  if (tiled || cs_tiled) return SDY_ERR_UNSUPPORTED;
   if (p->d_pct_frag && !no_frag)
     return sdy_leg_h3_launch(p->d_pct_frag, p->s_pct_frag, p->mtr, Cs, (long)p->mtr * N, N, Yf, N, (long)p->nlat * N, p->nlat,
                              p->lmax, N, SDY_TRI_LEG_INV, (hipStream_t)stream);
@@ -1169,21 +1172,26 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     // SpectralConvS2.forward (s2convolutions.py:158-193)
     const bool polar_in = plan_polar_ok(pin, E), polar_out = plan_polar_ok(pout, E);
     const bool tiled_in = plan_tiled_ok(pin, E, ilv), tiled_out = plan_tiled_ok(pout, E, ilv);   // Xf / Yf tile-major (fft.h)
+    // Cs / Cs2 tile-major by order too (analysis stores and synthesis loads become contiguous tiles; dh_h3 reads and writes
+    // 256-byte pieces instead of 2 KB rows, which it does not notice: it is matrix / issue bound).  SDY_NO_CS_TILED=1: off.
+    static const bool no_cs_tiled = std::getenv("SDY_NO_CS_TILED") != nullptr;
+    const bool cs_tiled = tiled_in && tiled_out && bw.fw.frag && !no_cs_tiled && pin->lmax == pout->lmax && pin->mtr == pout->mtr;
     SDY_STAGE(ST_FFT_FWD, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, B, E,
                                              pin->nlat, pin->mtr, tiled_in ? 2 : ilv, polar_in ? pin->d_mcut : nullptr, stream));
-    SDY_STAGE(ST_LEG_FWD, legendre_fwd_impl(pin, Xf, Cs, B, E, polar_in, stream, tiled_in));
+    SDY_STAGE(ST_LEG_FWD, legendre_fwd_impl(pin, Xf, Cs, B, E, polar_in, stream, tiled_in, cs_tiled));
     if (scale_residual) {  // residual = inverse_transform(forward_transform(x))
-      SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream, tiled_out));
+      SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream, tiled_out, cs_tiled));
       SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
                                                polar_out ? pout->d_mcut : nullptr, stream));
     }
     if (bw.fw.frag)
-      SDY_STAGE(ST_DHCONV, sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, B, ilv, (hipStream_t)stream));
+      SDY_STAGE(ST_DHCONV, sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, B, ilv, (hipStream_t)stream,
+                                            cs_tiled ? 1 : 0));
     else if (c.gemm_mode == 1)
       SDY_STAGE(ST_DHCONV, sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     else
       SDY_STAGE(ST_DHCONV, sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
-    SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs2, Xf, B, E, polar_out, stream, tiled_out));
+    SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs2, Xf, B, E, polar_out, stream, tiled_out, cs_tiled));
     SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
                                              polar_out ? pout->d_mcut : nullptr, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y

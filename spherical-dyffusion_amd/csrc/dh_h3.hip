@@ -47,6 +47,9 @@ struct DhParams {
   const f16x8* w;                  // [l][8 waves][16 channel blocks][wr | wi][hi | lo][64 lanes]
   int L, mtr, B;
   int ilv;                         // order of the 2C axis: 0 = [ri][c], 1 = [c / 16][ri][16] (fft.h)
+  int tiled;                       // coefficient tensors TILE-MAJOR by order (ilv == 1 only): [m][column tile j][l][64] with
+                                   // j = b * 8 + (column / 64) -- row (m, b) of a degree is row index r = m B + b, its eight
+                                   // 64-column pieces sit at ((8 r + piece) L + l) * 64: no division, no per-degree stride
   float out_scale;
   unsigned* flags;                 // sticky status word (sdy_status_flags)
   unsigned long long* stamps;      // timing experiments only (SDY_DH_STAMPS)
@@ -111,7 +114,9 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
     int rr = r0;
     asm volatile("" : "+v"(rr));   // computed where it is used: 16 hoisted addresses would not fit the register budget
     const int row = it.t * DTN + rr + 8 * i;
-    return p.X + (long)it.l * p.sX + (unsigned)((row < dh_rows(p, it.l) ? row : 0) * DK + 8 * oc);
+    const int rc = row < dh_rows(p, it.l) ? row : 0;
+    if (p.tiled) return p.X + (unsigned)(((rc * 8 + (oc >> 3)) * p.L + it.l) * 64 + 8 * (oc & 7));
+    return p.X + (long)it.l * p.sX + (unsigned)(rc * DK + 8 * oc);
   };
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -242,8 +247,12 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
       const int scol = p.ilv ? 32 * (l31 >> 4) + (l31 & 15) : l31;   // + (ilv ? 16 : 32) * t
       const int tstep = p.ilv ? 16 : 32;
       const int gcol = p.ilv ? 64 * wave + 4 * sc4 : DE * (sc4 >> 3) + 32 * wave + 4 * (sc4 & 7);
-      float* og = p.out + (long)cur.l * p.sC + (long)row0 * DN;           // uniform: rows are added in SGPR arithmetic
-      const unsigned olane = (unsigned)(srow * DN + gcol) * 4u;             // the lane part of every store address
+      // tile-major: the wave's 64 outputs of a row are piece `wave` of that row; rows are 8 L 64 floats apart
+      const long orow = p.tiled ? 8L * p.L * 64 : (long)DN;
+      float* og = p.tiled ? p.out + ((long)row0 * 8 + wave) * p.L * 64 + (long)cur.l * 64
+                          : p.out + (long)cur.l * p.sC + (long)row0 * DN;   // uniform: rows are added in SGPR arithmetic
+      const unsigned olane = p.tiled ? (unsigned)(srow * orow + 4 * sc4) * 4u
+                                     : (unsigned)(srow * DN + gcol) * 4u;   // the lane part of every store address
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
           for (int hh = 0; hh < 2; ++hh) {
             const int row = 32 * j + 8 * g + srow + 4 * hh;
             const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (srow + 4 * hh) * 64 + 4 * sc4);
-            if (row0 + row < M) sdy_st16s(og + (long)(32 * j + 8 * g + 4 * hh) * DN, olane, v);
+            if (row0 + row < M) sdy_st16s(og + (long)(32 * j + 8 * g + 4 * hh) * orow, olane, v);
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -326,13 +335,14 @@ extern "C" int sdy_dhconv_frag_pack(const float* w_host, int L, void* packed_dev
 }
 
 int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B, int ilv,
-                      hipStream_t stream) {
+                      hipStream_t stream, int tiled) {
   if (!Cs_in || !packed || !Cs_out || L <= 0 || mtr <= 0 || B <= 0 || !(scale > 0.f)) return SDY_ERR_ARG;
+  if (tiled && (!ilv || (long)mtr * B * 8 * L * 64 >= (1L << 32))) return SDY_ERR_UNSUPPORTED;   // 32-bit element offsets
   DhParams p;
   p.X = Cs_in; p.sX = (long)mtr * B * DK;
   p.out = Cs_out; p.sC = (long)mtr * B * DN;
   p.w = reinterpret_cast<const f16x8*>(packed);
-  p.L = L; p.mtr = mtr; p.B = B; p.ilv = ilv ? 1 : 0;
+  p.L = L; p.mtr = mtr; p.B = B; p.ilv = ilv ? 1 : 0; p.tiled = tiled ? 1 : 0;
   p.out_scale = 1.0f / (scale * DSX);
   SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;
@@ -358,5 +368,5 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
 }
 extern "C" int sdy_dhconv_frag(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B,
                                void* stream) {
-  return sdy_dh_h3_launch(Cs_in, packed, scale, Cs_out, L, mtr, B, 0, (hipStream_t)stream);
+  return sdy_dh_h3_launch(Cs_in, packed, scale, Cs_out, L, mtr, B, 0, (hipStream_t)stream, 0);
 }

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle (torch ops) is the slow half of every parity test.  On the GPU box torch defaults to one thread per host
+    # CPU (256): the full-size oracle forward then takes ~25 s instead of the ~5 s it takes on 32 threads (bench.py's
+    # cpu_baseline uses the same cap) -- the 8-block C3 test went from 11 minutes to under 3.
+    import torch
+
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
 
 
 def pytest_collection_modifyitems(config, items):

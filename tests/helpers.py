@@ -1,7 +1,7 @@
 """Shared builders for the parity tests: a product network and an oracle network with the same weights."""
 import torch
 
-from oracle.philox import drop_path_keep, element_keep_mask
+from oracle.philox import drop_path_keep, element_keep_mask, element_keep_mask_torch
 from oracle.sfno import OracleSFNO, SFNOConfig, make_state_dict
 
 
@@ -31,6 +31,7 @@ class PhiloxMasks:
         self.cfg, self.seed, self.batch_offset = cfg, seed, batch_offset
         self.call = 0
         self.rows = None      # optional: global trajectory index of every batch row (overrides batch_offset + b)
+        self.device = None    # "cuda": evaluate the (torch restatement of the) stream on the GPU -- full-size, full-depth tests
 
     def __call__(self, kind, layer, shape):
         c = self.cfg
@@ -40,5 +41,8 @@ class PhiloxMasks:
             return torch.from_numpy(keep).reshape(-1, 1, 1, 1)
         B, C, H, W = shape
         k = 0 if kind == "mlp_hidden" else 1
+        if self.device is not None:
+            return element_keep_mask_torch(self.seed, self.call, layer, k, c.dropout_mlp, B, C, H, W, self.batch_offset,
+                                           self.rows, device=self.device)
         return torch.from_numpy(element_keep_mask(self.seed, self.call, layer, k, c.dropout_mlp, B, C, H, W,
                                                   self.batch_offset, self.rows))

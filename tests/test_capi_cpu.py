@@ -155,3 +155,17 @@ def test_dropout_streams_are_independent_across_members_kinds_calls_and_layers()
     assert np.all(np.abs(dp.mean(1) - 0.7) < 4 * np.sqrt(0.21 / 4096))
     rr = np.corrcoef(dp)
     assert np.abs(rr[~np.eye(4, dtype=bool)]).max() < 4.5 / np.sqrt(4096)
+
+
+def test_torch_restatement_of_the_dropout_stream_equals_the_numpy_one():
+    """oracle.philox.element_keep_mask_torch (int64 tensors, 16-bit limbs; what the full-depth GPU parity test evaluates on the
+    device for speed) against the numpy restatement, bit for bit, including a ragged pixel count and a batch offset."""
+    import torch
+
+    from oracle.philox import element_keep_mask, element_keep_mask_torch
+
+    for args in ((0xABCDEF0123456789, 3, 5, 1, 0.13, 2, 16, 7, 50, 5), (77, 1, 2, 0, 0.1, 1, 64, 45, 64, 0),
+                 (1000, 9, 7, 0, 0.1, 3, 8, 3, 21, 40)):
+        a = element_keep_mask(*args[:9], batch_offset=args[9])
+        b = element_keep_mask_torch(*args[:9], batch_offset=args[9])
+        assert torch.equal(torch.from_numpy(a), b), args

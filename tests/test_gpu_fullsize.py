@@ -50,6 +50,8 @@ def test_c3_full_size_sampling_pass_with_dropout_vs_oracle(layers):
     one forward's rounding (1.1e-6 per unit of amplification measured) all the way through the pass."""
     exp, fnet, inet, fora, iora, icfg = _build(layers=layers)
     masks = PhiloxMasks(icfg, seed=1000)
+    if layers > 2:
+        masks.device = "cuda"   # 160 masks of 33 M decisions: the torch restatement of the stream, evaluated on the GPU
     n = {"i": 0}
 
     def ora_i(x, time, condition=None, static_condition=None):
