@@ -45,7 +45,6 @@ struct ParParams {
   const int* kdead;              // polar cut-off per order (rows k' < kdead[m] and their mirrors are skipped) or nullptr
   float out_scale;
   unsigned long long* stamps;    // timing experiments only (SDY_LEG_STAMPS): [4 sampled workgroups][3 waves][8]
-  int pf_dist;                   // > 0: L2 prefetch of the input tile of workgroup (linear id + pf_dist), tile-major inputs only
 };
 
 // same swizzle as leg_h3.hip: 16-byte chunk c (0..23) of column px
@@ -66,7 +65,6 @@ __device__ __forceinline__ void st4s(float* ubase, unsigned off_b, float v) {
 template <bool FWD, bool STAMPS>
 __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PTN * PKP * 2];   // 48 KB
-  __shared__ unsigned pf_sink[3 * 64];   // landing area of the L2-prefetch loads below (never read)
   _Float16* Xs_hi = reinterpret_cast<_Float16*>(smem);
   _Float16* Xs_lo = Xs_hi + PTN * PKP;
 
@@ -186,30 +184,7 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
   }
   __syncthreads();
   stamp(3);   // tile in LDS
-  // L2 PREFETCH (round 4 experiment, SDY_LEG_PREFETCH=<distance>): the kernel is limited by the bytes a CU keeps in flight
-  // (three workgroups x 49 KB at best), not by the memory system, so each workgroup also touches -- one 4-byte LDS-DMA load per
-  // 128-byte line, no register, 8 KB of lines per wave instruction -- the input tile of the workgroup that will run
-  // `pf_dist` ids later on the same XCD (pf_dist % 8 == 0): its row loads then hit L2 instead of HBM.  Issued where no
-  // later wait of this wave can queue behind it (dead waves: here; live waves: behind the MFMA loop, before the stores).
-  auto l2_prefetch = [&]() {
-    if (p.pf_dist <= 0 || !p.tsx) return;
-    const int lin = z * (int)gridDim.x + (int)blockIdx.x + p.pf_dist;
-    const int zt = __builtin_amdgcn_readfirstlane(lin / (int)gridDim.x);
-    if (zt >= (int)gridDim.y) return;
-    const int bt = __builtin_amdgcn_readfirstlane(lin - zt * (int)gridDim.x);
-    const int kdt = (FWD && p.kdead) ? __builtin_amdgcn_readfirstlane(p.kdead[zt]) : 0;
-    // live rows of that tile: analysis [kd, K - kd) latitudes, synthesis [m, K) degrees; rows are 256 bytes (tile-major)
-    const int r0 = FWD ? kdt : zt, r1 = FWD ? p.K - kdt : p.K;
-    const char* base = reinterpret_cast<const char*>(p.X + (long)zt * p.sX + (long)bt * p.tsx) + (long)r0 * 256;
-    const int nlines = (r1 - r0) * 2;
-    for (int ln = tid; ln < nlines; ln += 192)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (long)ln * 128),
-                                       (__attribute__((address_space(3))) void*)(pf_sink + 64 * wave), 4, 0, 0);
-  };
-  if (wave_dead) {   // (after the only barrier)
-    l2_prefetch();
-    return;
-  }
+  if (wave_dead) return;   // (after the only barrier)
 
   f32x16 acc[2][2];   // [half: E, O][column tile]
 #pragma unroll
@@ -252,7 +227,6 @@ __global__ __launch_bounds__(192, 3) void leg_par_kernel(const ParParams p) {
     __builtin_amdgcn_sched_barrier(0);
   }
   stamp(4);   // MFMA loop done
-  l2_prefetch();
 
   // ---- epilogue: accumulators -> global.  Register r of a tile is row 8 (r >> 2) + 4 h + (r & 3) of the wave's 32, lanes
   // l31 are 32 consecutive columns: one store instruction writes two 128-byte row segments.  Row = uniform part (SGPR
@@ -412,8 +386,6 @@ int sdy_leg_par_launch(const void* table, float scale, int nz, const float* X, l
   p.rows_out = rows_out; p.K = K; p.N = N; p.kdead = kdead;
   p.out_scale = 1.0f / (scale * PSX);
   p.stamps = nullptr;
-  static const int pf_env = std::getenv("SDY_LEG_PREFETCH") ? std::atoi(std::getenv("SDY_LEG_PREFETCH")) : 0;
-  p.pf_dist = (pf_env > 0 && tsx) ? (pf_env & ~7) : 0;
   dim3 grid((N + PTN - 1) / PTN, nz);
 #if SDY_STAMPS_ON
   if (std::getenv("SDY_LEG_STAMPS")) {
