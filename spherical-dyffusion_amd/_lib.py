@@ -215,6 +215,12 @@ SIGNATURES = {
 
 
 def _load():
+    # torch first: PyTorch-ROCm ships its own libamdhip64, and the process must end up with ONE HIP runtime.  Loaded after
+    # torch, libsdy_amd.so binds to the runtime torch already brought in (same soname); loaded BEFORE it, the library pulls
+    # /opt/rocm's copy, torch adds its own, and every sdy_* call then fails with "no ROCm-capable device is detected"
+    # (seen on the GPU box with `import sdy_amd` ahead of `import torch`).
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP library is required (no CPU/PyTorch fallback exists). "
