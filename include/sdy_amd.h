@@ -234,7 +234,11 @@ int sdy_mlp_h3(const sdy_mlp_args* args, void* stream);
 /* Two 1x1 convolutions with a GELU between them in ONE launch -- the encoder (src/models/sfno/sfnonet.py:609-618, with the
  * position embedding of :824 as the addend) and the decoder (:734-744 on [block output | inputs], :831-837):
  *   out[b] = W2 . GELU( W1 . x[b] + b1 ) + add[b or broadcast]
- * The 256-channel hidden activation stays on the compute unit.  Split-fp16 arithmetic of sdy_conv1x1 (w_h3).  Supported
+ * The 256-channel hidden activation stays on the compute unit.  Split-fp16 arithmetic of sdy_conv1x1 (w_h3), except that the
+ * activations are not staged with the fixed pre-scale: x by a power of two per 64-pixel tile (and channel part) from the tile's
+ * own maximum, the hidden activation by one from the bound max_row ||W1 row||_1 * max|x| + max|b1| (the L1 norm is computed by
+ * sdy_pair_h3_pack and travels in the last 64 bytes of the packed buffer).  Inputs of any finite magnitude keep 22 bits
+ * relative to their tile's maximum; SDY_FLAG_F16_RANGE is never raised here, SDY_FLAG_NONFINITE is for inf / NaN inputs.  Supported
  * shapes (sdy_pair_h3_supported): hidden == 256 and either Cout == 256 with Cin <= 144, or Cout <= 64 with Cin <= 416;
  * anything else returns SDY_ERR_UNSUPPORTED and the caller issues two sdy_conv1x1 calls. */
 typedef struct sdy_pair_args {

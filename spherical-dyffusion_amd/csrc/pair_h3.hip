@@ -21,6 +21,7 @@
 // for every tile, and position g's slot is refilled with group g + 16 right behind g's last MFMA.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -51,8 +52,10 @@ struct PairCfg {
   static constexpr int KMAX = 16 * KSP * NPART;           // input channels
   static constexpr size_t XS_BYTES = (size_t)2 * PTN * XROW * 2;
   static constexpr size_t HS_BYTES = (size_t)4 * PTN * PHC * 2;
-  static constexpr size_t LDS_BYTES = XS_BYTES + HS_BYTES + PH * 4;
+  static constexpr size_t LDS_BYTES = XS_BYTES + HS_BYTES + PH * 4 + 64;   // + 8 wave maxima of the tile's dynamic scale
+  static constexpr size_t STREAM_BYTES = (size_t)4 * (NPAD + PRING) * PGROUP * 16;   // weight stream; 64 bytes of tail follow
   static_assert(N >= PRING, "the first ring fill takes 16 real groups");
+  static_assert(NPART <= 2, "two slots of part maxima in LDS");
   static_assert(MO == 8 || XS_BYTES >= (size_t)64 * PTN * 4, "the 64-row output tile is staged in the x tile's storage");
 };
 
@@ -69,7 +72,8 @@ struct PairParams {
   float* out; long out_bs; int Cout;
   const float* add; long add_bs;
   int HW, B;
-  float s1, s2;                            // accumulator scales: 1 / (w_scale * PSX)
+  float s1, s2;                            // accumulator scales: 1 / w1_scale (the x tile's own scale joins per tile) and
+                                           // 1 / (w2_scale * PSX)
   double* stats;                           // optional [B][256][2] (MO == 8 only)
   unsigned* flags;
   unsigned long long* stamps;              // timing experiments only (SDY_PAIR_STAMPS)
@@ -78,7 +82,26 @@ struct PairParams {
 __device__ __forceinline__ int hs_swz(int px) { return (px & 15) ^ (((px >> 4) & 1) * 3); }   // (mlp_h3.hip, px_swz)
 __device__ __forceinline__ int hs_off(int px, int c) { return px * PHC + (((c ^ hs_swz(px)) & 15) << 3); }
 
-struct Piece { float v[4], t[4], e[4], q[4]; };
+// (a workgroup-uniform float the compiler would otherwise carry in a VGPR)
+__device__ __forceinline__ float sgpr_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+// Maximum of a wave's NON-NEGATIVE values by DPP (row shifts, then the two row broadcasts of gfx9): valid in lane 63.
+// (__shfl_xor is six dependent ds_bpermute round trips -- with one wave per SIMD every one of them is exposed.)
+#define SDY_DPP_MAX(v, ctrl, rmask)                                                                                         \
+  v = __builtin_fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, true)))
+__device__ __forceinline__ float wave_max_nonneg_l63(float v) {
+  SDY_DPP_MAX(v, 0x111, 0xF);   // row_shr:1
+  SDY_DPP_MAX(v, 0x112, 0xF);   // row_shr:2
+  SDY_DPP_MAX(v, 0x114, 0xF);   // row_shr:4
+  SDY_DPP_MAX(v, 0x118, 0xF);   // row_shr:8   -> lane 15 of every row holds its row's maximum
+  SDY_DPP_MAX(v, 0x142, 0xA);   // row_bcast:15 into rows 1 and 3
+  SDY_DPP_MAX(v, 0x143, 0xC);   // row_bcast:31 into rows 2 and 3 -> lane 63
+  return v;
+}
+#undef SDY_DPP_MAX
+
+struct Piece { float v[4], vr[4], t[4], e[4], q[4]; };   // vr = v * (this tile's hidden scale r <= 1, see the kernel)
 constexpr float G_CT = 0.3275911f * 0.70710678118654752440f, G_KAP = -0.5f * 1.44269504088896340736f, G_HS = 0.5f * PSX;
 constexpr float G_A5 = 1.061405429f * G_HS, G_A4 = -1.453152027f * G_HS, G_A3 = 1.421413741f * G_HS,
                 G_A2 = -0.284496736f * G_HS, G_A1 = 0.254829592f * G_HS;
@@ -124,11 +147,11 @@ __device__ __forceinline__ void gelu_slot(Piece& s, int st) {
     case 8:
       s.q[2] = fmaf(-s.q[2], s.e[2], G_HS); s.q[3] = fmaf(-s.q[3], s.e[3], G_HS);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s.q[r] *= __builtin_fabsf(s.v[r]);
+      for (int r = 0; r < 4; ++r) s.q[r] *= __builtin_fabsf(s.vr[r]);
       break;
-    case 9:
+    case 9:   // r * PSX * gelu(v) = HS (r v) + |r v| (HS - Q(v))
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s.v[r] = fmaf(s.v[r], G_HS, s.q[r]);
+      for (int r = 0; r < 4; ++r) s.v[r] = fmaf(s.vr[r], G_HS, s.q[r]);
       break;
     case 10:   // fp16 hi and the fp32 remainder (kept in e / t for the last slot)
 #pragma unroll
@@ -151,6 +174,7 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
   _Float16* Xs_lo = Xs_hi + PTN * XROW;
   _Float16* Hs = reinterpret_cast<_Float16*>(smem + Cfg::XS_BYTES);   // [chunk][hi | lo][px][PHC]
   float* Cb1 = reinterpret_cast<float*>(smem + Cfg::XS_BYTES + Cfg::HS_BYTES);
+  float* Am = Cb1 + PH;   // [12]: the four waves' maxima of part 0 / part 1 of the x tile (0..3 / 4..7), of |b1| (8..11)
   float* Os = MO == 8 ? reinterpret_cast<float*>(Hs) : reinterpret_cast<float*>(smem);   // output tile [rows][64 px]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -192,10 +216,13 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
   // last real channel.  Issued as ONE burst where nothing that is needed soon queues up behind it (vmcnt retires in order):
   // spread one behind an MFMA each, every ring refill issued after an x load waits for HBM instead of L2 (measured: the
   // decoder's fc1 4.6k -> 8.9k cycles).
+  bool x_ok = true;
+  bool bad = false;   // a non-finite value met in some x tile: raised as SDY_FLAG_NONFINITE when the kernel leaves
   auto load_x = [&](int t, int part) {
     const int tu = __builtin_amdgcn_readfirstlane(t);   // (workgroup-uniform; the base below must sit in SGPRs)
     const int zz = tu / tpi, nn = (tu - zz * tpi) * PTN;
     const bool ok = nn + 4 * q0 < p.HW;
+    x_ok = ok;
     const float* xz = p.x + (long)zz * p.x_bs;
     const unsigned pxo = (unsigned)(ok ? nn + 4 * q0 : 0);
 #pragma unroll
@@ -207,9 +234,37 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
         xr[i][e] = sdy_ld16s(xz, ((unsigned)ch * (unsigned)p.HW + pxo) * 4u);
       }
   };
-  auto split_x_impl = [&](int part, int n0, bool full, auto plain_t) {
+  // DYNAMIC SCALE of the x tile (round 4).  The encoder and the decoder are where un-normalised tensors enter the network -- user
+  // data, the last block's output -- so their x tile is not staged with the fixed pre-scale of the other kernels (overflow at
+  // |x| >= 4094, subnormal `lo` parts below 0.01) but with a power of two chosen per tile and part from its own maximum:
+  // max |x| * sx in [2^11, 2^12).  Any finite input magnitude keeps 22 significant bits relative to its tile's maximum; the
+  // factor leaves again through the accumulator scale.  `part_amax`: this thread's values -> the workgroup's maximum
+  // (wave reduction, one LDS word per wave and part).  It runs where the part's loads have landed anyway and a barrier the
+  // kernel has already stands between it and the reader: behind the previous part's MFMA loop (part > 0), behind fc2 of the
+  // previous tile (part 0) -- computed in front of the split, with a barrier of its own, the decoder was 13 % slower.
+  auto part_amax = [&](int part) {
+    // Branch-free (a select per value made the compiler wrap every load's wait in its own exec-masked block): the maximum over
+    // everything this thread loaded, then one AND per octet round drops the lanes whose loads were stand-ins -- pixels past the
+    // row's end (x_ok, of the tile the registers were loaded for) and the idle lanes of the last octet round.  Channels past Cin
+    // repeat the last real channel of this tile: they do not change the maximum.
+    float am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float a = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const f32x4 v = xr[i][e];
+        a = __builtin_fmaxf(a, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)),
+                                               __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+      }
+      const int keep = (x_ok && o0 + 16 * i < 2 * KSP) ? -1 : 0;
+      am = __builtin_fmaxf(am, __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep));
+    }
+    am = wave_max_nonneg_l63(am);
+    if (lane == 63) Am[4 * part + wave] = am;
+  };
+  auto split_x_impl = [&](int part, int n0, bool full, float sx, auto plain_t) {
     constexpr bool plain = decltype(plain_t)::value;   // a full tile of real channels: no select per value
-    float amax = 0.0f;
     // The decoder is the one consumer of the last block's output, which meets no InstanceNorm (whose statistics flag non-finite
     // tensors everywhere else), and the max-based range guard ignores NaNs: here a sum of magnitudes goes NaN / inf with them.
     float nansum = 0.0f;
@@ -225,8 +280,8 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            v[e] = (plain || (ok && 16 * KSP * part + 8 * o + e < p.Cin)) ? xr[i][e][pp] * PSX : 0.0f;
-          sdy_split8(v, vh, vl, amax);
+            v[e] = (plain || (ok && 16 * KSP * part + 8 * o + e < p.Cin)) ? xr[i][e][pp] * sx : 0.0f;
+          sdy_split8(v, vh, vl);
           if (MO != 8) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) nansum += __builtin_fabsf(v[e]);
@@ -236,16 +291,21 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
         }
       }
     }
-    sdy_flag_range(p.flags, amax);
-    if (MO != 8 && p.flags && !(nansum <= 3.0e38f)) atomicOr(p.flags, (unsigned)SDY_FLAG_NONFINITE);
+    if (MO != 8) bad |= !(nansum <= 3.0e38f);
   };
-  auto split_x = [&](int part, int n0, bool full) {
-    if (full && 16 * KSP * (part + 1) <= p.Cin) split_x_impl(part, n0, full, std::true_type{});   // (workgroup-uniform)
-    else split_x_impl(part, n0, full, std::false_type{});
+  auto split_x = [&](int part, int n0, bool full, float sx) {
+    if (full && 16 * KSP * (part + 1) <= p.Cin) split_x_impl(part, n0, full, sx, std::true_type{});   // (workgroup-uniform)
+    else split_x_impl(part, n0, full, sx, std::false_type{});
   };
 
   Cb1[tid] = p.b1 ? p.b1[tid] : 0.0f;
-  if (t_begin < t_end) load_x(t_begin, 0);
+  {   // max |b1| (with the L1 bound of W1 below: a bound of the hidden activation from the x tile's maximum)
+    const float bm = wave_max_nonneg_l63(__builtin_fabsf(p.b1 ? p.b1[tid] : 0.0f));
+    if (lane == 63) Am[8 + wave] = bm;
+  }
+  // max over the hidden rows of sum_k |W1[row][k]|, stored behind the weight stream by sdy_pair_h3_pack
+  const float w1_l1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.w) + Cfg::STREAM_BYTES);
+  if (t_begin < t_end) { load_x(t_begin, 0); part_amax(0); }
   double psum[MO == 8 ? 16 : 1], psq[MO == 8 ? 16 : 1];
 #pragma unroll
   for (int i = 0; i < (MO == 8 ? 16 : 1); ++i) { psum[i] = 0.0; psq[i] = 0.0; }
@@ -270,6 +330,14 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.0f;
+    // Per-tile scales (set when the last part is staged, before the first chain slot runs):
+    //   s1_t = 1 / (w1_scale * sx): the fc1 accumulators hold w1_scale * sx * (W1 . x);
+    //   r_t (a power of two): the hidden activation is staged as r_t * PSX * GELU(.), with r_t the largest power of two
+    //         that keeps the BOUND |hidden| <= max_row ||W1 row||_1 * max |x| + max |b1| below 2^15 after the PSX --
+    //         below 1 for |x| of a few hundred and more (no fp16 overflow), above 1 for small tiles (their `lo` parts stay
+    //         normal fp16 numbers); fc2's accumulator scale takes the 1 / r_t.
+    int se = 127;
+    float am_all = 0.0f, s1_t = p.s1, r_t = 1.0f, s2_t = p.s2;
 
     // ---- chain: bias + GELU + split of the accumulators -> hidden chunk in LDS, 8 pieces (pixel tile j, row group g4) of
     //      12 slots each
@@ -292,7 +360,9 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
       if (st == 0) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(Cb1 + PHC * c + 32 * wave + 4 * h + 8 * g4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s.v[r] = fmaf(acc[c][j][4 * g4 + r], p.s1, b4[r]);
+        for (int r = 0; r < 4; ++r) s.v[r] = fmaf(acc[c][j][4 * g4 + r], s1_t, b4[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.vr[r] = s.v[r] * r_t;
       } else if (st < 11) {
         gelu_slot(s, st);
       } else {
@@ -313,8 +383,49 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
     constexpr int NPI = !kChainInFc1 ? 0 : (KSP / 2 < 8 ? KSP / 2 : 8);
 #pragma unroll
     for (int part = 0; part < NPART; ++part) {
-      if (part > 0) __syncthreads();          // every wave is done reading the previous part
-      split_x(part, n0, full);
+      if (part > 0) __syncthreads();          // every wave is done reading the previous part (and has left its maximum)
+      // All of the scale arithmetic is on exponents (powers of two, workgroup-uniform -> scalar unit): no division.
+      const float am = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int,
+          __builtin_fmaxf(__builtin_fmaxf(Am[4 * part], Am[4 * part + 1]), __builtin_fmaxf(Am[4 * part + 2], Am[4 * part + 3])))));
+      const int e = (__builtin_bit_cast(int, am) >> 23) & 0xFF;            // (am >= 0)
+      bad |= e == 255;   // inf (NaNs: split_x / the statistics)
+      // biased exponent of the power of two that puts am into [2^11, 2^12); 2^0 for a zero / subnormal / non-finite maximum
+      int se_new = 265 - e;
+      se_new = (e == 0 || e == 255) ? 127 : (se_new < 1 ? 1 : (se_new > 253 ? 253 : se_new));
+      if (part > 0) {
+        // A later part keeps the scale of the one before it where its own maximum then lies in [2^8, 2^15) (22 bits relative
+        // to the maximum all the same) -- nearly always; otherwise the accumulators, which hold sx * (W1 . x) of the earlier
+        // parts, move to the new scale (exact).
+        const int te = e + se - 127;
+        if (e == 0 || (te >= 127 + 8 && te < 127 + 15)) se_new = se;
+        if (se_new != se) {
+          int d = se_new - se;
+          d = d < -126 ? -126 : (d > 127 ? 127 : d);
+          const float ratio = __builtin_bit_cast(float, (127 + d) << 23);
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[c][j][r] *= ratio;
+        }
+      }
+      se = se_new;
+      const float sx = __builtin_bit_cast(float, se << 23);
+      am_all = sgpr_f(__builtin_fmaxf(am_all, am));
+      if (part == NPART - 1) {
+        s1_t = sgpr_f(p.s1 * __builtin_bit_cast(float, (254 - se) << 23));      // p.s1 / sx
+        const float bmax = __builtin_fmaxf(__builtin_fmaxf(Am[8], Am[9]), __builtin_fmaxf(Am[10], Am[11]));
+        const float hb = fmaf(w1_l1, am_all, bmax);                      // bound of |hidden| on this tile
+        const int eh = (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hb)) >> 23) & 0xFF;
+        // hb < 2^(eh - 126): r = 2^(137 - eh) keeps PSX * r * |hidden| < 2^15; at most 2^40 (an all-zero tile and bias), 1 for
+        // a non-finite bound (flagged above or by split_x)
+        int re = 264 - eh;
+        re = eh == 255 ? 127 : (re > 167 ? 167 : (re < 1 ? 1 : re));
+        r_t = __builtin_bit_cast(float, re << 23);
+        s2_t = sgpr_f(p.s2 * __builtin_bit_cast(float, (254 - re) << 23));      // p.s2 / r_t
+      }
+      split_x(part, n0, full, sx);
       if (part + 1 < NPART) load_x(tile, part + 1);   // the x registers are free: they take the next part
       __syncthreads();
       stamp(1 + 2 * part);
@@ -375,6 +486,7 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
           }
         });
       }
+      if (part + 1 < NPART) part_amax(part + 1);   // (its loads were issued in front of this part's MFMA loop)
     }
     stamp(4);
     chain_alone(0, NPI);
@@ -468,6 +580,7 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
       }
     }
     stamp(12);
+    part_amax(0);   // the next tile's first part (loaded beside fc2's second chunk); the barriers below publish it
     // the holes of the numbering: their slots take the next tile's first groups
 #pragma unroll
     for (int g = N; g < NPAD; ++g) refill(g, 2);
@@ -489,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            Os[(row0 + (r & 3) + 8 * (r >> 2)) * PTN + 32 * j + l31] = oacc[mi][j][r] * p.s2;
+            Os[(row0 + (r & 3) + 8 * (r >> 2)) * PTN + 32 * j + l31] = oacc[mi][j][r] * s2_t;
       }
       __syncthreads();
       stamp(9);
@@ -531,7 +644,7 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
       {
         const int row0 = 32 * (wave >> 1) + 4 * h, px = 32 * (wave & 1) + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Os[(row0 + (r & 3) + 8 * (r >> 2)) * PTN + px] = oacc[0][0][r] * p.s2;
+        for (int r = 0; r < 16; ++r) Os[(row0 + (r & 3) + 8 * (r >> 2)) * PTN + px] = oacc[0][0][r] * s2_t;
       }
       __syncthreads();
       stamp(9);
@@ -552,6 +665,7 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
     stamp(10);
     __syncthreads();   // the output tile's storage (hidden chunks / x tile) is free for the next tile
   }
+  if (bad && p.flags) atomicOr(p.flags, (unsigned)SDY_FLAG_NONFINITE);   // (once, outside the tile loop: no live state across it)
 }
 
 float pick_scale(const float* w, size_t n) {   // power of two that puts max|w| in [2^12, 2^13)
@@ -590,14 +704,25 @@ bool pick_shape(int Cin, int hidden, int Cout, Shape* s) {
   return false;
 }
 
+// (the weight stream + 64 bytes of tail: [0] = max over the hidden rows of sum_k |W1[row][k]|, float)
 template <int KSP, int NPART, int MO>
-size_t pack_bytes() { return (size_t)4 * (PairCfg<KSP, NPART, MO>::NPAD + PRING) * PGROUP * sizeof(f16x8); }
+size_t pack_bytes() { return PairCfg<KSP, NPART, MO>::STREAM_BYTES + 64; }
 
 template <int KSP, int NPART, int MO>
 void pack(const float* w1, const float* w2, int Cin, int Cout, float s1, float s2, std::vector<_Float16>& buf) {
   using Cfg = PairCfg<KSP, NPART, MO>;
   const size_t gh = (size_t)PGROUP * 8;   // halfs per group
-  buf.assign((size_t)4 * (Cfg::NPAD + PRING) * gh, (_Float16)0.0f);
+  static_assert(Cfg::STREAM_BYTES == (size_t)4 * (Cfg::NPAD + PRING) * PGROUP * 8 * sizeof(_Float16), "stream size");
+  buf.assign((size_t)4 * (Cfg::NPAD + PRING) * gh + 32, (_Float16)0.0f);   // + 64 bytes of tail
+  {
+    float l1 = 0.0f;
+    for (int r = 0; r < PH; ++r) {
+      double acc = 0.0;
+      for (int k = 0; k < Cin; ++k) acc += std::fabs((double)w1[(size_t)r * Cin + k]);
+      l1 = std::fmax(l1, (float)acc);
+    }
+    std::memcpy(buf.data() + (size_t)4 * (Cfg::NPAD + PRING) * gh, &l1, sizeof(float));
+  }
   for (int w = 0; w < 4; ++w) {
     _Float16* base = buf.data() + (size_t)w * (Cfg::NPAD + PRING) * gh;
     _Float16* d = base;
@@ -707,7 +832,7 @@ extern "C" int sdy_pair_h3(const sdy_pair_args* a, void* stream) {
   p.out = a->out; p.out_bs = a->out_bstride; p.Cout = a->Cout;
   p.add = a->add; p.add_bs = a->add_bstride;
   p.HW = a->HW; p.B = a->B;
-  p.s1 = 1.0f / (a->w1_scale * PSX);
+  p.s1 = 1.0f / a->w1_scale;   // (the x tile's dynamic scale joins per tile)
   p.s2 = 1.0f / (a->w2_scale * PSX);
   p.stats = a->stats;
   SDY_TRY(sdy_flags_ptr(&p.flags));

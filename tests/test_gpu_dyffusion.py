@@ -309,8 +309,11 @@ def test_sharding_invariance_of_trajectories():
 
 @pytest.mark.parametrize("mode", ["h3", "f32"])
 def test_stepper_raises_on_fp16_range_overflow(mode, monkeypatch):
-    """|x| = 1e4 after normalisation: the split-precision path cannot represent it (x16 -> fp16 overflow) and the window
-    must fail loudly, naming the fp32 mode; the fp32-MFMA path runs the same data."""
+    """|x| = 1e4 after normalisation on a network of the GENERIC width (E = 16: the tile GEMM kernels with the fixed x16
+    pre-scale; the production width's fused encoder / decoder scale their tiles dynamically and take such inputs, see
+    tests/test_gpu_sfno.py::test_network_inputs_of_any_magnitude_in_split_fp16_mode): the split-precision tile kernels
+    cannot represent it (x16 -> fp16 overflow) and the window must fail loudly, naming the fp32 mode -- before anything
+    reaches a writer; the fp32-MFMA path runs the same data."""
     import sdy_amd
     from sdy_amd._lib import SdyError
 

@@ -167,3 +167,27 @@ def test_c2_full_size_interpolator_forward_with_dropout():
     # the masks matter at this depth: the next call of the stream gives a visibly different field
     again = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
     assert rel_l2(again, ref) > 1e-3
+
+
+@pytest.mark.parametrize("scale", [1.0e4, 3.0e2])
+def test_network_inputs_of_any_magnitude_in_split_fp16_mode(scale):
+    """|x| = 1e4 (and 300: where round 3's hidden activations overflowed first) in the default split-fp16 mode, production width (E = 256: the fused encoder / decoder kernels),
+    against the oracle: the un-normalised tensors -- the inputs at the encoder, [block output | inputs] at the decoder -- are
+    staged with a per-tile scale of their own maximum, everything between is InstanceNorm'ed, so the network no longer
+    needs inputs below 4094: parity at the network tolerance and a clean status word.
+    (The fixed pre-scale of round 3 raised SdyError here and sent the user to SDY_GEMM_MODE=f32.)"""
+    import sdy_amd
+
+    cfg = SFNOConfig(in_chans=10, out_chans=6, nlat=32, nlon=64, embed_dim=256, num_layers=2, with_time_emb=True,
+                     min_time=0.0, max_time=5.0)
+    net, ora, _ = make_pair(cfg, 8, 2)
+    assert net.gemm_mode == "h3"
+    x, cond = _inputs(cfg, 8, 2, 2)
+    x, cond = x * scale, cond * scale
+    t = torch.tensor([1.0, 4.0])
+    sdy_amd.ops.status_flags(reset=True)
+    got = net(x.cuda(), time=t.cuda(), condition=cond.cuda())
+    assert sdy_amd.ops.status_flags(reset=True) == 0
+    ref = ora(x, time=t, condition=cond)
+    err = rel_l2(got, ref)
+    assert err < TOL_TIGHT, f"inputs x {scale:g}: rel L2 {err:.3e}"
