@@ -926,7 +926,7 @@ WsLayout ws_layout(const sdy_sfno* n, int B) {
   w.ste = take((size_t)B * E * 4);   // the encoder output's statistics (block 0's norm0), kept for reuse_encoder
   w.ss = take((size_t)B * c.num_layers * 2 * E);
   w.dp = take((size_t)B * c.num_layers);
-  w.trep = take((size_t)B * (c.with_time_emb ? c.time_dim : 1));
+  w.trep = take((size_t)2 * B * (c.with_time_emb ? c.time_dim : 1));   // t_repr, then the time MLP's hidden layer
   w.total = off;
   return w;
 }
@@ -954,7 +954,12 @@ extern "C" int sdy_sfno_time_embed(sdy_sfno* n, const float* time, int B, float*
   SDY_TRY(sdy_sfno_ready(n));
   if (!n->cfg.with_time_emb) return SDY_ERR_UNSUPPORTED;
   if (!ss) return SDY_ERR_ARG;
-  return sdy_time_mlp_launch(n->tm, time, B, t_repr, ss, nullptr, nullptr, 0, 0, 0, 0, 0, (hipStream_t)stream);
+  // (not on the forward's path, which carries the scratch in its workspace: a stream-ordered allocation will do)
+  float* scratch = nullptr;
+  SDY_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)2 * B * n->cfg.time_dim * sizeof(float), (hipStream_t)stream));
+  const int rc = sdy_time_mlp_launch(n->tm, time, B, t_repr, ss, nullptr, nullptr, 0, 0, 0, 0, 0, (hipStream_t)stream, scratch);
+  SDY_HIP_TRY(hipFreeAsync(scratch, (hipStream_t)stream));
+  return rc;
 }
 
 // ---- stage timing of the forward (measurement only; off by default) ------------------------------------------------
@@ -1088,7 +1093,8 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   if (a->rows_per_call < 0 || (a->rows_per_call > 0 && B % a->rows_per_call)) return SDY_ERR_ARG;
   const int rpc = a->rows_per_call > 0 ? a->rows_per_call : B;   // stacked calls (sdy_sfno_fwd_args.rows_per_call)
   SDY_STAGE(ST_TIME_MLP, sdy_time_mlp_launch(n->tm, a->time, B, trep, ss, dp, a->drop_path_keep, drop ? 1 : 0, a->seed,
-                                             a->call, a->batch_offset, rpc, stream));
+                                             a->call, a->batch_offset, rpc, stream,
+                                             trep + (size_t)B * (n->cfg.with_time_emb ? n->cfg.time_dim : 1)));
 
   sdy_conv_args cv;
   static const bool no_frag = std::getenv("SDY_NO_CONV_FRAG") != nullptr;

@@ -23,8 +23,9 @@ int sdy_instnorm_coeffs_launch(const float* x, int B, int C, int HW, const float
 int sdy_concat_launch(const float* const* src, const int* chans, int nsrc, float* out, long out_bstride, int B, int HW,
                       hipStream_t stream);
 int sdy_cold_update_launch(const float* xs, const float* xn, const float* xi, float* out, size_t n, hipStream_t stream);
+// scratch: dev, B * T floats (2 B T when trep is NULL) -- the hidden layer between the launches
 int sdy_time_mlp_launch(const SdyTimeMlp& t, const float* time, int B, float* trep, float* ss, float* dp,
                         const float* dp_keep_in, int enable_dropout, uint64_t seed, uint32_t call,
-                        uint32_t batch_offset, int rows_per_call, hipStream_t stream);
+                        uint32_t batch_offset, int rows_per_call, hipStream_t stream, float* scratch);
 int sdy_spec_to_torch_launch(const float* Cs, float* out, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);
 int sdy_torch_to_spec_launch(const float* in, float* Cs, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);

@@ -140,76 +140,119 @@ __global__ __launch_bounds__(256) void cold_update_kernel(const float* __restric
 // ---- time embedding ---------------------------------------------------------------------------------------
 // SinusoidalPosEmb -> Linear -> GELU -> Linear (src/models/modules/misc.py:21-33,132-148), then per block
 // SiLU -> Linear (src/models/sfno/sfnonet.py:210-213,280-284); also the per-(sample, layer) drop-path scale
-// (src/models/modules/drop_path.py:15-22).  grid (num_layers + 1, B): block y=b, x<num_layers computes that
-// layer's (scale|shift); x == num_layers writes t_repr.  Every workgroup recomputes t_repr (0.4 MFLOP).
-// All weights are stored transposed ([in][out]) so consecutive threads read consecutive addresses.
-__global__ __launch_bounds__(256) void time_mlp_kernel(const SdyTimeMlp t, const float* __restrict__ time,
-                                                        float* __restrict__ trep_out, float* __restrict__ ss_out,
-                                                        float* __restrict__ dp_out, const float* __restrict__ dp_keep_in,
-                                                        int enable_dropout, uint32_t seed_lo, uint32_t seed_hi,
-                                                        uint32_t call, uint32_t batch_offset, int rows_per_call) {
-  extern __shared__ float sm[];
-  const int E = t.E, T = t.T, L = t.num_layers;
-  float* emb = sm;         // [E]
-  float* h1 = emb + E;     // [T]
-  float* tr = h1 + T;      // [T]
-  const int layer = blockIdx.x, b = blockIdx.y;
-  const float tv = time[b];
-  const int half = E / 2;
-  for (int i = threadIdx.x; i < E; i += 256) {
-    const float f = t.freq[i < half ? i : i - half];
-    const float arg = tv * f;
-    emb[i] = i < half ? sinf(arg) : cosf(arg);
-  }
-  __syncthreads();
-  // A dot product is a chain of L2 round trips, `unroll` terms per trip: four independent partial sums of 16 terms each keep 64
-  // loads in flight per thread (one accumulator with 16: 0.10 ms per launch, which is 1.3 % of a pass at the B = 3 of an 8-GPU
-  // rank; the fully serial version 0.27 ms).  The sum order differs from a single chain by fp32 rounding only.
-  auto dot4 = [&](const float* __restrict__ wt, long ld, const float* __restrict__ v, int n, int o, float init) {
-    float a0 = init, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    const int n4 = n & ~63;
-    for (int i = 0; i < n4; i += 64) {
+// (src/models/modules/drop_path.py:15-22).
+// Three launches of one dense-layer kernel (h1 = GELU(W1 emb + b1), t_repr = W2 h1 + b2, (scale|shift)_l = Wb_l SiLU(t_repr) +
+// bb_l): a workgroup owns 64 output columns and 8 batch rows, its four waves split the contraction, so every weight is read
+// once per 8 rows and the three layers' 7 MB are spread over 64 ... 256 workgroups.  (Until round 4 one launch did it all with
+// every workgroup recomputing t_repr from all 5 MB of W1 / W2 through its own 64 B/clk of L2 bandwidth: 77-103 us per forward
+// whatever the batch -- 2.3 % of a single-member pass.)  All weights are stored transposed ([in][out]): a wave reads 256
+// consecutive bytes per k.  Sums are fp32 in (wave slice, then four slices) order: rounding-level differences to a serial sum.
+constexpr int TM_ROWS = 8, TM_KC = 1024, TM_UNROLL = 8;
+enum { TM_EMB_GELU = 0, TM_PLAIN = 1, TM_SILU_LAYERS = 2 };
+template <int MODE>
+__global__ __launch_bounds__(256) void time_dense_kernel(const SdyTimeMlp t, const float* __restrict__ in,
+                                                         float* __restrict__ out, int B, float* __restrict__ dp_out,
+                                                         const float* __restrict__ dp_keep_in, int enable_dropout,
+                                                         uint32_t seed_lo, uint32_t seed_hi, uint32_t call,
+                                                         uint32_t batch_offset, int rows_per_call) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = MODE == TM_EMB_GELU ? t.E : t.T;                       // contraction length
+  const int O = MODE == TM_SILU_LAYERS ? 2 * t.E : t.T;                // outputs per weight matrix
+  const int cbs = (O + 63) / 64;                                       // column blocks per matrix
+  const int layer = MODE == TM_SILU_LAYERS ? (int)blockIdx.x / cbs : 0;
+  const int cb = MODE == TM_SILU_LAYERS ? (int)blockIdx.x - layer * cbs : (int)blockIdx.x;
+  const float* wt = MODE == TM_EMB_GELU ? t.w1t : MODE == TM_PLAIN ? t.w2t : t.wbt + (long)layer * t.T * 2 * t.E;
+  const float* bias = MODE == TM_EMB_GELU ? t.b1 : MODE == TM_PLAIN ? t.b2 : t.bb + (long)layer * 2 * t.E;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = (int)blockIdx.y * TM_ROWS;
+  const int nrows = B - b0 < TM_ROWS ? B - b0 : TM_ROWS;
+  const int o = cb * 64 + lane, oc = o < O ? o : O - 1;
+  const int kc_max = K < TM_KC ? (K + 3) & ~3 : TM_KC;
+  float* in_s = sm;                        // [TM_ROWS][kc_max]
+  float* red = sm + TM_ROWS * kc_max;      // [4 waves][TM_ROWS][64]
+  float acc[TM_ROWS];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        a0 += wt[(long)(i + u) * ld + o] * v[i + u];
-        a1 += wt[(long)(i + 16 + u) * ld + o] * v[i + 16 + u];
-        a2 += wt[(long)(i + 32 + u) * ld + o] * v[i + 32 + u];
-        a3 += wt[(long)(i + 48 + u) * ld + o] * v[i + 48 + u];
+  for (int r = 0; r < TM_ROWS; ++r) acc[r] = 0.0f;
+
+  for (int k0 = 0; k0 < K; k0 += TM_KC) {
+    const int kc = K - k0 < TM_KC ? K - k0 : TM_KC, kc4 = (kc + 3) & ~3;
+    // stage the rows' inputs of this k range (zeros past K and past the last row)
+    for (int i = tid; i < TM_ROWS * kc4; i += 256) {
+      const int r = i / kc4, k = i - r * kc4;
+      float v = 0.0f;
+      if (r < nrows && k < kc) {
+        if (MODE == TM_EMB_GELU) {
+          const int half = t.E / 2, e = k0 + k;
+          const float arg = in[b0 + r] * t.freq[e < half ? e : e - half];   // in = time[B]
+          v = e < half ? sinf(arg) : cosf(arg);
+        } else {
+          v = in[(long)(b0 + r) * K + k0 + k];
+          if (MODE == TM_SILU_LAYERS) v = silu(v);
+        }
+      }
+      in_s[r * kc_max + k] = v;
+    }
+    __syncthreads();
+    // wave w takes the k quads g = w, w + 4, ...: four weight rows (256 bytes each per wave) against eight broadcast quads
+    const int ngroups = kc4 >> 2;
+    // (eight quads per trip: 32 weight loads in flight per thread -- the layer's weights come from HBM on every forward, and a
+    // workgroup's 256 KB at 4 loads per thread were 64 dependent round trips)
+    for (int g0 = wave; g0 < ngroups; g0 += 4 * TM_UNROLL) {
+      float w4[TM_UNROLL][4];
+#pragma unroll
+      for (int u = 0; u < TM_UNROLL; ++u) {
+        const int k = 4 * (g0 + 4 * u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = k0 + k + e < K ? k0 + k + e : K - 1;   // (past K: the staged inputs are zero, or the quad is skipped)
+          w4[u][e] = wt[(long)kk * O + oc];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TM_UNROLL; ++u) {
+        const int g = g0 + 4 * u;
+        if (g < ngroups) {
+#pragma unroll
+          for (int r = 0; r < TM_ROWS; ++r) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(in_s + r * kc_max + 4 * g);
+            acc[r] += (w4[u][0] * v.x + w4[u][1] * v.y) + (w4[u][2] * v.z + w4[u][3] * v.w);
+          }
+        }
       }
     }
-    for (int i = n4; i < n; ++i) a0 += wt[(long)i * ld + o] * v[i];
-    return (a0 + a1) + (a2 + a3);
-  };
-  for (int o = threadIdx.x; o < T; o += 256) h1[o] = gelu_erf_exact(dot4(t.w1t, T, emb, E, o, t.b1[o]));
-  __syncthreads();
-  for (int o = threadIdx.x; o < T; o += 256) tr[o] = dot4(t.w2t, T, h1, T, o, t.b2[o]);
-  __syncthreads();
-  if (layer == L) {
-    if (trep_out)
-      for (int o = threadIdx.x; o < T; o += 256) trep_out[(long)b * T + o] = tr[o];
-    return;
+    __syncthreads();
   }
-  for (int i = threadIdx.x; i < T; i += 256) h1[i] = silu(tr[i]);
+#pragma unroll
+  for (int r = 0; r < TM_ROWS; ++r) red[(wave * TM_ROWS + r) * 64 + lane] = acc[r];
   __syncthreads();
-  const float* wb = t.wbt + (long)layer * T * 2 * E;
-  const float* bb = t.bb + (long)layer * 2 * E;
-  for (int o = threadIdx.x; o < 2 * E; o += 256) ss_out[((long)b * L + layer) * 2 * E + o] = dot4(wb, 2 * E, h1, T, o, bb[o]);
-  if (threadIdx.x == 0 && dp_out) {
-    float scale = 1.0f;
-    const float p = t.dp_rate[layer];
-    if (enable_dropout && p > 0.0f) {
-      bool keep;
-      if (dp_keep_in) {
-        keep = dp_keep_in[layer * gridDim.y + b] != 0.0f;
-      } else {
-        const int bq = b / rows_per_call;   // stacked calls: trajectory b % rows_per_call of call + b / rows_per_call
-        const philox4 w = philox4x32_10((uint32_t)((b - bq * rows_per_call) + batch_offset), 0xFFFFFFFFu,
-                                        0x1000u + (uint32_t)layer, call + (uint32_t)bq, seed_lo, seed_hi);
-        keep = w.x >= t.dp_thr[layer];
-      }
-      scale = keep ? 1.0f / (1.0f - p) : 0.0f;
+  for (int r = wave; r < nrows; r += 4) {
+    if (o < O) {
+      float v = bias[o] + ((red[(0 * TM_ROWS + r) * 64 + lane] + red[(1 * TM_ROWS + r) * 64 + lane]) +
+                           (red[(2 * TM_ROWS + r) * 64 + lane] + red[(3 * TM_ROWS + r) * 64 + lane]));
+      if (MODE == TM_EMB_GELU) v = gelu_erf_exact(v);
+      if (MODE == TM_SILU_LAYERS) out[((long)(b0 + r) * t.num_layers + layer) * O + o] = v;
+      else out[(long)(b0 + r) * O + o] = v;
     }
-    dp_out[layer * gridDim.y + b] = scale;  // [layer][b]
+  }
+  if (MODE == TM_SILU_LAYERS && dp_out && blockIdx.x == 0) {   // drop-path scales of this block's rows, [layer][b]
+    for (int i = tid; i < t.num_layers * nrows; i += 256) {
+      const int ly = i / nrows, b = b0 + (i - ly * nrows);
+      float scale = 1.0f;
+      const float p = t.dp_rate[ly];
+      if (enable_dropout && p > 0.0f) {
+        bool keep;
+        if (dp_keep_in) {
+          keep = dp_keep_in[ly * B + b] != 0.0f;
+        } else {
+          const int bq = b / rows_per_call;   // stacked calls: trajectory b % rows_per_call of call + b / rows_per_call
+          const philox4 w = philox4x32_10((uint32_t)((b - bq * rows_per_call) + batch_offset), 0xFFFFFFFFu,
+                                          0x1000u + (uint32_t)ly, call + (uint32_t)bq, seed_lo, seed_hi);
+          keep = w.x >= t.dp_thr[ly];
+        }
+        scale = keep ? 1.0f / (1.0f - p) : 0.0f;
+      }
+      dp_out[ly * B + b] = scale;
+    }
   }
 }
 
@@ -725,14 +768,22 @@ int sdy_cold_update_launch(const float* xs, const float* xn, const float* xi, fl
 
 int sdy_time_mlp_launch(const SdyTimeMlp& t, const float* time, int B, float* trep, float* ss, float* dp,
                         const float* dp_keep_in, int enable_dropout, uint64_t seed, uint32_t call,
-                        uint32_t batch_offset, int rows_per_call, hipStream_t stream) {
+                        uint32_t batch_offset, int rows_per_call, hipStream_t stream, float* scratch) {
   if (rows_per_call < 1) rows_per_call = B > 0 ? B : 1;
   const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
   if (t.E > 0) {
-    if (!time) return SDY_ERR_ARG;
-    const size_t smem = (size_t)(t.E + 2 * t.T) * sizeof(float);
-    hipLaunchKernelGGL(time_mlp_kernel, dim3(t.num_layers + 1, B), dim3(256), smem, stream, t, time, trep, ss, dp,
-                       dp_keep_in, enable_dropout, slo, shi, call, batch_offset, rows_per_call);
+    // scratch: B * T floats for the hidden layer, B * T more when the caller does not want t_repr
+    if (!time || !scratch || !ss) return SDY_ERR_ARG;
+    float* h1 = scratch;
+    float* tr = trep ? trep : scratch + (size_t)B * t.T;
+    const int rb = (B + TM_ROWS - 1) / TM_ROWS;
+    auto smem = [&](int K) { return (size_t)(TM_ROWS * (K < TM_KC ? (K + 3) & ~3 : TM_KC) + 4 * TM_ROWS * 64) * sizeof(float); };
+    hipLaunchKernelGGL(time_dense_kernel<TM_EMB_GELU>, dim3((t.T + 63) / 64, rb), dim3(256), smem(t.E), stream, t, time, h1, B,
+                       nullptr, nullptr, 0, 0u, 0u, 0u, 0u, 1);
+    hipLaunchKernelGGL(time_dense_kernel<TM_PLAIN>, dim3((t.T + 63) / 64, rb), dim3(256), smem(t.T), stream, t, h1, tr, B,
+                       nullptr, nullptr, 0, 0u, 0u, 0u, 0u, 1);
+    hipLaunchKernelGGL(time_dense_kernel<TM_SILU_LAYERS>, dim3(t.num_layers * ((2 * t.E + 63) / 64), rb), dim3(256), smem(t.T),
+                       stream, t, tr, ss, B, dp, dp_keep_in, enable_dropout, slo, shi, call, batch_offset, rows_per_call);
   } else if (dp) {
     const int n = B * t.num_layers;
     hipLaunchKernelGGL(droppath_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, t, dp, dp_keep_in, B, enable_dropout,
