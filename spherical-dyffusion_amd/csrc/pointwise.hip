@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256) void time_dense_kernel(const SdyTimeMlp t, con
 #pragma unroll
           for (int r = 0; r < TM_ROWS; ++r) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(in_s + r * kc_max + 4 * g);
-            acc[r] += (w4[u][0] * v.x + w4[u][1] * v.y) + (w4[u][2] * v.z + w4[u][3] * v.w);
+            // explicit FMAs, one chain per row: left to the compiler's contraction the unrolled rows came out with DIFFERENT
+            // roundings (row 7 of a block differed from rows 0 .. 6 in the last bit) -- a batch row must not depend on its place
+            acc[r] = __builtin_fmaf(w4[u][3], v.w, __builtin_fmaf(w4[u][2], v.z, __builtin_fmaf(w4[u][1], v.y, __builtin_fmaf(w4[u][0], v.x, acc[r]))));
           }
         }
       }

@@ -16,7 +16,7 @@ def make_pair(cfg: SFNOConfig, n_in: int, n_cond: int, seed: int = 4321, net_see
         spatial_shape_in=(cfg.nlat, cfg.nlon), embed_dim=cfg.embed_dim, num_layers=cfg.num_layers,
         mlp_ratio=cfg.mlp_ratio, dropout_mlp=cfg.dropout_mlp, drop_path_rate=cfg.drop_path_rate,
         with_time_emb=cfg.with_time_emb, data_grid=cfg.data_grid, big_skip=cfg.big_skip, pos_embed=cfg.pos_embed,
-        seed=net_seed,
+        seed=net_seed, time_dim_mult=cfg.time_dim_mult,
     )
     net.load_state_dict(sd, strict=True)
     if cfg.with_time_emb:

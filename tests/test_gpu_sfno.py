@@ -54,6 +54,36 @@ def test_tiny_sfno_with_condition_and_time(data_grid):
     assert rel_l2(trep, ora.time_repr(t)) < 2e-6
 
 
+def test_time_embedding_ragged_sizes():
+    """The time MLP's dense-layer kernel away from its comfortable sizes: a contraction longer than one 1024-term LDS chunk and
+    not a multiple of 64 (time_dim = 12 * 88 = 1056), fewer than 64 outputs per layer matrix (2 E = 24), 11 rows (two row
+    blocks, the second with three rows) -- t_repr and the blocks' (scale | shift) against the oracle, then a whole forward."""
+    cfg = SFNOConfig(in_chans=5, out_chans=3, nlat=32, nlon=64, embed_dim=12, num_layers=2, with_time_emb=True,
+                     time_dim_mult=88, min_time=0.0, max_time=9.0)
+    net, ora, _ = make_pair(cfg, 5, 0)
+    t = torch.linspace(0.0, 9.0, 11)
+    trep, ss = net.time_embedding(t.cuda())
+    assert trep.shape == (11, 1056) and rel_l2(trep, ora.time_repr(t)) < 2e-6
+    x, _ = _inputs(cfg, 5, 0, 11)
+    err = rel_l2(net(x.cuda(), time=t.cuda()), ora(x, time=t))
+    assert err < TOL_TIGHT, f"rel L2 {err:.3e}"
+
+
+def test_time_embedding_of_a_row_does_not_depend_on_the_batch():
+    """Member sharding relies on it: a trajectory's (t_repr, scale | shift) are BITWISE the same whatever batch it sits in and
+    wherever in it (the dense-layer kernel keeps one explicit FMA chain per row: with the sums left to the compiler's
+    contraction, row 7 of every 8-row block came out one ulp away from rows 0 .. 6)."""
+    cfg = SFNOConfig(in_chans=10, out_chans=6, nlat=32, nlon=64, embed_dim=256, num_layers=8, with_time_emb=True,
+                     min_time=0.0, max_time=5.0)
+    net, _, _ = make_pair(cfg, 10, 0)
+    a, sa = net.time_embedding(torch.full((25,), 3.0).cuda())
+    b, sb = net.time_embedding(torch.tensor([4.0, 3.0]).cuda())
+    c, sc = net.time_embedding(torch.tensor([3.0]).cuda())
+    for i in range(1, 25):
+        assert torch.equal(a[i], a[0]) and torch.equal(sa[i], sa[0]), f"row {i} of 25 equal times differs from row 0"
+    assert torch.equal(b[1], a[0]) and torch.equal(c[0], a[0]) and torch.equal(sb[1], sa[0]) and torch.equal(sc[0], sa[0])
+
+
 def test_tiny_sfno_no_time_no_skip():
     cfg = SFNOConfig(in_chans=4, out_chans=4, nlat=32, nlon=64, embed_dim=8, num_layers=2, with_time_emb=False,
                      big_skip=False, pos_embed=False)
