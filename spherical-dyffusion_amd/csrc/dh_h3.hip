@@ -19,6 +19,7 @@
 // Work distribution: each degree l belongs to ONE XCD (boustrophedon over l, so the (l+1)-proportional work balances), and
 // the 32 workgroups of an XCD walk its tile list interleaved -- at any time they sit on the same one or two degrees, whose
 // 1 MB weight streams stay in that XCD's 4 MB L2 and are fetched from HBM once.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -53,14 +54,20 @@ struct DhParams {
   float out_scale;
   unsigned* flags;                 // sticky status word (sdy_status_flags)
   unsigned long long* stamps;      // timing experiments only (SDY_DH_STAMPS)
+  int use_table;                   // degree -> XCD from xcd_of (L <= 256), else the boustrophedon formula
+  unsigned char xcd_of[256];       // balanced by the host for this (L, mtr, B): longest-processing-time over the degrees' tiles
 };
 
 __device__ __forceinline__ int dh_swz(int r) { return (r & 15) ^ (((r >> 4) & 1) * 3); }
 // half offset of 16-byte chunk c (0..63) of row r
 __device__ __forceinline__ int dh_off(int r, int c) { return r * DK + (((c & ~15) | ((c ^ dh_swz(r)) & 15)) << 3); }
 
-// degree -> XCD (boustrophedon), rows and tiles of a degree
-__device__ __forceinline__ int dh_xcd(int l) { return (l & 8) ? 7 - (l & 7) : (l & 7); }
+// degree -> XCD, rows and tiles of a degree.  The boustrophedon rule balances (l + 1) over groups of 16 degrees, but L = 180 / 181
+// leaves 4 / 5 of the heaviest degrees over (71 tiles each at B = 25): XCDs 0 .. 4 got 840 tiles, 5 .. 7 got 770, and the launch
+// took 27 rounds of 32 workgroups for 25.5.  The host's table (largest degree first to the least loaded XCD) is within one
+// tile of even: 26 rounds.
+__host__ __device__ __forceinline__ int dh_xcd_formula(int l) { return (l & 8) ? 7 - (l & 7) : (l & 7); }
+__device__ __forceinline__ int dh_xcd(const DhParams& p, int l) { return p.use_table ? (int)p.xcd_of[l] : dh_xcd_formula(l); }
 __device__ __forceinline__ int dh_rows(const DhParams& p, int l) { return (l + 1 < p.mtr ? l + 1 : p.mtr) * p.B; }
 
 struct TileIt {
@@ -69,7 +76,7 @@ struct TileIt {
 __device__ __forceinline__ void dh_advance(const DhParams& p, TileIt& it, int xcd, int step) {
   it.t += step;
   while (it.l >= 0) {
-    const int nt = (dh_xcd(it.l) == xcd) ? (dh_rows(p, it.l) + DTN - 1) / DTN : 0;
+    const int nt = (dh_xcd(p, it.l) == xcd) ? (dh_rows(p, it.l) + DTN - 1) / DTN : 0;
     if (it.t < nt) return;
     it.t -= nt;
     --it.l;
@@ -346,6 +353,27 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
   p.out_scale = 1.0f / (scale * DSX);
   SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;
+  {   // degree -> XCD: degrees by falling tile count (ties: higher degree first), each to the XCD with the fewest tiles so far
+    static const bool no_table = std::getenv("SDY_DH_NO_BALANCE") != nullptr;
+    p.use_table = (L <= 256 && !no_table) ? 1 : 0;
+    if (p.use_table) {
+      int order[256];
+      long tiles[256], load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int l = 0; l < L; ++l) {
+        order[l] = L - 1 - l;
+        tiles[l] = ((long)(l + 1 < mtr ? l + 1 : mtr) * B + DTN - 1) / DTN;
+      }
+      std::stable_sort(order, order + L, [&](int a, int b) { return tiles[a] > tiles[b]; });
+      for (int i = 0; i < L; ++i) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x)
+          if (load[x] < load[best]) best = x;
+        p.xcd_of[order[i]] = (unsigned char)best;
+        load[best] += tiles[order[i]];
+      }
+      for (int l = L; l < 256; ++l) p.xcd_of[l] = 0;
+    }
+  }
 #if SDY_STAMPS_ON
   if (std::getenv("SDY_DH_STAMPS")) {
     if (!g_dstamps) SDY_HIP_TRY(hipMalloc(&g_dstamps, 256 * sizeof(unsigned long long)));

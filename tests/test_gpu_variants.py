@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = ["SDY_NO_SPEC_ILV", "SDY_NO_DH_FRAG", "SDY_NO_FFT360", "SDY_NO_FUSED_MLP", "SDY_NO_CONV_FRAG",
             "SDY_NO_LEG_FRAG", "SDY_NO_LEG_PAR", "SDY_NO_FUSED_STATS", "SDY_NO_POLAR_SKIP", "SDY_NO_XF_TILED",
-            "SDY_NO_Z_TILED", "SDY_NO_CS_TILED", "SDY_NO_PAIR"]
+            "SDY_NO_Z_TILED", "SDY_NO_CS_TILED", "SDY_NO_PAIR", "SDY_DH_NO_BALANCE"]
 TOL = 2e-5
 
 
