@@ -41,6 +41,10 @@ constexpr int DGPW = 2 * DCB;      // groups per wave and degree (32)
 constexpr int DGROUP = 2 * 64;     // f16x8 elements per group (hi | lo)
 constexpr long DLSTRIDE = (long)DWAVES * DGPW * DGROUP;   // f16x8 elements per degree (512 KB)
 constexpr float DSX = SDY_ACT_SX;
+#ifndef DH_FRAG_AHEAD
+#define DH_FRAG_AHEAD 1   // LDS fragments of the next half step requested before the MFMAs of this one (second register set:
+                          // 221 -> 255 registers, no scratch; 0.621 -> 0.606 ms per launch, profiles/r4c/e2e_ab_dh_frag_ahead.txt)
+#endif
 
 struct DhParams {
   const float* X; long sX;         // Cs_in,  per-degree stride (floats)
@@ -143,6 +147,11 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
         p.stamps[((tile_it - 2) * 8 + wave) * 8 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    if (SDY_STAMPS_ON && p.stamps && blockIdx.x == 11 && tile_it < 64) {   // every tile of the sampled workgroup
+      const unsigned long long tm = __builtin_amdgcn_s_memtime();
+      const unsigned long long id = (unsigned long long)(cur.l * 1000 + cur.t);
+      if (lane == 0 && wave == 0) { p.stamps[256 + tile_it] = tm; p.stamps[320 + tile_it] = id; }
+    }
     const int row0 = cur.t * DTN;
     TileIt nxt = cur;
     dh_advance(p, nxt, xcd, nslots);
@@ -187,6 +196,63 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
       SDY_CROSS_TERM(c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo, c, 0, 0, 0));
       c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi, c, 0, 0, 0);
     };
+#if DH_FRAG_AHEAD
+    // Two register sets for the LDS fragments: x_im's of a channel block are requested before the MFMAs on x_re run, the next
+    // block's x_re before those on x_im -- a wave that has the SIMD to itself (the younger four at the end of the phase, all of
+    // them whenever their partner waits) no longer sits out an LDS round trip per half block.
+    f16x8 fa_h[2], fa_l[2], fb_h[2], fb_l[2];
+    auto ld_frags = [&](f16x8* fh, f16x8* fl, int kstep) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = dh_off(32 * j + l31, 2 * kstep + h);
+        fh[j] = *reinterpret_cast<const f16x8*>(Xs_hi + off);
+        fl[j] = *reinterpret_cast<const f16x8*>(Xs_lo + off);
+      }
+    };
+    ld_frags(fa_h, fa_l, p.ilv ? 0 : 0);
+#pragma unroll
+    for (int kb = 0; kb < DCB / 4; ++kb) {
+      if (kb == DCB / 4 - 1) {   // the refills of the last block fetch block 0 of the next tile's stream
+        wbase = wnext;
+        woff -= DGPW * DGROUP_BYTES;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cb = 4 * kb + i, s0 = 2 * i, s1 = 2 * i + 1;   // ring slots of (wr, wi)
+        const int kim = p.ilv ? 2 * cb + 1 : DCB + cb;            // k-step of x_im (x_re's: 2 cb / cb, requested a half block ago)
+        ld_frags(fb_h, fb_l, kim);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma3(acc[0][j], fa_h[j], fa_l[j], r_hi[s0], r_lo[s0]);   // re += x_re . wr
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma3(acc[1][j], fa_h[j], fa_l[j], r_hi[s1], r_lo[s1]);   // im += x_re . wi
+        __builtin_amdgcn_sched_barrier(0);
+        if (cb + 1 < DCB) ld_frags(fa_h, fa_l, p.ilv ? 2 * (cb + 1) : cb + 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma3(acc[1][j], fb_h[j], fb_l[j], r_hi[s0], r_lo[s0]);   // im += x_im . wr
+        r_hi[s0] = sdy_ring_ld(wbase, woff, 0);
+        r_lo[s0] = sdy_ring_ld(wbase, woff, DGROUP_BYTES / 2);
+        woff += DGROUP_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // -x_im
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 uh = __builtin_bit_cast(u32x4, fb_h[j]) ^ 0x80008000u, ul = __builtin_bit_cast(u32x4, fb_l[j]) ^ 0x80008000u;
+          fb_h[j] = __builtin_bit_cast(f16x8, uh);
+          fb_l[j] = __builtin_bit_cast(f16x8, ul);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma3(acc[0][j], fb_h[j], fb_l[j], r_hi[s1], r_lo[s1]);   // re -= x_im . wi
+        r_hi[s1] = sdy_ring_ld(wbase, woff, 0);
+        r_lo[s1] = sdy_ring_ld(wbase, woff, DGROUP_BYTES / 2);
+        woff += DGROUP_BYTES;
+#ifndef DH_NOPREFETCH
+        {   // one 16-byte piece of the next tile per channel block, never a burst
+          xr[cb >> 1][cb & 1] = *reinterpret_cast<const f32x4*>(x_ptr(pre, cb >> 1) + 4 * (cb & 1));
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads here (the scheduler otherwise sinks them next to their use)
+      }
+    }
+#else
 #pragma unroll
     for (int kb = 0; kb < DCB / 4; ++kb) {
       if (kb == DCB / 4 - 1) {   // the refills of the last block fetch block 0 of the next tile's stream
@@ -241,6 +307,8 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
       }
     }
 
+#endif
+
     stamp(3);
     // ---- epilogue: the accumulators hold channel = lane, i.e. a direct store is 4 bytes per lane (measured: the 64 dword
     // stores per lane took 40 % of the tile).  Each wave transposes 8-row chunks of its 64 x 64 block through a private
@@ -279,6 +347,10 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
         }
     }
     stamp(4);
+    if (SDY_STAMPS_ON && p.stamps && blockIdx.x == 11 && tile_it < 63 && !more) {
+      const unsigned long long tm = __builtin_amdgcn_s_memtime();
+      if (lane == 0 && wave == 0) p.stamps[256 + tile_it + 1] = tm;
+    }
     if (!more) break;
     cur = nxt;
     __syncthreads();   // every wave is done reading the LDS tile
@@ -290,11 +362,11 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
 
 #if SDY_STAMPS_ON
 static unsigned long long* g_dstamps = nullptr;
-SDY_DEBUG_EXPORT int sdy_dhconv_frag_debug_stamps(unsigned long long* host256) {
-  unsigned long long* host64 = host256;
+SDY_DEBUG_EXPORT int sdy_dhconv_frag_debug_stamps(unsigned long long* host384) {   // 256 phase stamps + 64 tile starts + 64 (l, t)
+  unsigned long long* host64 = host384;
   if (!g_dstamps || !host64) return SDY_ERR_STATE;
   SDY_HIP_TRY(hipDeviceSynchronize());
-  SDY_HIP_TRY(hipMemcpy(host64, g_dstamps, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  SDY_HIP_TRY(hipMemcpy(host64, g_dstamps, 384 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SDY_OK;
 }
 #endif
@@ -376,7 +448,10 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
   }
 #if SDY_STAMPS_ON
   if (std::getenv("SDY_DH_STAMPS")) {
-    if (!g_dstamps) SDY_HIP_TRY(hipMalloc(&g_dstamps, 256 * sizeof(unsigned long long)));
+    if (!g_dstamps) {
+      SDY_HIP_TRY(hipMalloc(&g_dstamps, 384 * sizeof(unsigned long long)));
+      SDY_HIP_TRY(hipMemset(g_dstamps, 0, 384 * sizeof(unsigned long long)));
+    }
     p.stamps = g_dstamps;
   }
 #endif

@@ -20,7 +20,7 @@ for _ in range(5):
     check(lib.sdy_dhconv_frag(ptr(Cs), ptr(wf), sc.value, ptr(Cs2), L, mtr, B, current_stream()))
 e1.record(); torch.cuda.synchronize()
 print("ms", e0.elapsed_time(e1) / 5)
-buf = (C.c_uint64 * 256)()
+buf = (C.c_uint64 * 384)()
 lib.sdy_dhconv_frag_debug_stamps.argtypes = [C.c_void_p]; lib.sdy_dhconv_frag_debug_stamps.restype = C.c_int
 assert lib.sdy_dhconv_frag_debug_stamps(buf) == 0
 v = list(buf)
@@ -30,3 +30,9 @@ print("tile 0 of the window: stamp times relative to the earliest wave (ticks); 
 for i in range(6):
     print("  stamp %d %-18s" % (i, "(before " + names[i] + ")"), " ".join("%7d" % (v[w * 8 + i] - t0) for w in range(8)))
 print("  next tile start          ", " ".join("%7d" % (v[(8 + w) * 8] - t0) for w in range(8)))
+
+ts, lt = v[256:320], v[320:384]
+n = max(i for i in range(64) if ts[i]) if any(ts) else 0
+print("every tile of the sampled workgroup: (degree l, tile t) and its duration in ticks")
+print("  " + "  ".join("(%d,%d) %d" % (lt[i] // 1000, lt[i] % 1000, ts[i + 1] - ts[i]) for i in range(n) if ts[i + 1]))
+print("  total ticks first -> last stamp", ts[n] - ts[0], "over", n, "tiles")
