@@ -188,6 +188,13 @@ constexpr int TAIL = Q4 - 64;   // 26
 // XCDs, each with its own L2.  The 16 channel blocks of one (ring group, image) write / read the two 64-byte halves of the
 // same 128-byte lines on the m-major side, so they are mapped to consecutive slots of ONE XCD: its L2 merges the halves
 // instead of every half-line going to HBM on its own.
+// Order of the workgroups an XCD runs at one time (160 of them): SDY_FFT_GROUP channel blocks fastest, then the ring, then the
+// remaining channel blocks, then the image.  Measured on one device (profiles/r4c/e2e_ab_fft_*.txt, inverse / forward ms per
+// launch): all 16 blocks of a ring first (10 rings in flight, rounds 1-3) 0.613 / 0.567; 8: the same; 4 (40 rings of two
+// tiles): 0.605 / 0.564; 2 (80 rings of one tile): 0.641 / 0.589; the images of one ring first: 0.72 / 0.63.
+#ifndef SDY_FFT_GROUP
+#define SDY_FFT_GROUP 4
+#endif
 struct WgId {
   int x, y, z;
 };
@@ -196,6 +203,15 @@ __device__ __forceinline__ WgId wg_id(int nx, int ny) {
   const unsigned xcd = L % 8u, slot = L / 8u;
   const unsigned id = xcd * (total / 8u) + min(xcd, total % 8u) + slot;
   WgId w;
+#if SDY_FFT_GROUP > 0
+  if (nx % SDY_FFT_GROUP == 0) {   // SDY_FFT_GROUP channel blocks fastest, then the ring, then the rest of the channel blocks
+    const unsigned G = SDY_FFT_GROUP;
+    w.x = (int)(G * ((id / (G * ny)) % ((unsigned)nx / G)) + id % G);
+    w.y = (int)((id / G) % (unsigned)ny);
+    w.z = (int)(id / ((unsigned)nx * ny));
+    return w;
+  }
+#endif
   w.x = id % nx;
   w.y = (id / nx) % ny;
   w.z = id / (nx * ny);
