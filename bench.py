@@ -53,7 +53,7 @@ PEAK_HBM_GBS = 8000.0          # same guide: HBM3E peak (6.3 TB/s measured with 
 # HBM bytes per launch of the dominant kernel at B = 25 from separate rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
 # the guide's gfx950 correction); source file under profiles/
 MLP_TRAFFIC_B25 = 5.265e9      # mlp_h3_kernel<true> inside the interpolator forward: fetch 3.604 GB + write 1.661 GB
-MLP_TRAFFIC_SRC = "profiles/r4e/pmc_summary.txt"   # (r4f, the last commit of the round: 5.266e9)
+MLP_TRAFFIC_SRC = "profiles/r4e/pmc_summary.txt"   # (r4f, another box at the last commit of the round: 5.283e9)
 POLAR_LIVE = 0.77              # share of (order, latitude) pairs the polar cut-off keeps
 NZ_PAIRS, ALL_PAIRS = 16290, 32580   # (l, m) pairs with m <= l / dense
 
