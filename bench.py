@@ -185,7 +185,11 @@ def profile_pass(exp, x, forc, B):
     for name, (cnt, ms) in sorted(t.stages.items(), key=lambda kv: -kv[1][1]):
         avg = ms / cnt
         fl, by, bound = work.get(name, (0.0, 0.0, "hbm"))
-        rows.append({"name": name, "launches_per_step": cnt, "ms": round(avg, 4), "share": round(ms / total, 4),
+        # drop-path skip: a block's kernels run on the trajectories its DropPath draw keeps, so a stage's average launch covers
+        # fewer than B rows; its algorithmic work is scaled to the rows it actually processed (weights are a rounding error)
+        avg_rows = t.rows.get(name, cnt * B) / cnt
+        fl, by = fl * avg_rows / B, by * avg_rows / B
+        rows.append({"name": name, "launches_per_step": cnt, "avg_rows": round(avg_rows, 2), "ms": round(avg, 4), "share": round(ms / total, 4),
                      "gflop": round(fl / 1e9, 2), "gbytes": round(by / 1e9, 3), "bound": bound,
                      "frac_mfma": round(fl / (avg * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4) if fl else None,
                      "frac_hbm": round(by / (avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if by else None})

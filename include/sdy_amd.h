@@ -176,6 +176,10 @@ typedef struct sdy_conv_args {
                                         tile padded to 64; out_bstride >= ceil(HW / 64) * Cout * 64), the layout sdy_mlp_args.x_tiled
                                         reads: a tile of the intermediate tensor between the two persistent kernels is then one
                                         contiguous 64 KB block for its producer and its consumer.  `out` must not alias `add`. */
+  const unsigned char* x_rows;       /* host [B] or NULL, w_frag path only, B <= 64: image z of this launch reads batch row x_rows[z] of
+                                        x / pa / pd (add, out and stats stay indexed by z).  sdy_sfno_forward runs a block whose
+                                        DropPath draw (src/models/modules/drop_path.py:15-22) zeroes some trajectories' branch on
+                                        the active trajectories only: its per-block tensors are compact, the block input is not. */
 } sdy_conv_args;
 int sdy_conv1x1(const sdy_conv_args* args, void* stream);
 
@@ -218,6 +222,9 @@ typedef struct sdy_mlp_args {
   const float* keep_hidden;            /* tests only, dev (B, hidden, HW) and (B, E, HW) 0/1 masks or NULL: with drop_p > 0 the */
   const float* keep_out;               /* keep decisions come from these (e.g. masks the reference's nn.Dropout drew) instead of
                                           the Philox stream -- same kernel code, a separate (untimed) instantiation */
+  const unsigned char* out_rows;       /* host [B] or NULL, B <= 64: image z of this launch (x, pa, pd indexed by z) IS batch row
+                                          out_rows[z] -- add, add_a, add_d, out, stats, batch_scale, keep_* and the dropout stream
+                                          (call, trajectory) are taken at that row (see sdy_conv_args.x_rows) */
 } sdy_mlp_args;
 /* (sum, sumsq) statistics -> the same per-(b,c) affine coefficients as sdy_instnorm_coeffs; clears `stats` for reuse. */
 int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, const float* gamma, const float* beta,
@@ -433,6 +440,9 @@ int sdy_profile_enable(int on);
 int sdy_profile_stage_count(void);
 const char* sdy_profile_stage_name(int stage);
 int sdy_profile_read(double* total_ms, long* launches, int n);   /* arrays of n >= sdy_profile_stage_count() */
+/* The same, plus per stage the summed batch rows its launches worked on (rows / launches = average batch of a launch: with
+ * the drop-path skip a block's kernels run on the trajectories its DropPath draw keeps). */
+int sdy_profile_read_rows(double* total_ms, long* launches, long* rows, int n);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

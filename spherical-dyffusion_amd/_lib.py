@@ -43,6 +43,7 @@ class SdyConvArgs(C.Structure):
         ("w_frag_scale", C.c_float),
         ("stats", C.c_void_p),
         ("out_tiled", C.c_int),
+        ("x_rows", C.c_void_p),
     ]
 
 
@@ -64,6 +65,7 @@ class SdyMlpArgs(C.Structure):
         ("stats", C.c_void_p),
         ("x_tiled", C.c_int),
         ("keep_hidden", C.c_void_p), ("keep_out", C.c_void_p),
+        ("out_rows", C.c_void_p),
     ]
 
 
@@ -211,6 +213,7 @@ SIGNATURES = {
     "sdy_profile_stage_count": (C.c_int, []),
     "sdy_profile_stage_name": (C.c_char_p, [C.c_int]),
     "sdy_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
+    "sdy_profile_read_rows": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
 }
 
 

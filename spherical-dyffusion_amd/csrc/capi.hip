@@ -308,10 +308,9 @@ static bool plan_polar_ok(const sdy_sht_plan* p, int C) {
 }
 // Tile-major grid-frequency tensor (fft.h, ilv == 2): like the polar cut-off a contract between fft360 and leg_par only --
 // the plane of one order is stored as whole 64-column tiles, so a Legendre workgroup's activation tile is one contiguous
-// block.  SDY_NO_XF_TILED=1 keeps the row-major planes (A/B measurements).
+// block.
 static bool plan_tiled_ok(const sdy_sht_plan* p, int C, int ilv) {
-  static const bool off = std::getenv("SDY_NO_XF_TILED") || std::getenv("SDY_NO_FFT360") || std::getenv("SDY_NO_LEG_PAR") ||
-                          std::getenv("SDY_NO_LEG_FRAG");
+  static const bool off = std::getenv("SDY_NO_FFT360") || std::getenv("SDY_NO_LEG_PAR") || std::getenv("SDY_NO_LEG_FRAG");
   return !off && ilv == 1 && p->d_wq_par && p->d_pct_par && p->fft.n == 180 && C % 32 == 0;
 }
 static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream,
@@ -508,7 +507,8 @@ extern "C" int sdy_conv1x1(const sdy_conv_args* a, void* stream) {
   if (a->drop_p < 0.0f || a->drop_p >= 1.0f) return SDY_ERR_ARG;
   if (a->w_frag && sdy_conv256_h3_supported(a->Cin, a->Cout) && a->drop_p == 0.0f && !a->keep_mask && !a->batch_scale)
     return sdy_conv256_h3_launch(a, (hipStream_t)stream);
-  if (a->stats) return SDY_ERR_UNSUPPORTED;   // statistics come from the persistent kernel only
+  // statistics, the tile-major output and the image map exist in the persistent kernel only
+  if (a->stats || a->out_tiled || a->x_rows) return SDY_ERR_UNSUPPORTED;
   GemmParams g{};
   g.A = a->wt; g.lda = a->ldw; g.sA = 0;
   g.B = a->x; g.ldb = a->HW; g.sB = a->x_bstride;
@@ -584,11 +584,8 @@ struct BlockW {
 }  // namespace
 
 // Channel order of the forward's spectral buffers (fft.h): the 128-byte-line order whenever the dhconv weights can be
-// packed for it (split-fp16 GEMM path, E % 16 == 0); SDY_NO_SPEC_ILV=1 keeps the ABI order (A/B measurements).
-static int spec_ilv(const sdy_sfno_config& c) {
-  static const bool off = std::getenv("SDY_NO_SPEC_ILV") != nullptr;
-  return (c.gemm_mode == 1 && c.embed_dim % 16 == 0 && !off) ? 1 : 0;
-}
+// packed for it (split-fp16 GEMM path, E % 16 == 0).
+static int spec_ilv(const sdy_sfno_config& c) { return (c.gemm_mode == 1 && c.embed_dim % 16 == 0) ? 1 : 0; }
 
 struct sdy_sfno {
   sdy_sfno_config cfg;
@@ -646,8 +643,7 @@ static int dev_upload_conv(DevBuf& b, const float* host, int out, int in, int ld
     b.h3 = nullptr;
     SDY_HIP_TRY(hipMalloc(&b.h3, sdy_h3_pack_bytes(out, in)));
     SDY_TRY(sdy_h3_pack_weight(host, out, in, b.h3, &b.h3_scale));
-    static const bool only256 = std::getenv("SDY_CONV_FRAG_256_ONLY") != nullptr;   // A/B: encoders on the tile GEMM
-    if (sdy_conv256_h3_supported(in, out) && !(only256 && in != 256)) {
+    if (sdy_conv256_h3_supported(in, out)) {
       if (b.frag) (void)hipFree(b.frag);
       b.frag = nullptr;
       SDY_HIP_TRY(hipMalloc(&b.frag, sdy_conv256_h3_pack_bytes_cin(in)));
@@ -732,6 +728,7 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
   const int E = c.embed_dim, T = c.time_dim, L = c.num_layers, H = c.mlp_hidden, Cin = c.in_chans;
   const std::string name(name_c);
   const bool h3 = c.gemm_mode == 1;
+  n->enc_ws = nullptr;   // new weights: a stored encoder output (sdy_sfno_fwd_args.reuse_encoder) is no longer this network's
   // non-persistent SHT buffers of older torch-harmonics releases: accepted, ignored
   if (name.find("trans") != std::string::npos && (name.find(".weights") != std::string::npos ||
                                                    name.find(".pct") != std::string::npos))
@@ -966,17 +963,18 @@ extern "C" int sdy_sfno_time_embed(sdy_sfno* n, const float* time, int B, float*
 namespace {
 enum SdyStage {
   ST_CONCAT, ST_TIME_MLP, ST_ENC0, ST_ENC2, ST_NORM_COEFFS, ST_FFT_FWD, ST_LEG_FWD, ST_LEG_INV, ST_FFT_INV, ST_DHCONV,
-  ST_SKIP_CONV, ST_MLP_FUSED, ST_MLP_FUSED_DROP, ST_FC1, ST_FC2, ST_DEC0, ST_DEC2, ST_ENC_PAIR, ST_DEC_PAIR, ST_COUNT
+  ST_SKIP_CONV, ST_MLP_FUSED, ST_MLP_FUSED_DROP, ST_FC1, ST_FC2, ST_DEC0, ST_DEC2, ST_ENC_PAIR, ST_DEC_PAIR, ST_DROP_COPY,
+  ST_COUNT
 };
 const char* const kStageNames[ST_COUNT] = {
   "concat", "time_mlp", "encoder.0 conv", "encoder.2 conv", "instnorm coefficients", "rfft (lon)", "legendre analysis",
   "legendre synthesis", "irfft (lon)", "dhconv", "inner-skip conv", "mlp fused", "mlp fused (dropout)", "mlp fc1", "mlp fc2",
-  "decoder.0 conv", "decoder.2 conv", "encoder (fused pair)", "decoder (fused pair)"};
+  "decoder.0 conv", "decoder.2 conv", "encoder (fused pair)", "decoder (fused pair)", "drop-path copy"};
 // Single-threaded by contract (one host thread issues forwards while the switch is on); the mutex only keeps the record list
 // consistent against a concurrent sdy_profile_read.  Events come from a pool and are reused across reads.
 struct SdyProfiler {
   bool on = false;
-  struct Rec { int stage; hipEvent_t e0, e1; bool closed; };
+  struct Rec { int stage; int rows; hipEvent_t e0, e1; bool closed; };   // rows: batch rows the launch worked on
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
   std::mutex mu;
@@ -986,9 +984,9 @@ struct SdyProfiler {
     return SDY_OK;
   }
   // returns the record's index (>= 0) in *idx; nothing is leaked when an event cannot be created or recorded
-  int begin(int stage, hipStream_t s, int* idx) {
+  int begin(int stage, int rows, hipStream_t s, int* idx) {
     std::lock_guard<std::mutex> g(mu);
-    Rec r{stage, nullptr, nullptr, false};
+    Rec r{stage, rows, nullptr, nullptr, false};
     SDY_TRY(get_event(&r.e0));
     int rc = get_event(&r.e1);
     if (rc == SDY_OK) {
@@ -1015,13 +1013,14 @@ struct SdyProfiler {
 }  // namespace
 
 // (a launch that fails returns before end(): its record stays open and sdy_profile_read skips it)
-#define SDY_STAGE(stage, call)                                              \
-  do {                                                                      \
-    int prof_idx_ = -1;                                                     \
-    if (g_prof.on) SDY_TRY(g_prof.begin((stage), stream, &prof_idx_));      \
-    SDY_TRY(call);                                                          \
-    if (prof_idx_ >= 0) (void)g_prof.end(prof_idx_, stream);                \
+#define SDY_STAGE_N(stage, rows, call)                                          \
+  do {                                                                          \
+    int prof_idx_ = -1;                                                         \
+    if (g_prof.on) SDY_TRY(g_prof.begin((stage), (rows), stream, &prof_idx_));  \
+    SDY_TRY(call);                                                              \
+    if (prof_idx_ >= 0) (void)g_prof.end(prof_idx_, stream);                    \
   } while (0)
+#define SDY_STAGE(stage, call) SDY_STAGE_N(stage, B, call)
 
 extern "C" int sdy_profile_enable(int on) {
   g_prof.on = on != 0;
@@ -1032,8 +1031,11 @@ extern "C" const char* sdy_profile_stage_name(int stage) {
   return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : "";
 }
 extern "C" int sdy_profile_read(double* total_ms, long* launches, int n) {
+  return sdy_profile_read_rows(total_ms, launches, nullptr, n);
+}
+extern "C" int sdy_profile_read_rows(double* total_ms, long* launches, long* rows, int n) {
   if (!total_ms || !launches || n < ST_COUNT) return SDY_ERR_ARG;
-  for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+  for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; if (rows) rows[i] = 0; }
   std::lock_guard<std::mutex> g(g_prof.mu);
   int rc = SDY_OK;
   for (auto& r : g_prof.recs) {
@@ -1042,7 +1044,7 @@ extern "C" int sdy_profile_read(double* total_ms, long* launches, int n) {
       hipError_t e = hipEventSynchronize(r.e1);
       if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.e0, r.e1);
       if (e != hipSuccess) rc = (int)e;
-      else { total_ms[r.stage] += ms; launches[r.stage] += 1; }
+      else { total_ms[r.stage] += ms; launches[r.stage] += 1; if (rows) rows[r.stage] += r.rows; }
     }
     g_prof.pool.push_back(r.e0);
     g_prof.pool.push_back(r.e1);
@@ -1074,6 +1076,9 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   double* ste = reinterpret_cast<double*>(ws + w.ste);
   const bool reuse = a->reuse_encoder != 0;
   if (reuse && (n->enc_ws != ws || n->enc_B != B)) return SDY_ERR_STATE;   // no previous forward on this workspace / batch
+  // (a forward that overwrites the inputs invalidates the stored encoder output until its own encoder launch has been
+  //  enqueued: an early error return must not leave a handle that claims a valid one)
+  if (!reuse) n->enc_ws = nullptr;
 
   // ---- input concat (BaseModel.concat_condition_if_needed, _base_model.py:166-192) into the tail of the big-skip
   //      buffer: cat = [ block output (E) | inputs (Cin) ]  (sfnonet.py:804-805,831-832)
@@ -1095,6 +1100,22 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   SDY_STAGE(ST_TIME_MLP, sdy_time_mlp_launch(n->tm, a->time, B, trep, ss, dp, a->drop_path_keep, drop ? 1 : 0, a->seed,
                                              a->call, a->batch_offset, rpc, stream,
                                              trep + (size_t)B * (n->cfg.with_time_emb ? n->cfg.time_dim : 1)));
+
+  // ---- drop-path skip.  DropPath (src/models/modules/drop_path.py:15-22, applied at sfnonet.py:330) multiplies the whole
+  //      branch of a trajectory -- transforms, dhconv, inner skip, MLP -- by 0 with the layer's rate; the keep decision is a
+  //      Philox function of (seed, call, layer, trajectory) that the host evaluates here exactly as time_dense_kernel does on
+  //      the device.  A block with dropped trajectories runs its kernels on the kept ones only (per-block intermediates are
+  //      indexed compactly, SdyImgMap) and writes the dropped ones' output a x + d with sdy_affine_copy_stats_launch.
+  //      Only on the default kernel path (fft360 + leg_par + dh_h3 + conv_h3 + mlp_h3); injected decisions (tests) are
+  //      device data, so they run unskipped.  SDY_NO_DROP_SKIP=1 computes everything (A/B: bit-identical results).
+  static const bool no_drop_skip = std::getenv("SDY_NO_DROP_SKIP") != nullptr;
+  const bool skip_allowed = drop && !a->drop_path_keep && !no_drop_skip && B <= SDY_MAP_MAX;
+  auto drop_path_keeps = [&](int layer, int b) {
+    const int bq = b / rpc;
+    const philox4 wd = philox4x32_10((uint32_t)(b - bq * rpc) + a->batch_offset, 0xFFFFFFFFu, 0x1000u + (uint32_t)layer,
+                                     a->call + (uint32_t)bq, (uint32_t)(a->seed & 0xFFFFFFFFu), (uint32_t)(a->seed >> 32));
+    return wd.x >= n->tm.dp_thr[layer];
+  };
 
   sdy_conv_args cv;
   static const bool no_frag = std::getenv("SDY_NO_CONV_FRAG") != nullptr;
@@ -1179,52 +1200,72 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     const bool polar_in = plan_polar_ok(pin, E), polar_out = plan_polar_ok(pout, E);
     const bool tiled_in = plan_tiled_ok(pin, E, ilv), tiled_out = plan_tiled_ok(pout, E, ilv);   // Xf / Yf tile-major (fft.h)
     // Cs / Cs2 tile-major by order too (analysis stores and synthesis loads become contiguous tiles; dh_h3 reads and writes
-    // 256-byte pieces instead of 2 KB rows, which it does not notice: it is matrix / issue bound).  SDY_NO_CS_TILED=1: off.
-    static const bool no_cs_tiled = std::getenv("SDY_NO_CS_TILED") != nullptr;
-    const bool cs_tiled = tiled_in && tiled_out && bw.fw.frag && !no_cs_tiled && pin->lmax == pout->lmax && pin->mtr == pout->mtr;
-    SDY_STAGE(ST_FFT_FWD, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, B, E,
-                                             pin->nlat, pin->mtr, tiled_in ? 2 : ilv, polar_in ? pin->d_mcut : nullptr, stream));
-    SDY_STAGE(ST_LEG_FWD, legendre_fwd_impl(pin, Xf, Cs, B, E, polar_in, stream, tiled_in, cs_tiled));
+    // 256-byte pieces instead of 2 KB rows, which it does not notice: it is matrix / issue bound).
+    const bool cs_tiled = tiled_in && tiled_out && bw.fw.frag && pin->lmax == pout->lmax && pin->mtr == pout->mtr;
+    static const bool no_stats1 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
+    const bool frag_conv = c.gemm_mode == 1 && !no_frag && bw.skw.frag && sdy_conv256_h3_supported(E, E);
+    const bool stats1 = frag_conv && !no_stats1;   // norm1 statistics from the inner-skip convolution's epilogue
+    // The tensor between the inner skip and the fused MLP has exactly one producer and one consumer, both walking 64-pixel
+    // tiles: it is stored TILE-MAJOR (a tile = one contiguous 64 KB block for the stores of one and the loads of the other).
+    const bool z_tiled = stats1 && fused_mlp;
+    const long zt_bs = (long)((HW + 63) / 64) * E * 64;
+    float* dst = (i == L - 1) ? cat : nxt;
+    const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;
+    const long cur_bs = (cur == cat) ? cat_bs : (long)E * HW;
+
+    // drop-path skip: the rows this block's kernels run on (Bp of them, `act` maps them to batch rows) and the dropped ones
+    unsigned char act[SDY_MAP_MAX], dropped[SDY_MAP_MAX];
+    int Bp = B, nD = 0;
+    if (skip_allowed && n->tm.dp_rate[i] > 0.f && lazy_norm && z_tiled && cs_tiled) {
+      Bp = 0;
+      for (int b = 0; b < B; ++b) {
+        if (drop_path_keeps(i, b)) act[Bp++] = (unsigned char)b;
+        else dropped[nD++] = (unsigned char)b;
+      }
+    }
+    const unsigned char* rows = nD > 0 ? act : nullptr;   // nullptr: every row is active, identity map
+
+    if (Bp > 0) {
+    SDY_STAGE_N(ST_FFT_FWD, Bp, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, Bp, E,
+                                                   pin->nlat, pin->mtr, tiled_in ? 2 : ilv, polar_in ? pin->d_mcut : nullptr, stream, rows));
+    SDY_STAGE_N(ST_LEG_FWD, Bp, legendre_fwd_impl(pin, Xf, Cs, Bp, E, polar_in, stream, tiled_in, cs_tiled));
     if (scale_residual) {  // residual = inverse_transform(forward_transform(x))
       SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream, tiled_out, cs_tiled));
       SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
                                                polar_out ? pout->d_mcut : nullptr, stream));
     }
     if (bw.fw.frag)
-      SDY_STAGE(ST_DHCONV, sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, B, ilv, (hipStream_t)stream,
-                                            cs_tiled ? 1 : 0));
+      SDY_STAGE_N(ST_DHCONV, Bp, sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, Bp, ilv, (hipStream_t)stream,
+                                                  cs_tiled ? 1 : 0));
     else if (c.gemm_mode == 1)
       SDY_STAGE(ST_DHCONV, sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     else
       SDY_STAGE(ST_DHCONV, sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
-    SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs2, Xf, B, E, polar_out, stream, tiled_out, cs_tiled));
-    SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, B, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
-                                             polar_out ? pout->d_mcut : nullptr, stream));
+    SDY_STAGE_N(ST_LEG_INV, Bp, legendre_inv_impl(pout, Cs2, Xf, Bp, E, polar_out, stream, tiled_out, cs_tiled));
+    SDY_STAGE_N(ST_FFT_INV, Bp, sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, Bp, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
+                                                   polar_out ? pout->d_mcut : nullptr, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
     conv_reset();
-    cv.x = lazy_norm ? cur : xn; cv.x_bstride = lazy_norm ? ((cur == cat) ? cat_bs : (long)E * HW) : (long)E * HW;
+    cv.B = Bp; cv.x_rows = rows;
+    cv.x = lazy_norm ? cur : xn; cv.x_bstride = lazy_norm ? cur_bs : (long)E * HW;
     if (lazy_norm) { cv.pa = ca; cv.pd = cd; }
     use_w(bw.skw); cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
     cv.Cin = E; cv.Cout = E; cv.bias = bw.skb.p; cv.add = y; cv.add_bstride = (long)E * HW; cv.add_mode = 1; cv.act = 1; cv.kernel_tag = 3;
-    static const bool no_stats1 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
-    const bool stats1 = cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats1;
     if (stats1) cv.stats = st1;
-    // The tensor between the inner skip and the fused MLP has exactly one producer and one consumer, both walking 64-pixel
-    // tiles: it is stored TILE-MAJOR (a tile = one contiguous 64 KB block for the stores of one and the loads of the other).
-    static const bool no_ztile = std::getenv("SDY_NO_Z_TILED") != nullptr;
-    const bool z_tiled = stats1 && fused_mlp && !no_ztile;
-    const long zt_bs = (long)((HW + 63) / 64) * E * 64;
     if (z_tiled) { cv.out = ws + w.zt; cv.out_bstride = zt_bs; cv.out_tiled = 1; }
-    SDY_STAGE(ST_SKIP_CONV, sdy_conv1x1(&cv, stream));
+    SDY_STAGE_N(ST_SKIP_CONV, Bp, sdy_conv1x1(&cv, stream));
     // norm1 (sfnonet.py:313-320) folded into the fc1 prologue; its statistics come from the convolution's epilogue
     if (stats1)
-      SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_from_stats(st1, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+      SDY_STAGE_N(ST_NORM_COEFFS, Bp, sdy_instnorm_from_stats(st1, Bp, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
     else
       SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+    }
     // MLP (layers.py:73-80): fc1 + GELU + dropout
-    float* dst = (i == L - 1) ? cat : nxt;
-    const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;
-    if (fused_mlp) {
+    static const bool no_stats = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
+    const bool stats_next = fused_mlp && i < L - 1 && !no_stats;   // the next block's norm0 statistics from this block's epilogue
+    if (Bp == 0) {
+      // (every trajectory dropped: nothing of the branch runs)
+    } else if (fused_mlp) {
       // fc1 + GELU + dropout + fc2 + dropout + DropPath + residual in one launch: the hidden activation stays on the CU
       sdy_mlp_args ma;
       std::memset(&ma, 0, sizeof(ma));
@@ -1232,9 +1273,9 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       if (z_tiled) { ma.x = ws + w.zt; ma.x_bstride = zt_bs; ma.x_tiled = 1; }
       ma.w = bw.mlp; ma.w1_scale = bw.mlp_s1; ma.w2_scale = bw.mlp_s2; ma.b1 = bw.b1.p; ma.b2 = bw.b2.p;
       ma.out = dst; ma.out_bstride = dst_bs;
-      if (lazy_norm) { ma.add = cur; ma.add_bstride = (long)E * HW; ma.add_a = ca; ma.add_d = cd; }
+      if (lazy_norm) { ma.add = cur; ma.add_bstride = cur_bs; ma.add_a = ca; ma.add_d = cd; }
       else { ma.add = xn; ma.add_bstride = (long)E * HW; }
-      ma.B = B; ma.E = E; ma.hidden = Hd; ma.HW = HW;
+      ma.B = Bp; ma.out_rows = rows; ma.E = E; ma.hidden = Hd; ma.HW = HW;
       ma.drop_p = pm; ma.seed = a->seed; ma.call = a->call; ma.stream_fc1 = 2u * i; ma.stream_fc2 = 2u * i + 1u;
       ma.batch_offset = a->batch_offset; ma.rows_per_call = rpc;
       if (drop && n->tm.dp_rate[i] > 0.f) ma.batch_scale = dp + (size_t)i * B;  // dp is laid out [layer][b]
@@ -1242,9 +1283,8 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
         ma.keep_hidden = static_cast<const float*>(a->keep_masks[2 * i]);
         ma.keep_out = static_cast<const float*>(a->keep_masks[2 * i + 1]);
       }
-      static const bool no_stats = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
-      if (i < L - 1 && !no_stats) { ma.stats = st0; have_st0 = true; }   // the next block's norm0 statistics
-      SDY_STAGE(pm > 0.f ? ST_MLP_FUSED_DROP : ST_MLP_FUSED, sdy_mlp_h3(&ma, stream));
+      if (stats_next) ma.stats = st0;
+      SDY_STAGE_N(pm > 0.f ? ST_MLP_FUSED_DROP : ST_MLP_FUSED, Bp, sdy_mlp_h3(&ma, stream));
     } else {
       conv_reset();
       cv.x = y; cv.x_bstride = (long)E * HW; use_w(bw.w1); cv.ldw = Hd; cv.out = hid; cv.out_bstride = (long)Hd * HW;
@@ -1260,6 +1300,10 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       cv.add = xn; cv.add_bstride = (long)E * HW; cv.add_mode = 2;
       SDY_STAGE(ST_FC2, sdy_conv1x1(&cv, stream));
     }
+    if (nD > 0)   // dropped trajectories: block output = the residual a x + d; their share of the next block's statistics
+      SDY_STAGE_N(ST_DROP_COPY, nD, sdy_affine_copy_stats_launch(cur, cur_bs, ca, cd, dst, dst_bs, stats_next ? st0 : nullptr, E, HW,
+                                                                 dropped, nD, stream));
+    if (stats_next) have_st0 = true;
     cur = dst;
     nxt = (dst == xa) ? xb : xa;
   }

@@ -56,6 +56,26 @@ struct SdyOncePerDevice {                            // `static SdyOncePerDevice
   }
 };
 
+// Image map of the drop-path skip (capi.hip, sdy_sfno_forward): a block whose DropPath draw zeroes the branch of some
+// trajectories (src/models/modules/drop_path.py:15-22) runs on the ACTIVE trajectories only.  Its per-block intermediates are
+// indexed compactly (j = 0 .. n_active - 1); the tensors that live across blocks keep their batch row idx[j].  Passed by value
+// in the kernel arguments (a uniform index into the kernarg segment: scalar loads); `on == 0` is the identity.
+constexpr int SDY_MAP_MAX = 64;
+struct SdyImgMap {
+  int on;
+  unsigned char idx[SDY_MAP_MAX];
+};
+__host__ __device__ __forceinline__ int sdy_img(const SdyImgMap& m, int j) { return m.on ? (int)m.idx[j] : j; }
+static inline int sdy_img_map_fill(SdyImgMap& m, const unsigned char* rows, int n) {   // rows == nullptr: identity
+  m.on = 0;
+  for (int i = 0; i < SDY_MAP_MAX; ++i) m.idx[i] = 0;
+  if (!rows) return SDY_OK;
+  if (n > SDY_MAP_MAX) return SDY_ERR_UNSUPPORTED;
+  m.on = 1;
+  for (int i = 0; i < n; ++i) m.idx[i] = rows[i];
+  return SDY_OK;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Compile-time loop: f(std::integral_constant<int, I>) for I = B .. E - 1.  `#pragma unroll` gives up on long bodies
 // ("unrolled size too large"), and register arrays indexed by the loop variable then live in scratch.
@@ -109,6 +129,14 @@ __device__ __forceinline__ void sdy_flag_range(unsigned* flags, float amax) {
 #define SDY_STREAM_STORE(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// InstanceNorm statistics of a stored 4-pixel quad as fp32 partials (summed in fp64 by the callers).  Spelled out with explicit
+// FMAs: the fused MLP's epilogue and the drop-path copy kernel (pointwise.hip) must round alike, or a block output written by one
+// instead of the other would change the next block's coefficients in the last bit (left to -ffp-contract, one kernel came out
+// as fma(x, x, y*y), the other as fma(y, y, x*x)).
+__device__ __forceinline__ float sdy_quad_sum(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float sdy_quad_sumsq(f32x4 v) {
+  return __builtin_fmaf(v.x, v.x, v.y * v.y) + __builtin_fmaf(v.z, v.z, v.w * v.w);
+}
 // MEASUREMENT BUILDS ONLY (csrc/Makefile EXTRA=-DSDY_H3_PASSES=1): drop the two cross terms Ah.Bl + Al.Bh of every
 // split-precision product, i.e. single-pass f16 MFMA arithmetic (fp16-class accuracy: ~1e-3) with everything else -- the
 // hi / lo splits, the loads of the lo fragments, the schedules -- unchanged.  Bounds what the three passes cost and gives the

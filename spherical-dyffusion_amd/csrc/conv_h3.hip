@@ -71,6 +71,7 @@ struct ConvParams {
   float out_scale;
   unsigned* flags;                 // sticky status word (sdy_status_flags)
   const float* gelu_tab;           // GELU table in global memory (sdy_gelu_table_ptr)
+  SdyImgMap xmap;                  // drop-path skip: image z of this launch reads x / pa / pd of batch row xmap.idx[z] (common.h)
   unsigned long long* stamps;    // timing experiments only (SDY_CONV_STAMPS)
 };
 
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
   // lane and tile), the SADDR form of global_load / global_store -- per-row 64-bit lane addresses (16 rows x 3 streams) would
   // be hoisted out of the tile loop and spilled.  Lane offsets: x rows 8 o0 + e, addend / output rows o0 + CRS i.
   auto img = [&](const float* base, long bs, int t) { return base + (long)(t / tpi) * bs; };   // uniform
+  auto ximg = [&](int t) { return p.x + (long)sdy_img(p.xmap, t / tpi) * p.x_bs; };             // uniform
   auto lane_col = [&](int t) {   // first pixel of this lane's quad in tile t; a lane beyond the ragged edge re-reads column 0
     const int nn = (t % tpi) * CTN + 4 * q0;
     return nn < p.HW ? nn : 0;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
   const float* addsrc = p.add ? p.add : p.out;          // (p.out: never dereferenced without an addend, keeps it branch-free)
   const long addsrc_bs = p.add ? p.add_bs : p.out_bs;
   if (t_begin < t_end) {
-    const float* xz = img(p.x, p.x_bs, t_begin);
+    const float* xz = ximg(t_begin);
     const unsigned xo = (unsigned)(8 * o0 * p.HW + lane_col(t_begin)) * 4u;
 #pragma unroll
     for (int oc = 0; oc < COC; ++oc)
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
     };
     stamp(0);
     const int z = tile / tpi;
+    const int zx = sdy_img(p.xmap, z);
     const int n0 = (tile - z * tpi) * CTN;
     const bool full = n0 + CTN <= p.HW;
 
@@ -196,10 +199,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
         if (8 * CRS * oc + 8 * CRS > KROW && c0 >= KROW) continue;   // octets beyond the LDS row
         float av[8], dv[8];
         if (p.pa) {
-          const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * CE + c0);
-          const f32x4 a1 = *reinterpret_cast<const f32x4*>(p.pa + (long)z * CE + c0 + 4);
-          const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.pd + (long)z * CE + c0);
-          const f32x4 d1 = *reinterpret_cast<const f32x4*>(p.pd + (long)z * CE + c0 + 4);
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.pa + (long)zx * CE + c0);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(p.pa + (long)zx * CE + c0 + 4);
+          const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.pd + (long)zx * CE + c0);
+          const f32x4 d1 = *reinterpret_cast<const f32x4*>(p.pd + (long)zx * CE + c0 + 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             av[e] = a0[e] * CSX; av[e + 4] = a1[e] * CSX;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
     const unsigned ro_out = p.out_tiled ? (unsigned)(o0 * CTN + 4 * q0) * 4u : ro;
     const int out_rs = p.out_tiled ? CTN : p.HW;
     const int tnext = (tile + 1 < t_end) ? tile + 1 : tile;   // past the end: a harmless re-read
-    const float* xz_next = img(p.x, p.x_bs, tnext);
+    const float* xz_next = ximg(tnext);
     const unsigned xo_next = (unsigned)(8 * o0 * p.HW + lane_col(tnext)) * 4u;
     stamp(2);
     // ---- MFMA phase: rows 32 CMT wave .. + 32 CMT, all 64 px, K = 64 KBLK
@@ -448,6 +451,7 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   SDY_TRY(sdy_flags_ptr(&p.flags));
   SDY_TRY(sdy_gelu_table_ptr(&p.gelu_tab));
   p.HW = a->HW; p.B = a->B; p.Cin = a->Cin;
+  SDY_TRY(sdy_img_map_fill(p.xmap, a->x_rows, a->B));
   p.out_scale = 1.0f / (a->w_frag_scale * CSX);
   p.stamps = nullptr;
 #if SDY_STAMPS_ON

@@ -426,8 +426,7 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
   SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;
   {   // degree -> XCD: degrees by falling tile count (ties: higher degree first), each to the XCD with the fewest tiles so far
-    static const bool no_table = std::getenv("SDY_DH_NO_BALANCE") != nullptr;
-    p.use_table = (L <= 256 && !no_table) ? 1 : 0;
+    p.use_table = L <= 256 ? 1 : 0;
     if (p.use_table) {
       int order[256];
       long tiles[256], load[8] = {0, 0, 0, 0, 0, 0, 0, 0};

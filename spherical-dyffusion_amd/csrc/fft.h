@@ -14,8 +14,11 @@ struct SdyFftDesc {
 // Polar cut-off (fused forward only): for latitude ring k only the orders m < mcut[k] are written (forward) / read (inverse);
 // the Legendre tables are negligible (< 1e-12 of their maximum) beyond it, see sdy_sht_plan::d_kdead.  nullptr = all orders.
 
+// x_rows (host, [B], or nullptr = identity; fft360 only, B <= 64): row b of Xf is the transform of batch row x_rows[b] of
+// x / a / d / xn_out -- the drop-path skip of the fused forward runs a block on its active trajectories only (common.h, SdyImgMap)
 int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                       int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream);
+                       int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream,
+                       const unsigned char* x_rows = nullptr);
 int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
                        int ilv, const int* mcut, hipStream_t stream);
 
@@ -30,6 +33,7 @@ int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, 
 //      of 180 runs of 256 bytes 2 B C floats apart.  C % 32 == 0.  The generic kernels refuse it.
 // nlon = 360 specialisation (fft360.hip); SDY_ERR_UNSUPPORTED when the shape does not fit
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                          int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream);
+                          int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream,
+                          const unsigned char* x_rows = nullptr);
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
                           int mtr, int ilv, const int* mcut, hipStream_t stream);

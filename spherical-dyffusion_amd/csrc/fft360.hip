@@ -224,23 +224,24 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
                                                            const float* __restrict__ pa, const float* __restrict__ pd,
                                                            float* __restrict__ xn_out, float* __restrict__ Xf, int B,
                                                            int C, int K, int mtr, int ilv,
-                                                           const int* __restrict__ mcut) {
+                                                           const int* __restrict__ mcut, const SdyImgMap xmap) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
   __shared__ c2 TW[TWN];
   __shared__ c2 AD[ROWS];   // per-slot affine (a, d)
   const Lane L = lane_roles(Z);
   const WgId id = wg_id(C / ROWS, (K + KPW - 1) / KPW);
   const int c0 = id.x * ROWS, b = id.z;
+  const int bx = sdy_img(xmap, b);   // drop-path skip: spectral row b of this launch is batch row bx of x / pa / pd / xn_out
   const int k_begin = id.y * KPW, k_end = min(K, k_begin + KPW);
 
   fill_twiddles(f, TW);
   if (threadIdx.x < ROWS) {
     const int s = threadIdx.x, ch = c0 + 4 * (s & 3) + (s >> 2);
-    AD[s] = pa ? c2{pa[b * C + ch], pd[b * C + ch]} : c2{1.0f, 0.0f};
+    AD[s] = pa ? c2{pa[bx * C + ch], pd[bx * C + ch]} : c2{1.0f, 0.0f};
   }
 
-  const float* xw = x + (((long)b * C + c0 + L.wave) * K) * NLON + 4 * L.lane;      // row r of the wave: + 4 r K N
-  float* xnw = xn_out ? xn_out + (((long)b * C + c0 + L.wave) * K) * NLON + 4 * L.lane : nullptr;
+  const float* xw = x + (((long)bx * C + c0 + L.wave) * K) * NLON + 4 * L.lane;      // row r of the wave: + 4 r K N
+  float* xnw = xn_out ? xn_out + (((long)bx * C + c0 + L.wave) * K) * NLON + 4 * L.lane : nullptr;
   const long rstride = 4L * K * NLON;
   c2* zw = Z + 4 * L.wave * P + 2 * L.lane;
   const bool tail = L.lane < TAIL;
@@ -431,12 +432,15 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
 
 // nlon = 360 fast path; returns SDY_ERR_UNSUPPORTED when the shape does not fit (the caller falls back to fft.hip)
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
-                          int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream) {
+                          int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream,
+                          const unsigned char* x_rows) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
   if (ilv == 2 && (C % (2 * ROWS) != 0 || ROWS != 16)) return SDY_ERR_UNSUPPORTED;   // a 64-column tile = two channel blocks
   constexpr int KPW = SDY_FFT_KPW;
+  SdyImgMap xmap;
+  SDY_TRY(sdy_img_map_fill(xmap, x_rows, B));
   dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
-  hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut);
+  hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut, xmap);
   return sdy_launch_status();
 }
 

@@ -525,7 +525,7 @@ int sdy_gemm_h3_launch(const GemmParams& p, const void* packed, int rows_pad, in
   if (rows_pad < ((p.M_store + 127) / 128) * 128) return SDY_ERR_ARG;
   // wide tile for 256-row conv layers (measured: 256 -> 256 and 512 -> 256 convs +8-10 %; the short-K, triangular
   // Legendre GEMMs and the 512-row fc1 are faster on the 128 x 128 kernel)
-  if (p.tri_mode == SDY_TRI_NONE && p.M_store == 256 && rows_pad % 256 == 0 && !getenv("SDY_H3_NO_WIDE")) {
+  if (p.tri_mode == SDY_TRI_NONE && p.M_store == 256 && rows_pad % 256 == 0) {
     switch (p.tag) {
       case 1: return launch_h3_wide<1>(p, pk, sx, out_scale, stream);
       case 2: return launch_h3_wide<2>(p, pk, sx, out_scale, stream);

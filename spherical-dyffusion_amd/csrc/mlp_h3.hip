@@ -72,6 +72,8 @@ struct MlpParams {
   const float* keep_h; const float* keep_o; // INJECT instantiation only (tests): 0/1 masks (B, MH, HW) / (B, ME, HW)
   unsigned* flags;                         // sticky status word (sdy_status_flags)
   unsigned long long* stamps;              // timing experiments only (SDY_MLP_STAMPS): per-phase s_memtime of one wave
+  SdyImgMap omap;                          // drop-path skip (common.h): image z of this launch (x, pa, pd) is batch row omap.idx[z]
+                                           // of add / add_a / add_d / out / stats / batch_scale / keep_* and of the dropout stream
 };
 
 // 4-bit slot swizzle of pixel row px: injective on each ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   const int t_per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t_begin = (int)blockIdx.x * t_per;
   const int t_end = (t_begin + t_per < ntiles) ? t_begin + t_per : ntiles;
-  int z = 0, n0 = 0;
+  int z = 0, zo = 0, n0 = 0;   // zo: the image's batch row outside this launch (omap)
   bool full = true;
 
   // ---- weight ring: slot s holds group s of the block being consumed; refilled for the next block right after its use
@@ -146,11 +148,11 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     // the thread index is rebuilt from the SGPR wave index and the lane count of the exec mask: kept in a register across the
     // tile loop for this rare use (image changes) it is the one value the dropout variant spills
     const int t = 64 * wave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const long c = (long)zz * ME + t;
+    const long c = (long)zz * ME + t, co = (long)sdy_img(p.omap, zz) * ME + t;
     Cf[t] = p.pa ? p.pa[c] * SX : SX;
     Cf[ME + t] = p.pa ? p.pd[c] * SX : 0.0f;
-    Cf[2 * ME + t] = p.add_a ? p.add_a[c] : 1.0f;
-    Cf[3 * ME + t] = p.add_a ? p.add_d[c] : 0.0f;
+    Cf[2 * ME + t] = p.add_a ? p.add_a[co] : 1.0f;
+    Cf[3 * ME + t] = p.add_a ? p.add_d[co] : 0.0f;
   };
   Cb2[tid] = DROP ? p.b2[tid] * p.drop_scale : p.b2[tid];   // (see s2e in the epilogue)
   if (t_begin < t_end) load_coeffs(t_begin / tpi);
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   };
   stamp(0);
   z = tile / tpi;
+  zo = sdy_img(p.omap, z);
   n0 = (tile - z * tpi) * TN;
   full = n0 + TN <= p.HW;   // workgroup-uniform
 
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 
   constexpr bool do_drop = DROP;
   // stacked calls: image z is trajectory z % rows_per_call of call + z / rows_per_call
-  const int zq = z / p.rows_per_call, zt = z - zq * p.rows_per_call;
+  const int zq = zo / p.rows_per_call, zt = zo - zq * p.rows_per_call;
   const uint32_t call_z = p.call + (uint32_t)zq;
   const uint32_t c1_base = (uint32_t)(((uint64_t)(zt + p.batch_offset) * (uint64_t)(MH >> 2)) & 0xFFFFFFFFu);
 
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   // INJECT: keep flag of hidden row `row`, tile pixel `px` of image z from the mask tensor (a global load per value: tests only)
   auto keep_h_at = [&](int row, int px) {
     const int pix = (n0 + px < p.HW) ? n0 + px : p.HW - 1;
-    return p.keep_h[((long)z * MH + row) * p.HW + pix] != 0.0f;
+    return p.keep_h[((long)zo * MH + row) * p.HW + pix] != 0.0f;
   };
   auto chain_stage = [&](Piece& s, int st, int hc, int j, int g4) {
     const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   {
     // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested before
     // the epilogue arithmetic, which covers most of their latency
-    const float* az = p.add ? p.add + (long)z * p.add_bs : p.x + (long)z * p.x_bs;   // uniform
+    const float* az = p.add ? p.add + (long)zo * p.add_bs : p.x + (long)z * p.x_bs;   // uniform
 #pragma unroll
     for (int i = 0; i < 16; ++i) rres[i] = sdy_ld16s(az + (long)(16 * i) * p.HW, e_ro);
   }
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   // ---- epilogue: bias, dropout, drop-path scale in accumulator layout -> LDS [256 rows][64 px] (the x tile's storage:
   //      every wave passed the last chunk's barrier after its final x read), then residual add + 16-byte row stores
   {
-    const float bscale = p.batch_scale ? p.batch_scale[z] : 1.0f;
+    const float bscale = p.batch_scale ? p.batch_scale[zo] : 1.0f;
     // Both dropouts scale what they keep by 1 / (1 - p): the hidden one is folded into the fc2 accumulator scale, the output
     // one into that scale and the bias (Cb2 holds b2 / (1 - p)) -- no multiply per value, and the fp16 split of the hidden
     // activation sees the unscaled values.
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
             if (do_drop) {
               if constexpr (INJECT) {
                 const int pix = (n0 + px < p.HW) ? n0 + px : p.HW - 1;
-                const float* km = p.keep_o + ((long)z * ME + row0 + 8 * g4 + r4) * p.HW + pix;
+                const float* km = p.keep_o + ((long)zo * ME + row0 + 8 * g4 + r4) * p.HW + pix;
                 o = sdy_gf2{km[0] != 0.0f ? o.x : 0.0f, km[p.HW] != 0.0f ? o.y : 0.0f};
               } else {
                 o = sdy_gf2{sdy_keep16(words[r4], j, p.drop_thr) ? o.x : 0.0f,
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     __syncthreads();
     stamp(14);
     if (e_ok) {
-      float* oz = p.out + (long)z * p.out_bs;   // uniform
+      float* oz = p.out + (long)zo * p.out_bs;   // uniform
       const float* os = Os + (tid >> 4) * TN + 4 * (tid & 15);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -756,8 +759,8 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         if (p.add) v += rres[i] * Cf[2 * ME + row] + Cf[3 * ME + row];
         sdy_st16s(oz + (long)(16 * i) * p.HW, e_ro, v);
         if (p.stats) {
-          psum[i] += (double)((v.x + v.y) + (v.z + v.w));
-          psq[i] += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+          psum[i] += (double)sdy_quad_sum(v);
+          psq[i] += (double)sdy_quad_sumsq(v);
         }
       }
     }
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
             s2 += __shfl_xor(s2, m, 64);
           }
           if ((tid & 15) == 0) {
-            double* st = p.stats + ((long)z * ME + (tid >> 4) + 16 * i) * 2;
+            double* st = p.stats + ((long)zo * ME + (tid >> 4) + 16 * i) * 2;
             __hip_atomic_fetch_add(st, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(st + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -910,11 +913,15 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   }
   p.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFu); p.seed_hi = (uint32_t)(a->seed >> 32);
   p.stream1 = a->stream_fc1; p.stream2 = a->stream_fc2; p.call = a->call; p.batch_offset = a->batch_offset;
-  if (a->rows_per_call < 0 || (a->rows_per_call > 0 && a->B % a->rows_per_call)) return SDY_ERR_ARG;
+  // (with out_rows the launch's B counts the mapped rows only: the stacking is a property of the batch rows they map to)
+  if (a->rows_per_call < 0 || (!a->out_rows && a->rows_per_call > 0 && a->B % a->rows_per_call)) return SDY_ERR_ARG;
+  if (a->out_rows && a->rows_per_call == 0) return SDY_ERR_ARG;
   p.rows_per_call = a->rows_per_call > 0 ? a->rows_per_call : a->B;
   p.batch_scale = a->batch_scale;
   p.stats = a->stats;
   p.keep_h = a->keep_hidden; p.keep_o = a->keep_out;
+  if (a->out_rows && !a->add) return SDY_ERR_ARG;   // (without `add` the residual is x itself: one index for both)
+  SDY_TRY(sdy_img_map_fill(p.omap, a->out_rows, a->B));
   SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;
 #if SDY_STAMPS_ON && !defined(SDY_MLP_INJECT_TU)

@@ -95,6 +95,52 @@ __global__ __launch_bounds__(256) void instnorm_from_stats_kernel(double* __rest
   d_out[i] = d;
 }
 
+// ---- drop-path skip: the block output of a trajectory whose branch DropPath zeroed ------------------------------------
+// The block computes  out = drop_path(mlp(...)) + residual  with residual = norm0(x) (+ time scale / shift) = a x + d
+// (src/models/sfno/sfnonet.py:289-337, src/models/modules/drop_path.py:15-22); for a dropped trajectory that is
+// out = 0 * (...) + (a x + d).  capi.hip runs the block's kernels on the kept trajectories only; this kernel writes the dropped
+// ones' output -- the same fma the fused MLP's epilogue applies to its residual rows -- and, like that epilogue, the
+// (sum, sum of squares) of what it stores for the next block's InstanceNorm: fp32 per 4-pixel quad, fp64 across quads.
+// One workgroup per (channel, dropped image).
+__global__ __launch_bounds__(256) void affine_copy_stats_kernel(const float* __restrict__ x, long x_bs,
+                                                                 const float* __restrict__ a, const float* __restrict__ d,
+                                                                 float* __restrict__ out, long out_bs,
+                                                                 double* __restrict__ stats, int C, int HW,
+                                                                 const SdyImgMap rows) {
+  const int c = blockIdx.x, b = sdy_img(rows, blockIdx.y);
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(x + (long)b * x_bs + (long)c * HW);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out + (long)b * out_bs + (long)c * HW);
+  const float av = a[b * C + c], dv = d[b * C + c];
+  double s = 0.0, s2 = 0.0;
+  const int n4 = HW >> 2;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 r = p4[i];
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(r[e], av, dv);
+    o4[i] = v;
+    s += (double)sdy_quad_sum(v);
+    s2 += (double)sdy_quad_sumsq(v);
+  }
+  if (!stats) return;   // (uniform)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  __shared__ double sh[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[wave] = s;
+    sh[4 + wave] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // the one writer of this (image, channel): the caller zeroed the slot
+    stats[((long)b * C + c) * 2] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    stats[((long)b * C + c) * 2 + 1] += (sh[4] + sh[5]) + (sh[6] + sh[7]);
+  }
+}
+
 // ---- channel concat (torch.cat(dim=1)) ------------------------------------------------------------------
 struct ConcatArgs {
   const float* src[4];
@@ -735,6 +781,16 @@ extern "C" int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, cons
   SDY_TRY(sdy_flags_ptr(&flags));
   hipLaunchKernelGGL(instnorm_from_stats_kernel, dim3((BC + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, BC, C, HW,
                      gamma, beta, ss, ss_stride, eps, a, d, flags);
+  return sdy_launch_status();
+}
+
+int sdy_affine_copy_stats_launch(const float* x, long x_bs, const float* a, const float* d, float* out, long out_bs,
+                                 double* stats, int C, int HW, const unsigned char* rows, int n_rows, hipStream_t stream) {
+  if (!x || !a || !d || !out || !rows || C <= 0 || HW <= 0 || n_rows <= 0) return SDY_ERR_ARG;
+  if ((HW & 3) || (x_bs & 3) || (out_bs & 3)) return SDY_ERR_ALIGN;
+  SdyImgMap m;
+  SDY_TRY(sdy_img_map_fill(m, rows, n_rows));
+  hipLaunchKernelGGL(affine_copy_stats_kernel, dim3(C, n_rows), dim3(256), 0, stream, x, x_bs, a, d, out, out_bs, stats, C, HW, m);
   return sdy_launch_status();
 }
 

@@ -371,19 +371,21 @@ def raise_on_status_flags(flags: int, where: str) -> None:
 
 class stage_timer:
     """Context manager around `sdy_profile_*`: per-stage HIP-event timing of every SFNO forward issued inside the block
-    (events on the launch stream).  `.stages` afterwards: {stage name: (launches, total_ms)}.  Measurement only."""
+    (events on the launch stream).  `.stages` afterwards: {stage name: (launches, total_ms)}; `.rows`: {stage name: batch rows
+    summed over its launches} (with the drop-path skip a block's kernels run on the kept trajectories only).  Measurement only."""
 
     def __enter__(self):
         n = lib.sdy_profile_stage_count()
         check(lib.sdy_profile_read((C.c_double * n)(), (C.c_long * n)(), n))      # drop stale records
         check(lib.sdy_profile_enable(1))
-        self.stages = {}
+        self.stages, self.rows = {}, {}
         return self
 
     def __exit__(self, *exc):
         check(lib.sdy_profile_enable(0))
         n = lib.sdy_profile_stage_count()
-        ms, cnt = (C.c_double * n)(), (C.c_long * n)()
-        check(lib.sdy_profile_read(ms, cnt, n), "sdy_profile_read")
+        ms, cnt, rows = (C.c_double * n)(), (C.c_long * n)(), (C.c_long * n)()
+        check(lib.sdy_profile_read_rows(ms, cnt, rows, n), "sdy_profile_read_rows")
         self.stages = {lib.sdy_profile_stage_name(i).decode(): (int(cnt[i]), float(ms[i])) for i in range(n) if cnt[i]}
+        self.rows = {lib.sdy_profile_stage_name(i).decode(): int(rows[i]) for i in range(n) if cnt[i]}
         return False

@@ -11,9 +11,8 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = ["SDY_NO_SPEC_ILV", "SDY_NO_DH_FRAG", "SDY_NO_FFT360", "SDY_NO_FUSED_MLP", "SDY_NO_CONV_FRAG",
-            "SDY_NO_LEG_FRAG", "SDY_NO_LEG_PAR", "SDY_NO_FUSED_STATS", "SDY_NO_POLAR_SKIP", "SDY_NO_XF_TILED",
-            "SDY_NO_Z_TILED", "SDY_NO_CS_TILED", "SDY_NO_PAIR", "SDY_DH_NO_BALANCE"]
+VARIANTS = ["SDY_NO_DH_FRAG", "SDY_NO_FFT360", "SDY_NO_FUSED_MLP", "SDY_NO_CONV_FRAG", "SDY_NO_LEG_FRAG", "SDY_NO_LEG_PAR",
+            "SDY_NO_FUSED_STATS", "SDY_NO_POLAR_SKIP", "SDY_NO_PAIR"]
 TOL = 2e-5
 
 
@@ -36,3 +35,28 @@ def test_kernel_selection_switches_agree(tmp_path):
         got = _run(tmp_path, v, {v: "1"})
         err = (torch.linalg.vector_norm(got.double() - ref.double()) / torch.linalg.vector_norm(ref.double())).item()
         assert err < TOL, f"{v}=1 differs from the default path: rel L2 {err:.3e}"
+
+
+@pytest.mark.gpu
+def test_drop_path_skip_is_bit_identical(tmp_path):
+    """The drop-path skip (capi.hip: a block runs on the trajectories its DropPath draw keeps, the dropped ones' output is the
+    residual a x + d) against SDY_NO_DROP_SKIP=1, which computes every branch and multiplies the dropped ones by 0
+    (src/models/modules/drop_path.py:15-22, sfnonet.py:330-337): the same bits, for a batch, for stacked calls, for single
+    trajectories whose blocks are dropped whole, on both data grids (with the Legendre-Gauss grid the last block skips too)."""
+    def run(tag, env_extra):
+        out = tmp_path / f"{tag}.pt"
+        env = dict(os.environ)
+        env.update(env_extra)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "drop_skip_forward.py"), str(out)], env=env, cwd=ROOT,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, f"{tag}: {r.stderr[-2000:]}"
+        return torch.load(out)
+
+    skip, full = run("skip", {}), run("full", {"SDY_NO_DROP_SKIP": "1"})
+    assert skip.keys() == full.keys()
+    bad = {k: (skip[k] - full[k]).abs().max().item() for k in skip if not torch.equal(skip[k], full[k])}
+    assert all(torch.isfinite(v).all() for v in skip.values())
+    assert not bad, f"outputs differ (max |diff| per case): {bad}"
+    # the stacked forward is the two calls of three trajectories: its rows differ from the one-call batch (other call numbers)
+    assert not torch.equal(skip["equiangular/b6"][3:], skip["equiangular/b6_stacked"][3:])
