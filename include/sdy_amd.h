@@ -225,6 +225,8 @@ typedef struct sdy_mlp_args {
   const unsigned char* out_rows;       /* host [B] or NULL, B <= 64: image z of this launch (x, pa, pd indexed by z) IS batch row
                                           out_rows[z] -- add, add_a, add_d, out, stats, batch_scale, keep_* and the dropout stream
                                           (call, trajectory) are taken at that row (see sdy_conv_args.x_rows) */
+  int add_by_launch_row;               /* with out_rows and without add_a / add_d: `add` is indexed by the launch's image z, like x
+                                          (a residual that was materialised in the launch's own row order) */
 } sdy_mlp_args;
 /* (sum, sumsq) statistics -> the same per-(b,c) affine coefficients as sdy_instnorm_coeffs; clears `stats` for reuse. */
 int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, const float* gamma, const float* beta,

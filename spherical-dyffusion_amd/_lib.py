@@ -66,6 +66,7 @@ class SdyMlpArgs(C.Structure):
         ("x_tiled", C.c_int),
         ("keep_hidden", C.c_void_p), ("keep_out", C.c_void_p),
         ("out_rows", C.c_void_p),
+        ("add_by_launch_row", C.c_int),
     ]
 
 

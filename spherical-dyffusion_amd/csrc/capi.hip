@@ -1213,30 +1213,43 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     const long dst_bs = (i == L - 1) ? cat_bs : (long)E * HW;
     const long cur_bs = (cur == cat) ? cat_bs : (long)E * HW;
 
-    // drop-path skip: the rows this block's kernels run on (Bp of them, `act` maps them to batch rows) and the dropped ones
-    unsigned char act[SDY_MAP_MAX], dropped[SDY_MAP_MAX];
+    // drop-path skip: the rows this block's kernels run on (Bp of them: perm[0 .. Bp) are their batch rows) and the dropped
+    // ones (perm[Bp .. B)).  Two forms:
+    //  * the residual is a x + d of the block input (lazy_norm: every block between the first and the last, or all of them when
+    //    the data grid is the Gauss grid): NOTHING of the block runs for a dropped row, its output is the affine copy;
+    //  * the residual is the SHT round trip of a x + d (scale_residual, s2convolutions.py:79-83: the first / last block on an
+    //    equiangular data grid): forward transform and the residual's inverse transform run on all rows, in the ORDER perm
+    //    (kept rows first -- a row's transform does not depend on its place in the batch), so that the dhconv, the second
+    //    inverse transform, the inner skip and the MLP work on the leading Bp rows of tensors in that order; a dropped row's
+    //    output is the copy of its residual.
+    unsigned char perm[SDY_MAP_MAX];
     int Bp = B, nD = 0;
-    if (skip_allowed && n->tm.dp_rate[i] > 0.f && lazy_norm && z_tiled && cs_tiled) {
+    if (skip_allowed && n->tm.dp_rate[i] > 0.f && fused_mlp && z_tiled && cs_tiled) {
+      unsigned char drp[SDY_MAP_MAX];
       Bp = 0;
       for (int b = 0; b < B; ++b) {
-        if (drop_path_keeps(i, b)) act[Bp++] = (unsigned char)b;
-        else dropped[nD++] = (unsigned char)b;
+        if (drop_path_keeps(i, b)) perm[Bp++] = (unsigned char)b;
+        else drp[nD++] = (unsigned char)b;
       }
+      for (int k = 0; k < nD; ++k) perm[Bp + k] = drp[k];
     }
-    const unsigned char* rows = nD > 0 ? act : nullptr;   // nullptr: every row is active, identity map
+    const unsigned char* rows = nD > 0 ? perm : nullptr;   // nullptr: every row is active, identity map
+    const int Bf = scale_residual ? B : Bp;                // rows of the forward transform
 
-    if (Bp > 0) {
-    SDY_STAGE_N(ST_FFT_FWD, Bp, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, Bp, E,
+    if (Bf > 0) {
+    SDY_STAGE_N(ST_FFT_FWD, Bf, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, Bf, E,
                                                    pin->nlat, pin->mtr, tiled_in ? 2 : ilv, polar_in ? pin->d_mcut : nullptr, stream, rows));
-    SDY_STAGE_N(ST_LEG_FWD, Bp, legendre_fwd_impl(pin, Xf, Cs, Bp, E, polar_in, stream, tiled_in, cs_tiled));
-    if (scale_residual) {  // residual = inverse_transform(forward_transform(x))
+    SDY_STAGE_N(ST_LEG_FWD, Bf, legendre_fwd_impl(pin, Xf, Cs, Bf, E, polar_in, stream, tiled_in, cs_tiled));
+    if (scale_residual) {  // residual = inverse_transform(forward_transform(x)); in the order `perm` when rows were dropped
       SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream, tiled_out, cs_tiled));
       SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
                                                polar_out ? pout->d_mcut : nullptr, stream));
     }
+    }
+    if (Bp > 0) {
     if (bw.fw.frag)
       SDY_STAGE_N(ST_DHCONV, Bp, sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, Bp, ilv, (hipStream_t)stream,
-                                                  cs_tiled ? 1 : 0));
+                                                  cs_tiled ? 1 : 0, Bf));
     else if (c.gemm_mode == 1)
       SDY_STAGE(ST_DHCONV, sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
     else
@@ -1246,7 +1259,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
                                                    polar_out ? pout->d_mcut : nullptr, stream));
     // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
     conv_reset();
-    cv.B = Bp; cv.x_rows = rows;
+    cv.B = Bp; cv.x_rows = lazy_norm ? rows : nullptr;   // (xn is in the launch's own row order)
     cv.x = lazy_norm ? cur : xn; cv.x_bstride = lazy_norm ? cur_bs : (long)E * HW;
     if (lazy_norm) { cv.pa = ca; cv.pd = cd; }
     use_w(bw.skw); cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
@@ -1274,7 +1287,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       ma.w = bw.mlp; ma.w1_scale = bw.mlp_s1; ma.w2_scale = bw.mlp_s2; ma.b1 = bw.b1.p; ma.b2 = bw.b2.p;
       ma.out = dst; ma.out_bstride = dst_bs;
       if (lazy_norm) { ma.add = cur; ma.add_bstride = cur_bs; ma.add_a = ca; ma.add_d = cd; }
-      else { ma.add = xn; ma.add_bstride = (long)E * HW; }
+      else { ma.add = xn; ma.add_bstride = (long)E * HW; ma.add_by_launch_row = rows ? 1 : 0; }
       ma.B = Bp; ma.out_rows = rows; ma.E = E; ma.hidden = Hd; ma.HW = HW;
       ma.drop_p = pm; ma.seed = a->seed; ma.call = a->call; ma.stream_fc1 = 2u * i; ma.stream_fc2 = 2u * i + 1u;
       ma.batch_offset = a->batch_offset; ma.rows_per_call = rpc;
@@ -1300,9 +1313,14 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       cv.add = xn; cv.add_bstride = (long)E * HW; cv.add_mode = 2;
       SDY_STAGE(ST_FC2, sdy_conv1x1(&cv, stream));
     }
-    if (nD > 0)   // dropped trajectories: block output = the residual a x + d; their share of the next block's statistics
-      SDY_STAGE_N(ST_DROP_COPY, nD, sdy_affine_copy_stats_launch(cur, cur_bs, ca, cd, dst, dst_bs, stats_next ? st0 : nullptr, E, HW,
-                                                                 dropped, nD, stream));
+    if (nD > 0) {   // dropped trajectories: block output = the residual; their share of the next block's statistics
+      if (lazy_norm)
+        SDY_STAGE_N(ST_DROP_COPY, nD, sdy_affine_copy_stats_launch(cur, cur_bs, ca, cd, dst, dst_bs, stats_next ? st0 : nullptr, E, HW,
+                                                                   perm + Bp, nD, stream));
+      else
+        SDY_STAGE_N(ST_DROP_COPY, nD, sdy_affine_copy_stats_launch(xn, (long)E * HW, nullptr, nullptr, dst, dst_bs,
+                                                                   stats_next ? st0 : nullptr, E, HW, perm + Bp, nD, stream, Bp));
+    }
     if (stats_next) have_st0 = true;
     cur = dst;
     nxt = (dst == xa) ? xb : xa;

@@ -344,8 +344,9 @@ extern "C" int sdy_conv256_h3_pack_cin(const float* w_host, int Cin, void* dev, 
 extern "C" size_t sdy_conv256_h3_pack_bytes_cin(int Cin);
 // dh_h3.hip: fragment-stream pack of the dhconv weight; ilv = channel order of the 2C axis (fft.h)
 int sdy_dh_h3_pack(const float* w_host, int L, void* packed_dev, float* scale, int ilv);
+// B_in (tiled only; 0 = B): the input tensor holds B_in >= B images per order and the first B of them are contracted
 int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B, int ilv,
-                      hipStream_t stream, int tiled = 0);
+                      hipStream_t stream, int tiled = 0, int B_in = 0);
 
 // ---- skinny Legendre GEMM with the table streamed as MFMA fragments (leg_h3.hip), rows and K <= 192
 typedef float (*sdy_leg_value_fn)(void* ctx, int z, int row, int k);

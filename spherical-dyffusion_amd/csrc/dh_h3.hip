@@ -58,6 +58,9 @@ struct DhParams {
   float out_scale;
   unsigned* flags;                 // sticky status word (sdy_status_flags)
   unsigned long long* stamps;      // timing experiments only (SDY_DH_STAMPS)
+  int B_in;                        // images per order of the INPUT tensor (>= B; tiled only): row (m, b) of this launch is input
+                                   // row m B_in + b -- the drop-path skip contracts only the first B of B_in images (capi.hip)
+  unsigned b_magic;                // floor(2^32 / B) + 1: m = umulhi(row, b_magic) for row < 2^16
   int use_table;                   // degree -> XCD from xcd_of (L <= 256), else the boustrophedon formula
   unsigned char xcd_of[256];       // balanced by the host for this (L, mtr, B): longest-processing-time over the degrees' tiles
 };
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
     int rr = r0;
     asm volatile("" : "+v"(rr));   // computed where it is used: 16 hoisted addresses would not fit the register budget
     const int row = it.t * DTN + rr + 8 * i;
-    const int rc = row < dh_rows(p, it.l) ? row : 0;
+    int rc = row < dh_rows(p, it.l) ? row : 0;
+    if (p.B_in != p.B) rc += (int)__umulhi((unsigned)rc, p.b_magic) * (p.B_in - p.B);   // (uniform branch)
     if (p.tiled) return p.X + (unsigned)(((rc * 8 + (oc >> 3)) * p.L + it.l) * 64 + 8 * (oc & 7));
     return p.X + (long)it.l * p.sX + (unsigned)(rc * DK + 8 * oc);
   };
@@ -414,14 +418,17 @@ extern "C" int sdy_dhconv_frag_pack(const float* w_host, int L, void* packed_dev
 }
 
 int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B, int ilv,
-                      hipStream_t stream, int tiled) {
+                      hipStream_t stream, int tiled, int B_in) {
   if (!Cs_in || !packed || !Cs_out || L <= 0 || mtr <= 0 || B <= 0 || !(scale > 0.f)) return SDY_ERR_ARG;
-  if (tiled && (!ilv || (long)mtr * B * 8 * L * 64 >= (1L << 32))) return SDY_ERR_UNSUPPORTED;   // 32-bit element offsets
+  if (B_in <= 0) B_in = B;
+  if (B_in < B || (B_in != B && (!tiled || (long)mtr * B >= 65536))) return SDY_ERR_UNSUPPORTED;
+  if (tiled && (!ilv || (long)mtr * B_in * 8 * L * 64 >= (1L << 32))) return SDY_ERR_UNSUPPORTED;   // 32-bit element offsets
   DhParams p;
   p.X = Cs_in; p.sX = (long)mtr * B * DK;
   p.out = Cs_out; p.sC = (long)mtr * B * DN;
   p.w = reinterpret_cast<const f16x8*>(packed);
   p.L = L; p.mtr = mtr; p.B = B; p.ilv = ilv ? 1 : 0; p.tiled = tiled ? 1 : 0;
+  p.B_in = B_in; p.b_magic = (unsigned)((1ull << 32) / (unsigned)B) + 1u;
   p.out_scale = 1.0f / (scale * DSX);
   SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;
@@ -470,5 +477,5 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
 }
 extern "C" int sdy_dhconv_frag(const float* Cs_in, const void* packed, float scale, float* Cs_out, int L, int mtr, int B,
                                void* stream) {
-  return sdy_dh_h3_launch(Cs_in, packed, scale, Cs_out, L, mtr, B, 0, (hipStream_t)stream, 0);
+  return sdy_dh_h3_launch(Cs_in, packed, scale, Cs_out, L, mtr, B, 0, (hipStream_t)stream, 0, 0);
 }

@@ -74,6 +74,7 @@ struct MlpParams {
   unsigned long long* stamps;              // timing experiments only (SDY_MLP_STAMPS): per-phase s_memtime of one wave
   SdyImgMap omap;                          // drop-path skip (common.h): image z of this launch (x, pa, pd) is batch row omap.idx[z]
                                            // of add / add_a / add_d / out / stats / batch_scale / keep_* and of the dropout stream
+  int add_local;                           // 1: `add` is indexed by the launch's image z like x (sdy_mlp_args.add_by_launch_row)
 };
 
 // 4-bit slot swizzle of pixel row px: injective on each ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   {
     // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested before
     // the epilogue arithmetic, which covers most of their latency
-    const float* az = p.add ? p.add + (long)zo * p.add_bs : p.x + (long)z * p.x_bs;   // uniform
+    const float* az = p.add ? p.add + (long)(p.add_local ? z : zo) * p.add_bs : p.x + (long)z * p.x_bs;   // uniform
 #pragma unroll
     for (int i = 0; i < 16; ++i) rres[i] = sdy_ld16s(az + (long)(16 * i) * p.HW, e_ro);
   }
@@ -921,6 +922,8 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   p.stats = a->stats;
   p.keep_h = a->keep_hidden; p.keep_o = a->keep_out;
   if (a->out_rows && !a->add) return SDY_ERR_ARG;   // (without `add` the residual is x itself: one index for both)
+  if (a->add_by_launch_row && (!a->out_rows || a->add_a)) return SDY_ERR_ARG;
+  p.add_local = a->add_by_launch_row ? 1 : 0;
   SDY_TRY(sdy_img_map_fill(p.omap, a->out_rows, a->B));
   SDY_TRY(sdy_flags_ptr(&p.flags));
   p.stamps = nullptr;

@@ -106,11 +106,12 @@ __global__ __launch_bounds__(256) void affine_copy_stats_kernel(const float* __r
                                                                  const float* __restrict__ a, const float* __restrict__ d,
                                                                  float* __restrict__ out, long out_bs,
                                                                  double* __restrict__ stats, int C, int HW,
-                                                                 const SdyImgMap rows) {
-  const int c = blockIdx.x, b = sdy_img(rows, blockIdx.y);
-  const f32x4* p4 = reinterpret_cast<const f32x4*>(x + (long)b * x_bs + (long)c * HW);
+                                                                 const SdyImgMap rows, int src_row0) {
+  // batch row b of out / a / d / stats; x row: the same, or src_row0 + (index in the list) when the source is in launch order
+  const int c = blockIdx.x, b = sdy_img(rows, blockIdx.y), bs = src_row0 >= 0 ? src_row0 + (int)blockIdx.y : b;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(x + (long)bs * x_bs + (long)c * HW);
   f32x4* o4 = reinterpret_cast<f32x4*>(out + (long)b * out_bs + (long)c * HW);
-  const float av = a[b * C + c], dv = d[b * C + c];
+  const float av = a ? a[b * C + c] : 1.0f, dv = a ? d[b * C + c] : 0.0f;   // (fma(r, 1, 0) == r: the plain copy is exact)
   double s = 0.0, s2 = 0.0;
   const int n4 = HW >> 2;
   for (int i = threadIdx.x; i < n4; i += 256) {
@@ -785,12 +786,14 @@ extern "C" int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, cons
 }
 
 int sdy_affine_copy_stats_launch(const float* x, long x_bs, const float* a, const float* d, float* out, long out_bs,
-                                 double* stats, int C, int HW, const unsigned char* rows, int n_rows, hipStream_t stream) {
-  if (!x || !a || !d || !out || !rows || C <= 0 || HW <= 0 || n_rows <= 0) return SDY_ERR_ARG;
+                                 double* stats, int C, int HW, const unsigned char* rows, int n_rows, hipStream_t stream,
+                                 int src_row0) {
+  if (!x || (a == nullptr) != (d == nullptr) || !out || !rows || C <= 0 || HW <= 0 || n_rows <= 0) return SDY_ERR_ARG;
   if ((HW & 3) || (x_bs & 3) || (out_bs & 3)) return SDY_ERR_ALIGN;
   SdyImgMap m;
   SDY_TRY(sdy_img_map_fill(m, rows, n_rows));
-  hipLaunchKernelGGL(affine_copy_stats_kernel, dim3(C, n_rows), dim3(256), 0, stream, x, x_bs, a, d, out, out_bs, stats, C, HW, m);
+  hipLaunchKernelGGL(affine_copy_stats_kernel, dim3(C, n_rows), dim3(256), 0, stream, x, x_bs, a, d, out, out_bs, stats, C, HW, m,
+                     src_row0);
   return sdy_launch_status();
 }
 

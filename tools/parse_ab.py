@@ -14,6 +14,7 @@ for line in open(sys.argv[1]):
 print({k:round(sum(v)/len(v),2) for k,v in vals.items()})
 base=modes[0]
 for name,d in rows.items():
+    if not d[base] or any(not d[mo] for mo in modes[1:]): continue   # a stage only one side runs (e.g. the drop-path copy)
     c=d[base][0][0]; h=sum(x[1] for x in d[base])/len(d[base])
     out=f"{name:26s} x{c:4d} {base} {h:.4f}"
     for mo in modes[1:]:
