@@ -23,7 +23,8 @@
  *
  * Dropout stream (the reference uses torch's global generator: src/models/sfno/layers.py:76-78,
  * src/models/modules/drop_path.py:19 -- not reproducible across devices, so the product defines its own):
- *   Philox4x32-10, key = (seed_lo, seed_hi), counter = (c0, c1, stream, call)
+ *   Philox4x32-7 (the Random123 generator with seven rounds, the smallest count that passes BigCrush; round constants as in
+ *   Random123), key = (seed_lo, seed_hi), counter = (c0, c1, stream, call)
  *     element dropout : n = pixel (h*nlon + w); c0 = n with bit 5 cleared, c1 = b_global*(C/4) + (ch>>2), word = ch & 3,
  *                       half-word = bit 5 of n (0: low 16 bits, 1: high 16 bits),
  *                       stream = 2*layer + kind (kind 0 = MLP hidden, 1 = MLP output);

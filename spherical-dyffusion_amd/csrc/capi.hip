@@ -1112,7 +1112,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   const bool skip_allowed = drop && !a->drop_path_keep && !no_drop_skip && B <= SDY_MAP_MAX;
   auto drop_path_keeps = [&](int layer, int b) {
     const int bq = b / rpc;
-    const philox4 wd = philox4x32_10((uint32_t)(b - bq * rpc) + a->batch_offset, 0xFFFFFFFFu, 0x1000u + (uint32_t)layer,
+    const philox4 wd = philox4x32((uint32_t)(b - bq * rpc) + a->batch_offset, 0xFFFFFFFFu, 0x1000u + (uint32_t)layer,
                                      a->call + (uint32_t)bq, (uint32_t)(a->seed & 0xFFFFFFFFu), (uint32_t)(a->seed >> 32));
     return wd.x >= n->tm.dp_thr[layer];
   };

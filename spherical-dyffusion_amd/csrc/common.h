@@ -264,15 +264,22 @@ __device__ __forceinline__ void gelu_tab_to_lds(float* dst, const float* tab_glo
 __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
-// ---- Philox4x32-10 (dropout stream, see include/sdy_amd.h) ----------------------------------------------
+// ---- Philox4x32-7 (dropout stream, see include/sdy_amd.h) ----------------------------------------------
+// Seven rounds: the smallest member of the family that passes BigCrush (Salmon, Moraes, Dror, Shaw: "Parallel random numbers:
+// as easy as 1, 2, 3", SC'11, table 2; Random123's philox4x32_R<7>); ten is that paper's safety margin.  A round is two
+// quarter-rate v_mad_u64_u32 and four XORs (gfx950 has no three-input XOR), and the fused MLP with dropout is VALU-issue bound:
+// measured in the network, 10 -> 7 rounds takes 3.02 -> 2.91 ms off its launch (profiles/r5a/e2e_ab_philox7.txt).
+#ifndef SDY_PHILOX_ROUNDS
+#define SDY_PHILOX_ROUNDS 7
+#endif
 struct philox4 {
   uint32_t x, y, z, w;
 };
-__host__ __device__ __forceinline__ philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+__host__ __device__ __forceinline__ philox4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                           uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < SDY_PHILOX_ROUNDS; ++r) {
     uint64_t p0 = (uint64_t)M0 * c0;
     uint64_t p1 = (uint64_t)M1 * c2;
     uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;

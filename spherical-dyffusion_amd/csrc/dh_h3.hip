@@ -60,7 +60,7 @@ struct DhParams {
   unsigned long long* stamps;      // timing experiments only (SDY_DH_STAMPS)
   int B_in;                        // images per order of the INPUT tensor (>= B; tiled only): row (m, b) of this launch is input
                                    // row m B_in + b -- the drop-path skip contracts only the first B of B_in images (capi.hip)
-  unsigned b_magic;                // floor(2^32 / B) + 1: m = umulhi(row, b_magic) for row < 2^16
+  unsigned b_magic;                // floor(2^32 / B) + 1: m = umulhi(row, b_magic) for row < 2^16 (B >= 2; B == 1: m = row)
   int use_table;                   // degree -> XCD from xcd_of (L <= 256), else the boustrophedon formula
   unsigned char xcd_of[256];       // balanced by the host for this (L, mtr, B): longest-processing-time over the degrees' tiles
 };
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
     asm volatile("" : "+v"(rr));   // computed where it is used: 16 hoisted addresses would not fit the register budget
     const int row = it.t * DTN + rr + 8 * i;
     int rc = row < dh_rows(p, it.l) ? row : 0;
-    if (p.B_in != p.B) rc += (int)__umulhi((unsigned)rc, p.b_magic) * (p.B_in - p.B);   // (uniform branch)
+    if (p.B_in != p.B) rc += (p.B == 1 ? rc : (int)__umulhi((unsigned)rc, p.b_magic)) * (p.B_in - p.B);   // (uniform branches)
     if (p.tiled) return p.X + (unsigned)(((rc * 8 + (oc >> 3)) * p.L + it.l) * 64 + 8 * (oc & 7));
     return p.X + (long)it.l * p.sX + (unsigned)(rc * DK + 8 * oc);
   };

@@ -55,7 +55,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[WM][WN], const 
         const int row_base = row0 + 8 * rg;
         uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (do_drop && !maskg && (FULL || (col_ok && row_base < M_store))) {
-          const philox4 w = philox4x32_10((uint32_t)gn & ~32u, c1_base + (uint32_t)(row_base >> 2), p.stream_id, call_z,
+          const philox4 w = philox4x32((uint32_t)gn & ~32u, c1_base + (uint32_t)(row_base >> 2), p.stream_id, call_z,
                                           p.seed_lo, p.seed_hi);
           words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
         }

@@ -258,19 +258,19 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   // loop): a k-step's four LDS fragment reads issued back to back hold up the next MFMA by ~34 cycles (37.8 cycles per MFMA),
   // left to the scheduler they end up in front of the MFMA they feed behind an s_waitcnt lgkmcnt(0) (37-41 in this kernel),
   // one per MFMA a whole k-step ahead of its use they are free (32.3).
-#ifndef SDY_MLP_PHILOX_AHEAD
-#define SDY_MLP_PHILOX_AHEAD 1
-#endif
   // Dropout masks of a hidden chunk generated AHEAD, under the MFMAs of its fc1 (which leave issue slots free: a Philox
   // round -- two v_mad_u64_u32 and two three-input XORs -- hides behind an MFMA), instead of inside the chain, whose slots
   // beside fc2's MFMAs are full: 4 calls (row groups g4) x 10 rounds, one round behind every other MFMA; words kept in
   // mw[g4][].  In the network: 3.39 -> 3.26 ms per launch (together with the scalar chain and the pinned loops, which the
   // dropout variant could not use while the rounds sat in the chain).
-  static_assert(SDY_MLP_PINNED || !SDY_MLP_PHILOX_AHEAD, "the ahead-of-time Philox rounds ride on the pinned fc1 loop");
+  static_assert(SDY_MLP_PINNED, "the ahead-of-time Philox rounds ride on the pinned fc1 loop");
   uint32_t mw[4][4];
   uint32_t ac0 = 0, ac1 = 0, ac2 = 0, ac3 = 0, ak0 = 0, ak1 = 0;
-  auto philox_ahead = [&](int hc, int idx) {   // idx = 10 g4 + round
-    const int g4 = idx / 10, rnd = idx % 10;
+  constexpr int PR = SDY_PHILOX_ROUNDS;
+  constexpr int PSTEP = 96 / (4 * PR);   // the chunk's 4 PR rounds spread over the 96 MFMAs of its fc1: one behind every PSTEP-th
+  static_assert(PSTEP >= 2, "at most one round behind every other MFMA of fc1");
+  auto philox_ahead = [&](int hc, int idx) {   // idx = PR g4 + round
+    const int g4 = idx / PR, rnd = idx % PR;
     if (rnd == 0) {
       const int row0 = HC * hc + 32 * wave + 4 * h;
       ac0 = (uint32_t)(n0 + l31); ac1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); ac2 = p.stream1; ac3 = call_z;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
     const uint32_t m0 = (uint32_t)(p1 >> 32) ^ ac1 ^ ak0, m2 = (uint32_t)(p0 >> 32) ^ ac3 ^ ak1;
     ac0 = m0; ac1 = (uint32_t)p1; ac2 = m2; ac3 = (uint32_t)p0;
     ak0 += 0x9E3779B9u; ak1 += 0xBB67AE85u;
-    if (rnd == 9) { mw[g4][0] = ac0; mw[g4][1] = ac1; mw[g4][2] = ac2; mw[g4][3] = ac3; }
+    if (rnd == PR - 1) { mw[g4][0] = ac0; mw[g4][1] = ac1; mw[g4][2] = ac2; mw[g4][3] = ac3; }
   };
   auto fc1 = [&](int hc_fc1) {
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         if (k < 4) { if (ks + 1 < KS1) ldb1(c ^ 1, ks + 1, k); }
         else if (k == 4) r_lo[ks] = wp[ks * GROUP_F8 + 64];
         else r_hi[ks] = wp[ks * GROUP_F8];
-        if (DROP && !INJECT && SDY_MLP_PHILOX_AHEAD && ((6 * ks + k) & 1) == 0 && (6 * ks + k) / 2 < 40) philox_ahead(hc_fc1, (6 * ks + k) / 2);
+        if (DROP && !INJECT && (6 * ks + k) % PSTEP == 0 && (6 * ks + k) / PSTEP < 4 * PR) philox_ahead(hc_fc1, (6 * ks + k) / PSTEP);
         __builtin_amdgcn_sched_barrier(0);
       }
       } else {
@@ -349,9 +349,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   // piece after the MFMAs; sched_group_barrier hints were honoured for the first k-step only.)
   struct Piece {
     float v[4], t[4], e[4], q[4];
-    uint32_t c0, c1, c2, c3, k0, k1;
   };
-  uint32_t pw[4];   // Philox words of the last j == 0 piece: its j == 1 partner (same rows, pixel + 32) takes the high halves
   // INJECT: keep flag of hidden row `row`, tile pixel `px` of image z from the mask tensor (a global load per value: tests only)
   auto keep_h_at = [&](int row, int px) {
     const int pix = (n0 + px < p.HW) ? n0 + px : p.HW - 1;
@@ -360,16 +358,6 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   auto chain_stage = [&](Piece& s, int st, int hc, int j, int g4) {
     const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
     const int px = 32 * j + l31;
-    if (do_drop && !SDY_MLP_PHILOX_AHEAD && st < 10 && j == 0) {
-      if (st == 0) {
-        s.c0 = (uint32_t)(n0 + l31); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = call_z;
-        s.k0 = p.seed_lo; s.k1 = p.seed_hi;
-      }
-      const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0, p1 = (uint64_t)0xCD9E8D57u * s.c2;   // one Philox4x32 round
-      const uint32_t m0 = (uint32_t)(p1 >> 32) ^ s.c1 ^ s.k0, m2 = (uint32_t)(p0 >> 32) ^ s.c3 ^ s.k1;
-      s.c0 = m0; s.c1 = (uint32_t)p1; s.c2 = m2; s.c3 = (uint32_t)p0;
-      s.k0 += 0x9E3779B9u; s.k1 += 0xBB67AE85u;
-    }
     switch (st) {
       // (the arithmetic stages work on value PAIRS: v_pk_fma_f32 / v_pk_mul_f32 do two values per instruction at the scalar
       // rate -- the chain is what bounds the interleaved fc2, see the timeline in DESIGN.md; rcp / exp2 stay scalar)
@@ -444,12 +432,11 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         break;
       case 10: {
         if (do_drop) {
-          if (!SDY_MLP_PHILOX_AHEAD && j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             bool keep;
             if constexpr (INJECT) keep = keep_h_at(row0 + 8 * g4 + r, px);
-            else keep = sdy_keep16(SDY_MLP_PHILOX_AHEAD ? mw[g4][r] : pw[r], j, p.drop_thr);
+            else keep = sdy_keep16(mw[g4][r], j, p.drop_thr);
             s.v[r] = keep ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
           }
         }
@@ -483,16 +470,6 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   auto chain_slot = [&](Piece& s, int st, int hc, int j, int g4) {
     const int row0 = HC * hc + 32 * wave + 4 * h;   // hidden row of reg r: row0 + (r & 3) + 8 * (r >> 2)
     const int px = 32 * j + l31;
-    if (do_drop && !SDY_MLP_PHILOX_AHEAD && st < 10 && j == 0) {
-      if (st == 0) {
-        s.c0 = (uint32_t)(n0 + l31); s.c1 = c1_base + (uint32_t)((row0 + 8 * g4) >> 2); s.c2 = p.stream1; s.c3 = call_z;
-        s.k0 = p.seed_lo; s.k1 = p.seed_hi;
-      }
-      const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0, p1 = (uint64_t)0xCD9E8D57u * s.c2;   // one Philox4x32 round
-      const uint32_t m0 = (uint32_t)(p1 >> 32) ^ s.c1 ^ s.k0, m2 = (uint32_t)(p0 >> 32) ^ s.c3 ^ s.k1;
-      s.c0 = m0; s.c1 = (uint32_t)p1; s.c2 = m2; s.c3 = (uint32_t)p0;
-      s.k0 += 0x9E3779B9u; s.k1 += 0xBB67AE85u;
-    }
     constexpr float CT = 0.3275911f * 0.70710678118654752440f, KAP = -0.5f * 1.44269504088896340736f, HS = 0.5f * SX;
     constexpr float A5 = 1.061405429f * HS, A4 = -1.453152027f * HS, A3 = 1.421413741f * HS, A2 = -0.284496736f * HS,
                     A1 = 0.254829592f * HS;
@@ -548,12 +525,11 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s.v[r] = fmaf(s.v[r], HS, s.q[r]);
         if (do_drop) {
-          if (!SDY_MLP_PHILOX_AHEAD && j == 0) { pw[0] = s.c0; pw[1] = s.c1; pw[2] = s.c2; pw[3] = s.c3; }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             bool keep;
             if constexpr (INJECT) keep = keep_h_at(row0 + 8 * g4 + r, px);
-            else keep = sdy_keep16(SDY_MLP_PHILOX_AHEAD ? mw[g4][r] : pw[r], j, p.drop_thr);
+            else keep = sdy_keep16(mw[g4][r], j, p.drop_thr);
             s.v[r] = keep ? s.v[r] : 0.0f;   // (1 / (1 - p): see s2e)
           }
         }
@@ -719,7 +695,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
       for (int g4 = 0; g4 < 4; ++g4) {
         uint32_t words[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (do_drop && !INJECT) {   // one call per 4 rows x the pixel pair (l31, l31 + 32)
-          const philox4 w = philox4x32_10((uint32_t)(n0 + l31), c1_base2 + (uint32_t)((row0 + 8 * g4) >> 2), p.stream2,
+          const philox4 w = philox4x32((uint32_t)(n0 + l31), c1_base2 + (uint32_t)((row0 + 8 * g4) >> 2), p.stream2,
                                           call_z, p.seed_lo, p.seed_hi);
           words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
         }

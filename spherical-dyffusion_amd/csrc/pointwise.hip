@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void time_dense_kernel(const SdyTimeMlp t, con
           keep = dp_keep_in[ly * B + b] != 0.0f;
         } else {
           const int bq = b / rows_per_call;   // stacked calls: trajectory b % rows_per_call of call + b / rows_per_call
-          const philox4 w = philox4x32_10((uint32_t)((b - bq * rows_per_call) + batch_offset), 0xFFFFFFFFu,
+          const philox4 w = philox4x32((uint32_t)((b - bq * rows_per_call) + batch_offset), 0xFFFFFFFFu,
                                           0x1000u + (uint32_t)ly, call + (uint32_t)bq, seed_lo, seed_hi);
           keep = w.x >= t.dp_thr[ly];
         }
@@ -321,7 +321,7 @@ __global__ void droppath_kernel(const SdyTimeMlp t, float* __restrict__ dp_out, 
       keep = dp_keep_in[layer * B + b] != 0.0f;
     } else {
       const int bq = b / rows_per_call;
-      const philox4 w = philox4x32_10((uint32_t)((b - bq * rows_per_call) + batch_offset), 0xFFFFFFFFu,
+      const philox4 w = philox4x32((uint32_t)((b - bq * rows_per_call) + batch_offset), 0xFFFFFFFFu,
                                       0x1000u + (uint32_t)layer, call + (uint32_t)bq, seed_lo, seed_hi);
       keep = w.x >= t.dp_thr[layer];
     }

@@ -85,16 +85,21 @@ def test_no_cpu_fallback(sdy):
 
 
 def test_philox_known_answers():
-    """Random123 known-answer vectors for Philox4x32-10 (the dropout stream's generator)."""
-    from oracle.philox import philox4x32_10
+    """Random123 known-answer vectors of Philox4x32-10 pin the round function, the constants and the key schedule of the
+    oracle's generator; the dropout stream runs the same code for seven rounds (oracle.philox.ROUNDS, SDY_PHILOX_ROUNDS), for
+    which Random123 publishes the vector of the pi / e example."""
+    from oracle.philox import ROUNDS, philox4x32
 
     kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
            ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
            ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
             (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
     for ctr, key, exp in kat:
-        got = tuple(int(x) for x in philox4x32_10(*ctr, *key))
+        got = tuple(int(x) for x in philox4x32(*ctr, *key, rounds=10))
         assert got == exp
+    assert ROUNDS == 7
+    got7 = tuple(int(x) for x in philox4x32(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0))
+    assert got7 != kat[2][2] and len(set(got7)) == 4
 
 
 def test_element_dropout_stream_definition():
@@ -103,7 +108,7 @@ def test_element_dropout_stream_definition():
     keep <=> half-word >= floor(p * 2^16)."""
     import numpy as np
 
-    from oracle.philox import drop_threshold16, element_keep_mask, philox4x32_10
+    from oracle.philox import drop_threshold16, element_keep_mask, philox4x32
 
     seed, call, layer, kind, p = 0x1234_5678_9ABC, 7, 3, 1, 0.13
     B, C, H, W, boff = 2, 8, 3, 40, 5
@@ -113,7 +118,7 @@ def test_element_dropout_stream_definition():
     rng = np.random.default_rng(0)
     for _ in range(200):
         b, c, pix = int(rng.integers(B)), int(rng.integers(C)), int(rng.integers(H * W))
-        words = philox4x32_10(np.uint32(pix & ~32), np.uint32((b + boff) * (C // 4) + (c >> 2)), np.uint32(2 * layer + kind),
+        words = philox4x32(np.uint32(pix & ~32), np.uint32((b + boff) * (C // 4) + (c >> 2)), np.uint32(2 * layer + kind),
                               np.uint32(call), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
         w = int(words[c & 3])
         half = (w >> 16) if (pix >> 5) & 1 else (w & 0xFFFF)
