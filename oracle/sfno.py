@@ -85,7 +85,7 @@ MaskFn = Callable[[str, int, tuple], Optional[torch.Tensor]]
 def sinusoidal_pos_emb(t: torch.Tensor, dim: int) -> torch.Tensor:
     half = dim // 2
     emb = math.log(10000) / (half - 1)
-    emb = torch.exp(torch.arange(half, dtype=t.dtype) * -emb)
+    emb = torch.exp(torch.arange(half, dtype=t.dtype, device=t.device) * -emb)
     emb = t[:, None] * emb[None, :]
     return torch.cat((emb.sin(), emb.cos()), dim=-1)
 
@@ -93,26 +93,32 @@ def sinusoidal_pos_emb(t: torch.Tensor, dim: int) -> torch.Tensor:
 class OracleSFNO:
     """Functional restatement; `sd` maps reference state_dict names to CPU fp32 tensors."""
 
-    def __init__(self, cfg: SFNOConfig, sd: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float32):
+    def __init__(self, cfg: SFNOConfig, sd: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float32, device="cpu"):
         """`dtype=torch.float64`: the same op sequence in double precision -- the yardstick that tells how much of a
         difference between two fp32 implementations is either one's rounding (tools/chain_error_probe.py); the reference,
-        and every parity test, run fp32."""
+        and every parity test, run fp32.
+        `device`: where torch evaluates the op sequence.  "cpu" is the oracle of every parity test; "cuda" runs the SAME torch
+        ops on the GPU (as the reference itself does in production) -- only the float64 yardstick of the chain-error test uses
+        it, where sixteen chained full-depth forwards in double precision take minutes on the host cores."""
         self.cfg = cfg
         self.dtype = dtype
-        self.sd = {k: v.detach().to(dtype).cpu() for k, v in sd.items()}
+        self.device = torch.device(device)
+        self.sd = {k: v.detach().to(device=self.device, dtype=dtype) for k, v in sd.items()}
         c = cfg
         kw = dict(lmax=c.modes_lat, mmax=c.modes_lon)
         self.trans_down = RealSHT(c.nlat, c.nlon, grid=c.data_grid, **kw).to(dtype)
         self.itrans_up = InverseRealSHT(c.nlat, c.nlon, grid=c.data_grid, **kw).to(dtype)
         self.trans = RealSHT(c.h, c.w, grid="legendre-gauss", **kw).to(dtype)
         self.itrans = InverseRealSHT(c.h, c.w, grid="legendre-gauss", **kw).to(dtype)
+        for m in (self.trans_down, self.itrans_up, self.trans, self.itrans):
+            m.to(self.device)
 
     # ---- pieces ---------------------------------------------------------------------------
     def time_repr(self, time: torch.Tensor) -> torch.Tensor:
         sd, c = self.sd, self.cfg
         if c.min_time is not None:
             assert (c.min_time <= time).all() and (time <= c.max_time).all(), f"time out of range: {time}"
-        e = sinusoidal_pos_emb(time.to(self.dtype), c.embed_dim)
+        e = sinusoidal_pos_emb(time.to(device=self.device, dtype=self.dtype), c.embed_dim)
         h = F.linear(e, sd["time_emb_mlp.1.weight"], sd["time_emb_mlp.1.bias"])
         h = F.gelu(h)
         return F.linear(h, sd["time_emb_mlp.3.weight"], sd["time_emb_mlp.3.bias"])
@@ -154,24 +160,24 @@ class OracleSFNO:
         if mask_fn is not None and pm > 0.0:
             m = mask_fn("mlp_hidden", i, tuple(h.shape))
             if m is not None:
-                h = h * m * (1.0 / (1.0 - pm))
+                h = h * m.to(h.device) * (1.0 / (1.0 - pm))
         k2 = p + c.mlp_fc2_key
         h = F.conv2d(h, sd[k2 + ".weight"], sd[k2 + ".bias"])
         if mask_fn is not None and pm > 0.0:
             m = mask_fn("mlp_out", i, tuple(h.shape))
             if m is not None:
-                h = h * m * (1.0 / (1.0 - pm))
+                h = h * m.to(h.device) * (1.0 / (1.0 - pm))
         dp = c.drop_path_rates[i]
         if mask_fn is not None and dp > 0.0:
             m = mask_fn("drop_path", i, (h.shape[0], 1, 1, 1))
             if m is not None:
-                h = h.div(1.0 - dp) * m
+                h = h.div(1.0 - dp) * m.to(h.device)
         return h + residual
 
     # ---- full network ---------------------------------------------------------------------
     def forward(self, inputs, time=None, condition=None, static_condition=None, mask_fn: Optional[MaskFn] = None):
         c, sd = self.cfg, self.sd
-        parts = [t.to(self.dtype) for t in (inputs, condition, static_condition) if t is not None]
+        parts = [t.to(device=self.device, dtype=self.dtype) for t in (inputs, condition, static_condition) if t is not None]
         x = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
         assert x.shape[1] == c.in_chans, f"expected {c.in_chans} channels, got {x.shape[1]}"
         residual = x
