@@ -330,6 +330,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(32, host CPUs))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the stage profile, B=1 latencies and the weak leg")
+    ap.add_argument("--no-relay", action="store_true",
+                    help="strong scaling with the static split only (25 over 8 = 4,3,3,...), no relayed remainder members")
+    ap.add_argument("--digests", action="store_true", help="add (sum, norm) of every trajectory's final state to the JSON line")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: all ranks on GPU 0 with the gloo backend (exercises the N>1 path on a 1-GPU box; "
                          "the numbers mean nothing)")
@@ -374,6 +377,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    digests = {}
+
+    def digest(first_unit, x):
+        """(sum, L2 norm) in float64 of every trajectory's final state: what `--digests` prints, so that runs with different
+        world sizes / schedules can be compared trajectory by trajectory (tests/test_gpu_fullsize.py)."""
+        for r in range(x.shape[0]):
+            v = x[r].double()
+            digests[first_unit + r] = [float(v.sum()), float(v.norm())]
+
     def timed_leg(ic_index, first_unit, B):
         """W warm-up + K timed sampling passes of this rank's B trajectories; returns the max-over-ranks seconds."""
         exp.set_batch_offset(first_unit)
@@ -395,20 +407,102 @@ def main():
             dt = float(tt.item())
         if B > 0:
             assert torch.isfinite(x).all(), "non-finite state after the rollout"
+            if ic_index == 0 and args.scaling == "strong":
+                digest(first_unit, x)
+        return dt
+
+    def relay_leg(M):
+        """Strong scaling with the remainder members RELAYED (ensemble.relay_plan): every rank keeps M // world resident
+        members; the M % world others advance as batches of one, each rank hosting a slice of the timed windows and handing
+        the state to the next (torch.distributed send / recv: the only data-path message, 16 MB per hand-over).  Every pass
+        sets the trajectory offset and the dropout call counters of its (trajectory, window), so the samples are those of
+        the one-GPU job."""
+        plan = ensemble.relay_plan(M, world, args.steps, rank)
+        q = plan.count
+        x1, forc1 = synthetic_state(0, 1, device)
+        xr, forc_r = synthetic_state(0, q, device) if q else (None, None)
+        c0 = exp.dropout_calls()
+        one_pass(exp, x1, forc1)                       # B = 1 warm-up (workspace, kernels); also: calls per pass
+        per_pass = tuple(b - a for a, b in zip(c0, exp.dropout_calls()))
+
+        def run(x, forc, first_unit, w_abs):
+            exp.set_batch_offset(first_unit)
+            exp.set_dropout_calls((per_pass[0] * w_abs, per_pass[1] * w_abs))
+            return one_pass(exp, x, forc)
+
+        for w in range(args.warmup):
+            if q:
+                xr = run(xr, forc_r, plan.start, w)
+        if world > 1:                                  # the ring the hand-overs use: connections are set up outside the timed region
+            ping = torch.zeros(8, device=red_dev)
+            req = dist.isend(ping, dst=(rank + 1) % world)
+            dist.recv(torch.empty_like(ping), src=(rank - 1) % world)
+            req.wait()
+        sends = []
+        state = {"res": xr}
+
+        def resident_step(w):
+            state["res"] = run(state["res"], forc_r, plan.start, args.warmup + w)
+
+        def relay_step(task, w, x):
+            return run(x, forc1, task.unit, args.warmup + w)
+
+        def initial_state(unit):
+            x = x1.clone()
+            for w in range(args.warmup):               # (a relay trajectory's warm-up windows: untimed, on its first host)
+                x = run(x, forc1, unit, w)
+            return x
+
+        def recv(task):
+            buf = torch.empty(x1.shape, dtype=x1.dtype, device=red_dev)
+            dist.recv(buf, src=task.src)
+            return buf.to(device)
+
+        def send(task, x):
+            t = x.to(red_dev).contiguous()
+            sends.append((dist.isend(t, dst=task.dst), t))
+
+        firsts = {t.unit: initial_state(t.unit) for t in plan.tasks if t.src is None}
+        barrier()
+        t0 = time.perf_counter()
+        finals = ensemble.run_relay(plan, args.steps, resident_step, relay_step, lambda u: firsts[u], recv, send)
+        for req, _ in sends:
+            req.wait()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        if q:
+            assert torch.isfinite(state["res"]).all(), "non-finite state after the rollout"
+            digest(plan.start, state["res"])
+        for u, x in finals.items():
+            assert torch.isfinite(x).all(), "non-finite relay state after the rollout"
+            digest(u, x)
         return dt
 
     M = args.members
     parts = ensemble.partition(M, world)                   # strong: members of ONE initial condition over the ranks
+    relay = world > 1 and M % world != 0 and M >= world and not args.no_relay
     legs = {}
     if args.scaling == "strong":
         start, cnt = parts[rank]
-        legs["strong"] = (timed_leg(0, start, cnt), M)
+        legs["strong"] = (relay_leg(M) if relay else timed_leg(0, start, cnt), M)
         if world > 1 and not args.no_extras:
             legs["weak"] = (timed_leg(rank, rank * M, M), world * M)
     else:
         legs["weak"] = (timed_leg(rank, rank * M, M), world * M)
     dt, n_traj = legs[args.scaling]
     value = n_traj * HORIZON * args.steps / dt
+    all_digests = None
+    if args.digests:
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, digests)
+            all_digests = {str(k): v for d in gathered for k, v in d.items()}
+        else:
+            all_digests = {str(k): v for k, v in digests.items()}
 
     if rank == 0:
         B0 = parts[0][1] if args.scaling == "strong" else M
@@ -433,12 +527,17 @@ def main():
                             "forwards, dropout stream on, AR feedback), 180x360, %d state + %d forcing channels, embed 256, "
                             "8 blocks" % (M, STATE_CH, FORCING_CH),
                 "horizon": HORIZON, "forwards_per_step": 16,
-                "members_per_gpu": [c for _, c in parts] if args.scaling == "strong" else [M] * world,
+                "members_per_gpu": ([M // world] * world if relay else [c for _, c in parts]) if args.scaling == "strong"
+                else [M] * world,
+                "relayed_members": (M % world) if (relay and args.scaling == "strong") else 0,
                 "forecast_steps_per_step": n_traj * HORIZON,
                 "per_gpu_forecast_steps_per_s": round(value / world, 3),
                 "ensemble_steps_per_s": round(value / n_traj, 4),
                 "parallelism": ("members of one initial condition sharded over GPUs" if args.scaling == "strong" else
-                                "one initial condition (x %d members) per GPU" % M) + ", no data-path collective",
+                                "one initial condition (x %d members) per GPU" % M) +
+                               (", the %d remainder member(s) relayed between GPUs in time slices as batches of one (one 16 MB "
+                                "send / recv per hand-over; no collective)" % (M % world) if relay and args.scaling == "strong"
+                                else ", no data-path collective"),
             },
         }
         if "weak" in legs and args.scaling == "strong":
@@ -450,18 +549,35 @@ def main():
         res["c5_extrapolation"] = {"trajectories": 100, "steps": 14600, "measured_steps": HORIZON * args.steps,
                                    "hours_at_this_rate": round(100 * 14600 / value / 3600.0, 2), "n_gpus": world,
                                    "note": "extrapolated from the measured rate; run --steps >= 100 for a 600-step sample"}
+        if all_digests is not None:
+            res["trajectory_digests"] = dict(sorted(all_digests.items(), key=lambda kv: int(kv[0])))
+
+        def extra(key, fn):
+            """An optional measurement must not cost the headline: its failure is recorded under its key."""
+            try:
+                res[key] = fn()
+            except Exception as e:      # noqa: BLE001
+                res[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+
         if not args.no_extras:
-            x, forc = synthetic_state(0, B0, device)
-            exp.set_batch_offset(0)
-            rows, total = profile_pass(exp, x, forc, B0)
-            res["roofline"] = roofline_from(rows, total, B0, h3)
+            def roof():
+                x, forc = synthetic_state(0, B0, device)
+                exp.set_batch_offset(0)
+                rows, total = profile_pass(exp, x, forc, B0)
+                return roofline_from(rows, total, B0, h3)
+
+            extra("roofline", roof)
             if world == 1:
-                res["latency"] = latency_b1(exp, device)
-                del x, forc
-                res["f32_fallback"] = f32_fallback(device, B0)
-                res["f32_fallback"]["slowdown_vs_h3"] = round(value / res["f32_fallback"]["value"], 2)
+                extra("latency", lambda: latency_b1(exp, device))
+
+                def f32():
+                    r = f32_fallback(device, B0)
+                    r["slowdown_vs_h3"] = round(value / r["value"], 2)
+                    return r
+
+                extra("f32_fallback", f32)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_threads or min(32, os.cpu_count() or 1))
+            extra("cpu_baseline", lambda: cpu_baseline(args.cpu_threads or min(32, os.cpu_count() or 1)))
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

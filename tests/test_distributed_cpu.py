@@ -174,3 +174,108 @@ def test_time_mean_maps_weigh_ranks_by_their_rows():
     tm = torch.randn(2, 5, 4, 8, generator=g)
     naive = 0.5 * (tm[:, :3].mean(dim=(0, 1)) + tm[:, 3:].mean(dim=(0, 1)))
     assert not torch.allclose(naive, tm.mean(dim=(0, 1)), rtol=1e-3, atol=1e-3)
+
+
+def _advance(x, unit, w):
+    """Stand-in for one window of one trajectory (the network needs a GPU): a deterministic, order-sensitive update keyed
+    by (global trajectory, window) -- any mix-up of states, owners or windows changes the result."""
+    return x * 1.0001 + torch.sin(torch.arange(4, dtype=torch.float64) + 7.0 * unit + 0.37 * w) * (1.0 + x.abs().sum())
+
+
+def _relay_worker(rank, world, port, n_units, n_windows, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sdy_amd import ensemble
+
+    plan = ensemble.relay_plan(n_units, world, n_windows, rank)
+    res = {u: torch.full((4,), float(u), dtype=torch.float64) for u in range(plan.start, plan.start + plan.count)}
+    log, sends = [], []
+
+    def resident_step(w):
+        for u in res:
+            res[u] = _advance(res[u], u, w)
+        log.append(("res", w))
+
+    def relay_step(task, w, x):
+        log.append(("relay", task.unit, w))
+        return _advance(x, task.unit, w)
+
+    def recv(task):
+        buf = torch.empty(4, dtype=torch.float64)
+        dist.recv(buf, src=task.src)
+        return buf
+
+    def send(task, x):
+        sends.append((dist.isend(x.clone(), dst=task.dst), x))
+
+    finals = ensemble.run_relay(plan, n_windows, resident_step, relay_step,
+                                lambda u: torch.full((4,), float(u), dtype=torch.float64), recv, send)
+    for req, _ in sends:
+        req.wait()
+    out = dict(res)
+    out.update(finals)
+    ret[rank] = (plan, out, log)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _serial(n_units, n_windows):
+    out = {}
+    for u in range(n_units):
+        x = torch.full((4,), float(u), dtype=torch.float64)
+        for w in range(n_windows):
+            x = _advance(x, u, w)
+        out[u] = x
+    return out
+
+
+def test_relayed_remainder_trajectories_equal_the_unsharded_run():
+    """ensemble.relay_plan / run_relay: 5 trajectories over 2 ranks = 2 resident each + ONE relayed in two time slices (the
+    25-over-8 case in miniature: 3 resident each + one relayed through 8 slices); 7 over 3 = 2 each + one relayed; with real
+    send / recv between the ranks (gloo).  Every trajectory's final state equals the serial run bit for bit, every
+    (trajectory, window) is advanced exactly once, and the work is even."""
+    for world, n_units, n_windows in ((2, 5, 6), (3, 7, 7), (3, 8, 5)):
+        port = _free_port()
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_relay_worker, args=(world, port, n_units, n_windows, ret), nprocs=world, join=True)
+        want = _serial(n_units, n_windows)
+        got, seen, load = {}, [], []
+        for r in range(world):
+            plan, out, log = ret[r]
+            assert plan.count == n_units // world
+            got.update(out)
+            seen += [(u, w) for kind, *rest in log if kind == "res" for w in rest for u in range(plan.start, plan.start + plan.count)]
+            seen += [(rest[0], rest[1]) for kind, *rest in log if kind == "relay"]
+            load.append(plan.count * n_windows + sum(t.w_end - t.w_begin for t in plan.tasks))
+        assert sorted(got) == list(range(n_units))
+        for u in range(n_units):
+            assert torch.equal(got[u], want[u]), (world, n_units, u)
+        assert sorted(seen) == [(u, w) for u in range(n_units) for w in range(n_windows)]
+        assert max(load) - min(load) <= (n_units % world) * (-(-n_windows // world)), load
+
+
+def test_relay_plan_of_the_headline_job():
+    """25 members over 8 GPUs, 20 windows: 3 resident members per rank, member 24 relayed through all eight ranks in slices of
+    2-3 windows; every rank carries 62-63 member-windows instead of 80 on the rank a static 4,3,3,... split overloads."""
+    from sdy_amd import ensemble
+
+    plans = [ensemble.relay_plan(25, 8, 20, r) for r in range(8)]
+    assert [(p.start, p.count) for p in plans] == [(3 * r, 3) for r in range(8)]
+    tasks = [t for p in plans for t in p.tasks]
+    assert all(t.unit == 24 for t in tasks) and len(tasks) == 8
+    chain = sorted(tasks, key=lambda t: t.w_begin)
+    assert chain[0].src is None and chain[-1].dst is None and chain[0].w_begin == 0 and chain[-1].w_end == 20
+    for a, b in zip(chain, chain[1:]):
+        assert a.w_end == b.w_begin
+    hosts = [r for t in chain for r in range(8) if t in plans[r].tasks]
+    assert hosts == list(range(8))
+    for a, b, h in zip(chain, chain[1:], hosts):
+        assert a.dst == h + 1 and b.src == h
+    load = [p.count * 20 + sum(t.w_end - t.w_begin for t in p.tasks) for p in plans]
+    assert sum(load) == 25 * 20 and max(load) <= 63
+    # divisible jobs and jobs with fewer trajectories than ranks fall back to the static split
+    assert ensemble.relay_plan(24, 8, 20, 3) == ensemble.RelayPlan(9, 3, ())
+    assert [ensemble.relay_plan(5, 8, 20, r).count for r in range(8)] == [1, 1, 1, 1, 1, 0, 0, 0]

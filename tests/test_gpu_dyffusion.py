@@ -641,3 +641,63 @@ def test_interpolator_pair_with_shared_encoder_equals_two_full_forwards(hack):
                                       with_time_emb=False), 4, 0)
     with pytest.raises(sdy_amd.SdyError):
         net2(torch.zeros(1, 4, 32, 64).cuda(), reuse_encoder=True)
+
+
+def test_relayed_remainder_member_equals_the_unsharded_ensemble():
+    """ensemble.relay_plan / run_relay with the REAL sampler (dropout and drop path on): 7 members x 6 windows as one batch of
+    seven, and as three ranks' plans -- two resident members each and member 6 relayed through the ranks in slices of two
+    windows, every pass keyed by (global trajectory, window) through set_batch_offset / set_dropout_calls (what bench.py's
+    strong-scaling leg does on N GPUs).  The ranks are played one after the other in this process with a mailbox for the
+    hand-overs (the host order of a single relay trajectory is the rank order, so nothing waits); the transport itself is
+    covered with real send / recv by tests/test_distributed_cpu.py.  Every trajectory must equal its row of the batch of
+    seven at every window (2e-5: the InstanceNorm sums are accumulated in an order that depends on the batch)."""
+    from sdy_amd import ensemble
+
+    exp, _, cs, n_forc = _build(hack=False, dropout=True)
+    g = torch.Generator(device="cpu").manual_seed(99)
+    n_units, n_windows, world = 7, 6, 3
+    x0 = torch.randn(1, cs, 32, 64, generator=g).expand(n_units, -1, -1, -1).contiguous().cuda()
+    forc = torch.randn(1, n_forc, 32, 64, generator=g).cuda()
+
+    def one_pass(x, first_unit, w):
+        exp.set_batch_offset(first_unit)
+        exp.set_dropout_calls((6 * w, 10 * w))
+        out = None
+        for h in range(1, 7):
+            batch = {"dynamics": x, "static_condition": forc.expand(x.shape[0], -1, -1, -1).contiguous()}
+            with exp.ema_scope(), exp.inference_dropout_scope():
+                out = exp.get_preds_at_t_for_batch(batch, horizon=h, split="predict", is_autoregressive=False,
+                                                   prepare_inputs=False, ensemble=False, num_predictions=1)
+        assert exp.dropout_calls() == (6 * (w + 1), 10 * (w + 1))
+        return out["t6_preds_normed"]
+
+    full, x = [], x0
+    for w in range(n_windows):
+        x = one_pass(x, 0, w)
+        full.append(x.clone())
+    assert float((full[-1][0] - full[-1][1]).abs().max()) > 1e-3          # members are different samples
+
+    mailbox, seen = {}, {}
+    for rank in range(world):
+        plan = ensemble.relay_plan(n_units, world, n_windows, rank)
+        assert plan.count == 2 and len(plan.tasks) == 1 and plan.tasks[0].unit == 6
+        state = {"res": x0[plan.start:plan.start + plan.count].clone()}
+
+        def resident_step(w):
+            state["res"] = one_pass(state["res"], plan.start, w)
+            for r in range(plan.count):
+                seen[(plan.start + r, w)] = state["res"][r:r + 1].clone()
+
+        def relay_step(task, w, xs):
+            xs = one_pass(xs, task.unit, w)
+            seen[(task.unit, w)] = xs.clone()
+            return xs
+
+        finals = ensemble.run_relay(plan, n_windows, resident_step, relay_step, lambda u: x0[u:u + 1].clone(),
+                                    lambda task: mailbox.pop((task.src, rank, task.unit)),
+                                    lambda task, xs: mailbox.__setitem__((rank, task.dst, task.unit), xs.clone()))
+        assert (rank == world - 1) == (6 in finals)
+    assert not mailbox and sorted(seen) == [(u, w) for u in range(n_units) for w in range(n_windows)]
+    for (u, w), v in seen.items():
+        e = rel_l2(v[0], full[w][u])
+        assert e < 2e-5 * (4 ** w), f"trajectory {u}, window {w}: rel L2 {e:.3e}"
