@@ -297,7 +297,7 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
     def run(*extra):
-        cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--members", "5",
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "0", "--members", "5",
                "--no-cpu-baseline", "--no-extras", "--digests", *extra]
         p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
@@ -324,6 +324,28 @@ def test_bench_two_ranks_as_the_driver_launches_it():
             assert abs(n2 - n1) <= 2.5e-3 * n1, (u, n1, n2)
     norms = sorted(v[1] for v in one["trajectory_digests"].values())
     assert min(b - a for a, b in zip(norms, norms[1:])) > 5e-3 * norms[0], norms
+
+
+def test_rccl_path_when_two_devices_are_visible():
+    """`bench.py --gpus 2` over RCCL proper (init_process_group("nccl"), barriers, the max-over-ranks all_reduce and the relay's
+    send / recv between two GPUs).  The GPU boxes of the development pool have ONE device, where two ranks cannot share a
+    communicator (RCCL refuses duplicate devices) and the N > 1 path runs over gloo (`--share-gpu`, above); this test runs
+    wherever at least two devices are visible, so that the first multi-GPU run of a round is not the first RCCL run."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device: RCCL needs a device per rank")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--members", "5",
+           "--no-cpu-baseline", "--no-extras", "--digests"]
+    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["relayed_members"] == 1 and len(res["trajectory_digests"]) == 5
+    assert "TEST MODE" not in res["data"]
 
 
 def test_c4_rollout_two_ranks_shared_gpu():
