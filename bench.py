@@ -50,10 +50,6 @@ HIDDEN = 2 * EMBED
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: BF16/FP16 MFMA dense peak
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E peak (6.3 TB/s measured with a float4 copy)
-# HBM bytes per launch of the dominant kernel at B = 25 from separate rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
-# the guide's gfx950 correction); source file under profiles/
-MLP_TRAFFIC_B25 = 5.265e9      # mlp_h3_kernel<true> inside the interpolator forward: fetch 3.604 GB + write 1.661 GB
-MLP_TRAFFIC_SRC = "profiles/r4e/pmc_summary.txt"   # (r4f, another box at the last commit of the round: 5.283e9)
 POLAR_LIVE = 0.77              # share of (order, latitude) pairs the polar cut-off keeps
 NZ_PAIRS, ALL_PAIRS = 16290, 32580   # (l, m) pairs with m <= l / dense
 
@@ -130,6 +126,23 @@ def synthetic_state(ic_index, B, device):
 
 
 # ---- roofline ------------------------------------------------------------------------------------------------------------
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel, `mlp_h3_kernel<true>` at 25 rows, from the NEWEST counter summary under
+    profiles/ (profiles/<round>/pmc_summary.txt: separate rocprofv3 --pmc passes over an interpolator forward with every launch
+    at 25 rows, FETCH_SIZE x 2 + WRITE_SIZE with the guide's gfx950 correction; tools/profile_round.sh, tools/pmc_summary.py).
+    Counters cannot be collected inside a timed run, so the bench line cites the file it read.  (bytes, path) or (None, None)."""
+    import glob
+    import re
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.txt")), reverse=True):
+        for line in open(path):
+            if "mlp_h3_kernel<true, false>" in line:
+                m = re.search(r"\s([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+[0-9.]+%", line)
+                if m:
+                    return float(m.group(3)) * 1e9, os.path.relpath(path, ROOT)
+    return None, None
+
+
 def stage_work(B):
     """Algorithmic work per LAUNCH of every stage of one SFNO forward at batch B: (flops, HBM bytes, bound).
     Flops are the useful count (m > l zeros skipped, no credit for the three split-f16 passes or the parity fold);
@@ -204,9 +217,13 @@ def roofline_from(rows, total_ms, B, h3):
     hbm_bytes = sum(r["gbytes"] * 1e9 * r["launches_per_step"] for r in rows if r["bound"] == "hbm")
     peak = PEAK_F16_MFMA_TFLOPS if h3 else PEAK_F32_MFMA_TFLOPS
     achieved = fl / (ms * 1e-3) / 1e12
+    traffic25, traffic_src = measured_traffic()
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-        "traffic": MLP_TRAFFIC_B25 if B == 25 else None, "traffic_source": MLP_TRAFFIC_SRC if B == 25 else None,
+        # counter traffic of a 25-row launch, scaled to the rows an average launch of this run covered (drop-path skip)
+        "traffic": round(traffic25 * dom.get("avg_rows", B) / 25.0) if traffic25 else None,
+        "traffic_source": ("%s (mlp_h3_kernel<true> at 25 rows: %.3f GB), x %.2f / 25 rows per launch here"
+                           % (traffic_src, traffic25 / 1e9, dom.get("avg_rows", B))) if traffic25 else None,
         "kernel": "mlp_h3_kernel<true> = stage '%s' (fused MLP 256->512->256 + GELU + Philox dropout + residual, 3-pass "
                   "split-f16 MFMA), B=%d, timed in the network" % (dom["name"], B),
         "ms_per_launch": ms, "launches_per_step": dom["launches_per_step"],

@@ -95,7 +95,6 @@ class DYffusion(torch.nn.Module):
         # (same inputs: sdy_sfno_fwd_args.reuse_encoder); False = two full forwards (A/B, tests)
         import os
         self.reuse_interpolator_encoder = bool(reuse_interpolator_encoder) and os.environ.get("SDY_NO_ENCODER_REUSE") is None
-        self._last_packed_inputs = None
         self.full_sampling_schedule = list(range(0, self.num_timesteps))
         self.sampling_schedule = sampling_schedule or self.full_sampling_schedule
         # DYffusion.__init__ consistency check (dyffusion.py:632-640)
@@ -186,8 +185,10 @@ class DYffusion(torch.nn.Module):
     def _time_tensor(value: float, like: Tensor) -> Tensor:
         return torch.full((like.shape[0],), float(value), dtype=torch.float32, device=like.device)
 
-    def q_sample(self, x0, x_end, t, interpolation_time=None, is_artificial_step: bool = True, **kwargs) -> Tensor:
-        """Interpolator call (dyffusion.py:190-240).  `t` is a host scalar diffusion step."""
+    def q_sample(self, x0, x_end, t, interpolation_time=None, is_artificial_step: bool = True, _keep_packed=None,
+                 **kwargs) -> Tensor:
+        """Interpolator call (dyffusion.py:190-240).  `t` is a host scalar diffusion step.  `_keep_packed`: a list that
+        receives the call's packed input concat (q_sample_two hands it to its second call; nothing is kept on the module)."""
         assert t is None or interpolation_time is None, "Either t or interpolation_time must be None."
         i_n = interpolation_time if t is None else self.diffusion_step_to_interpolation_step(t)
         dyn = kwargs.pop("dynamical_condition", None)
@@ -200,10 +201,10 @@ class DYffusion(torch.nn.Module):
         )
         kwargs.pop("num_predictions", None)
         with self.interpolator.inference_dropout_scope(condition=do_enable):
-            return self._interpolate(initial_condition=x_end, x_last=x0, t=time, t_host=i_n, **kwargs)
+            return self._interpolate(initial_condition=x_end, x_last=x0, t=time, t_host=i_n, _keep_packed=_keep_packed, **kwargs)
 
     def _interpolate(self, initial_condition: Tensor, x_last: Tensor, t: Tensor, t_host=None, num_predictions: int = 1,
-                     _packed_inputs: Optional[Tensor] = None, **kwargs) -> Tensor:
+                     _packed_inputs: Optional[Tensor] = None, _keep_packed=None, **kwargs) -> Tensor:
         """dyffusion.py:642-662.  `_packed_inputs`: the channel concat of a previous call on the same (x_end, x0)."""
         if t_host is not None:
             assert 0 < t_host < self.interpolator_horizon, \
@@ -214,7 +215,8 @@ class DYffusion(torch.nn.Module):
             inputs = ops.concat_channels(pieces)
         else:
             inputs = _packed_inputs
-        self._last_packed_inputs = inputs
+        if _keep_packed is not None:
+            _keep_packed.append(inputs)
         out = self.interpolator.predict_packed(inputs, time=t, **kwargs)["preds"]
         if hack:
             out = ops.concat_channels([initial_condition[:, :1], out])
@@ -231,11 +233,11 @@ class DYffusion(torch.nn.Module):
         """`(q_sample(t=t_first), q_sample(t=t_second))` as two interpolator forwards that share ONE input concat and ONE
         encoder pass (`reuse_encoder`): the encoder sees only (x_end, x0, static condition), which are the same for both
         calls; time embedding and dropout enter behind it.  Bit-identical to the two plain calls."""
-        first = self.q_sample(x0=x0, x_end=x_end, t=t_first, is_artificial_step=is_artificial_step, **dict(kwargs))
-        packed = self._last_packed_inputs
+        packed = []     # (lives for this call only: 0.8 GB at 25 members, 180 x 360, 128 channels)
+        first = self.q_sample(x0=x0, x_end=x_end, t=t_first, is_artificial_step=is_artificial_step, _keep_packed=packed,
+                              **dict(kwargs))
         second = self.q_sample(x0=x0, x_end=x_end, t=t_second, is_artificial_step=is_artificial_step,
-                               _packed_inputs=packed, reuse_encoder=True, **dict(kwargs))
-        self._last_packed_inputs = None
+                               _packed_inputs=packed[0], reuse_encoder=True, **dict(kwargs))
         return first, second
 
     def _can_stack_calls(self) -> bool:

@@ -29,6 +29,8 @@ for (k, c), v in sorted(agg.items()):
     print(f"{k:66s} {c:26s} avg {sum(v)/len(v):16.1f} over {len(v)} dispatches")
 PY
 }
+# (the counter passes keep every launch at 25 rows: bench.py scales the per-launch traffic to the rows its launches covered)
+export SDY_NO_DROP_SKIP=1
 for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE"; do
   T=$(echo $CTRS | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/pmc_$T -- python3 $R/tools/pmc_forward25.py > $OUT/pmc_$T.log 2>&1
@@ -38,3 +40,5 @@ for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
   find $OUT/pmc_$T -name "*.csv" -size +5M -delete
   head -60 $OUT/pmc_$T.txt
 done
+unset SDY_NO_DROP_SKIP
+python3 $R/tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>/dev/null; head -20 $OUT/pmc_summary.txt
