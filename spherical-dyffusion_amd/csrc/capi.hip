@@ -95,10 +95,26 @@ struct sdy_sht_plan {
   int* d_mcut = nullptr;    // [nlat]
 };
 
-static int env_gemm_mode() {
-  const char* e = std::getenv("SDY_GEMM_MODE");
-  return (e && std::string(e) == "f32") ? 0 : 1;
+// Every environment switch of the library, read once per process.  Each routes a stage to its fallback kernel (the only
+// implementation for other shapes; tests/test_gpu_variants.py holds all of them to the default path's output) -- INTEGRATION.md
+// section 5 lists what they do.
+namespace {
+struct SdySwitches {
+  bool gemm_f32, no_polar_skip, no_fft360, no_leg_par, no_leg_frag, no_dh_frag, no_conv_frag, no_pair, no_fused_stats,
+      no_fused_mlp, no_drop_skip;
+};
+const SdySwitches& sw() {
+  static const SdySwitches v = [] {
+    auto on = [](const char* n) { return std::getenv(n) != nullptr; };
+    const char* g = std::getenv("SDY_GEMM_MODE");
+    return SdySwitches{g && std::string(g) == "f32", on("SDY_NO_POLAR_SKIP"), on("SDY_NO_FFT360"), on("SDY_NO_LEG_PAR"),
+                       on("SDY_NO_LEG_FRAG"), on("SDY_NO_DH_FRAG"), on("SDY_NO_CONV_FRAG"), on("SDY_NO_PAIR"),
+                       on("SDY_NO_FUSED_STATS"), on("SDY_NO_FUSED_MLP"), on("SDY_NO_DROP_SKIP")};
+  }();
+  return v;
 }
+}  // namespace
+static int env_gemm_mode() { return sw().gemm_f32 ? 0 : 1; }
 
 extern "C" int sdy_sht_plan_create(int nlat, int nlon, int lmax, int mmax, int grid, sdy_sht_plan** out) {
   return sdy_sht_plan_create_ex(nlat, nlon, lmax, mmax, grid, env_gemm_mode(), out);
@@ -302,15 +318,14 @@ extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* C
 // polar: skip the rows / orders of the polar cut-off (only valid when the producer / consumer of Xf is fft360 with the same
 // cut-off: plan_polar_ok)
 static bool plan_polar_ok(const sdy_sht_plan* p, int C) {
-  static const bool off = std::getenv("SDY_NO_POLAR_SKIP") || std::getenv("SDY_NO_FFT360") || std::getenv("SDY_NO_LEG_PAR") ||
-                          std::getenv("SDY_NO_LEG_FRAG");
+  const bool off = sw().no_polar_skip || sw().no_fft360 || sw().no_leg_par || sw().no_leg_frag;
   return !off && p->d_kdead && p->d_wq_par && p->fft.n == 180 && C % 16 == 0;
 }
 // Tile-major grid-frequency tensor (fft.h, ilv == 2): like the polar cut-off a contract between fft360 and leg_par only --
 // the plane of one order is stored as whole 64-column tiles, so a Legendre workgroup's activation tile is one contiguous
 // block.
 static bool plan_tiled_ok(const sdy_sht_plan* p, int C, int ilv) {
-  static const bool off = std::getenv("SDY_NO_FFT360") || std::getenv("SDY_NO_LEG_PAR") || std::getenv("SDY_NO_LEG_FRAG");
+  const bool off = sw().no_fft360 || sw().no_leg_par || sw().no_leg_frag;
   return !off && ilv == 1 && p->d_wq_par && p->d_pct_par && p->fft.n == 180 && C % 32 == 0;
 }
 static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, int B, int C, bool polar, void* stream,
@@ -324,8 +339,7 @@ static int legendre_fwd_impl(const sdy_sht_plan* p, const float* Xf, float* Cs, 
   g.C = Cs; g.ldc = p->mtr * N; g.sC = N;
   g.M = p->Lpad4; g.M_store = p->lmax; g.N = N; g.K = p->nlat; g.nbatch = p->mtr;
   g.tri_mode = SDY_TRI_LEG_FWD; g.tile = SDY_TILE_64x128;
-  static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
-  static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
+  const bool no_frag = sw().no_leg_frag, no_par = sw().no_leg_par;
   if (p->d_wq_par && !no_frag && !no_par)
     // cs_tiled: the coefficients TILE-MAJOR by order, [m][column tile][l][64] (dh_h3.hip, DhParams::tiled)
     return sdy_leg_par_launch(p->d_wq_par, p->s_wq_par, p->mtr, Xf, tiled ? 64 : N, (long)p->nlat * N, Cs,
@@ -358,8 +372,7 @@ static int legendre_inv_impl(const sdy_sht_plan* p, const float* Cs, float* Yf, 
   g.C = Yf; g.ldc = N; g.sC = (long)p->nlat * N;
   g.M = p->Kpad4; g.M_store = p->nlat; g.N = N; g.K = p->lmax; g.nbatch = p->mtr;
   g.tri_mode = SDY_TRI_LEG_INV; g.tile = SDY_TILE_64x128;
-  static const bool no_frag = std::getenv("SDY_NO_LEG_FRAG") != nullptr;
-  static const bool no_par = std::getenv("SDY_NO_LEG_PAR") != nullptr;
+  const bool no_frag = sw().no_leg_frag, no_par = sw().no_leg_par;
   if (p->d_pct_par && !no_frag && !no_par)
     return sdy_leg_par_launch(p->d_pct_par, p->s_pct_par, p->mtr, Cs, cs_tiled ? 64L : (long)p->mtr * N,
                               cs_tiled ? (long)(N / 64) * p->lmax * 64 : (long)N, Yf, tiled ? 64 : N,
@@ -810,7 +823,7 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
     }
     if (rest == "filter.filter.weight") {
       EXPECT_NUMEL((size_t)E * E * c.lmax * 2);
-      static const bool no_dh_frag = std::getenv("SDY_NO_DH_FRAG") != nullptr;
+      const bool no_dh_frag = sw().no_dh_frag;
       if (h3 && sdy_dhconv_frag_supported(E, E) && !no_dh_frag) {   // persistent fragment-stream kernel (dh_h3.hip)
         if (!w.fw.frag) SDY_HIP_TRY(hipMalloc(&w.fw.frag, sdy_dhconv_frag_pack_bytes(c.lmax)));
         SDY_TRY(sdy_dh_h3_pack(host, c.lmax, w.fw.frag, &w.fw.frag_scale, spec_ilv(c)));
@@ -1108,7 +1121,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   //      indexed compactly, SdyImgMap) and writes the dropped ones' output a x + d with sdy_affine_copy_stats_launch.
   //      Only on the default kernel path (fft360 + leg_par + dh_h3 + conv_h3 + mlp_h3); injected decisions (tests) are
   //      device data, so they run unskipped.  SDY_NO_DROP_SKIP=1 computes everything (A/B: bit-identical results).
-  static const bool no_drop_skip = std::getenv("SDY_NO_DROP_SKIP") != nullptr;
+  const bool no_drop_skip = sw().no_drop_skip;
   const bool skip_allowed = drop && !a->drop_path_keep && !no_drop_skip && B <= SDY_MAP_MAX;
   auto drop_path_keeps = [&](int layer, int b) {
     const int bq = b / rpc;
@@ -1118,7 +1131,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   };
 
   sdy_conv_args cv;
-  static const bool no_frag = std::getenv("SDY_NO_CONV_FRAG") != nullptr;
+  const bool no_frag = sw().no_conv_frag;
   auto use_w = [&](const DevBuf& b) {
     cv.wt = b.p;
     if (c.gemm_mode == 1) {
@@ -1132,8 +1145,8 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   };
 
   // ---- encoder (sfnonet.py:609-618,810,824): conv+bias -> GELU -> conv (no bias) -> + pos_embed
-  static const bool no_pair = std::getenv("SDY_NO_PAIR") != nullptr;   // A/B: the two-launch encoder / decoder
-  static const bool no_stats0 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
+  const bool no_pair = sw().no_pair;   // A/B: the two-launch encoder / decoder
+  const bool no_stats0 = sw().no_fused_stats;
   // The encoder writes to a buffer of its own (xe) and its statistics to `ste`; block 0 works on a copy of the statistics
   // (sdy_instnorm_from_stats clears what it reads), so that a following forward on the same inputs can restart here.
   bool have_ste = false;
@@ -1181,7 +1194,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     const sdy_sht_plan* pout = (i == L - 1) ? n->plan_data : n->plan_lg;
     const bool scale_residual = pin != pout;  // s2convolutions.py:79-83
     const float pm = (drop && c.dropout_mlp > 0.f) ? c.dropout_mlp : 0.f;
-    static const bool no_fused = std::getenv("SDY_NO_FUSED_MLP") != nullptr;
+    const bool no_fused = sw().no_fused_mlp;
     const bool fused_mlp = bw.mlp && !no_fused;   // (injected masks too: sdy_mlp_args.keep_hidden / keep_out)
     // The block's residual is norm0(x) (or its SHT round trip when the grids differ).  With the fused MLP kernel the
     // normalised tensor is never materialised: its two consumers (inner skip, final residual add) apply a*x + d to `cur`.
@@ -1202,7 +1215,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     // Cs / Cs2 tile-major by order too (analysis stores and synthesis loads become contiguous tiles; dh_h3 reads and writes
     // 256-byte pieces instead of 2 KB rows, which it does not notice: it is matrix / issue bound).
     const bool cs_tiled = tiled_in && tiled_out && bw.fw.frag && pin->lmax == pout->lmax && pin->mtr == pout->mtr;
-    static const bool no_stats1 = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
+    const bool no_stats1 = sw().no_fused_stats;
     const bool frag_conv = c.gemm_mode == 1 && !no_frag && bw.skw.frag && sdy_conv256_h3_supported(E, E);
     const bool stats1 = frag_conv && !no_stats1;   // norm1 statistics from the inner-skip convolution's epilogue
     // The tensor between the inner skip and the fused MLP has exactly one producer and one consumer, both walking 64-pixel
@@ -1274,7 +1287,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
     }
     // MLP (layers.py:73-80): fc1 + GELU + dropout
-    static const bool no_stats = std::getenv("SDY_NO_FUSED_STATS") != nullptr;
+    const bool no_stats = sw().no_fused_stats;
     const bool stats_next = fused_mlp && i < L - 1 && !no_stats;   // the next block's norm0 statistics from this block's epilogue
     if (Bp == 0) {
       // (every trajectory dropped: nothing of the branch runs)

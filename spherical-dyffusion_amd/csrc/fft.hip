@@ -423,7 +423,7 @@ size_t fft_smem_bytes(const SdyFftDesc& f) { return ((size_t)4 * CB * f.S + 2 * 
 
 // SDY_NO_FFT360=1 keeps the generic Stockham kernels for nlon = 360 too (A/B measurements)
 bool use_generic_only() {
-  static const bool v = [] { const char* e = getenv("SDY_NO_FFT360"); return e && e[0] == '1'; }();
+  static const bool v = getenv("SDY_NO_FFT360") != nullptr;   // (set = on, like every other switch: capi.hip, SdySwitches)
   return v;
 }
 
