@@ -451,10 +451,12 @@ def main():
             if q:
                 xr = run(xr, forc_r, plan.start, w)
         if world > 1:                                  # the ring the hand-overs use: connections are set up outside the timed region
-            ping = torch.zeros(8, device=red_dev)
-            req = dist.isend(ping, dst=(rank + 1) % world)
-            dist.recv(torch.empty_like(ping), src=(rank - 1) % world)
-            req.wait()
+            # (one batched send + receive: issued one after the other, two ranks that each send first would wait for each
+            #  other's receive on RCCL's per-pair stream)
+            ping, pong = torch.zeros(8, device=red_dev), torch.empty(8, device=red_dev)
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, ping, (rank + 1) % world),
+                                               dist.P2POp(dist.irecv, pong, (rank - 1) % world)]):
+                req.wait()
         sends = []
         state = {"res": xr}
 

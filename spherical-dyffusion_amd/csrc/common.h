@@ -300,8 +300,11 @@ static inline uint32_t sdy_drop_threshold16(float p) {
   if (t <= 0.0) return 0u;
   return (uint32_t)t;
 }
+// (written so that neither half needs an extraction: the high half-word compares as the whole word against thr16 << 16 -- the
+//  low bits cannot change the outcome --, the low one as a 16-bit compare (v_cmp_*_u16 reads the low halves of its operands);
+//  two instructions per decision with the select instead of three, in kernels that are VALU-issue bound with dropout on)
 __host__ __device__ __forceinline__ bool sdy_keep16(uint32_t word, int half, uint32_t thr16) {
-  return ((half ? (word >> 16) : (word & 0xFFFFu)) >= thr16);
+  return half ? (word >= (thr16 << 16)) : ((uint16_t)word >= (uint16_t)thr16);
 }
 static inline uint32_t sdy_drop_threshold(float p) {
   double t = (double)p * 4294967296.0;
