@@ -177,7 +177,7 @@ typedef struct sdy_conv_args {
                                         tile padded to 64; out_bstride >= ceil(HW / 64) * Cout * 64), the layout sdy_mlp_args.x_tiled
                                         reads: a tile of the intermediate tensor between the two persistent kernels is then one
                                         contiguous 64 KB block for its producer and its consumer.  `out` must not alias `add`. */
-  const unsigned char* x_rows;       /* host [B] or NULL, w_frag path only, B <= 64: image z of this launch reads batch row x_rows[z] of
+  const unsigned char* x_rows;       /* host [B] or NULL, w_frag path only, B <= 128: image z of this launch reads batch row x_rows[z] of
                                         x / pa / pd (add, out and stats stay indexed by z).  sdy_sfno_forward runs a block whose
                                         DropPath draw (src/models/modules/drop_path.py:15-22) zeroes some trajectories' branch on
                                         the active trajectories only: its per-block tensors are compact, the block input is not. */
@@ -223,7 +223,7 @@ typedef struct sdy_mlp_args {
   const float* keep_hidden;            /* tests only, dev (B, hidden, HW) and (B, E, HW) 0/1 masks or NULL: with drop_p > 0 the */
   const float* keep_out;               /* keep decisions come from these (e.g. masks the reference's nn.Dropout drew) instead of
                                           the Philox stream -- same kernel code, a separate (untimed) instantiation */
-  const unsigned char* out_rows;       /* host [B] or NULL, B <= 64: image z of this launch (x, pa, pd indexed by z) IS batch row
+  const unsigned char* out_rows;       /* host [B] or NULL, B <= 128: image z of this launch (x, pa, pd indexed by z) IS batch row
                                           out_rows[z] -- add, add_a, add_d, out, stats, batch_scale, keep_* and the dropout stream
                                           (call, trajectory) are taken at that row (see sdy_conv_args.x_rows) */
   int add_by_launch_row;               /* with out_rows and without add_a / add_d: `add` is indexed by the launch's image z, like x
@@ -301,8 +301,9 @@ int sdy_sfno_set_param(sdy_sfno* net, const char* name, const float* host, size_
 int sdy_sfno_ready(const sdy_sfno* net);
 const char* sdy_sfno_missing(const sdy_sfno* net);
 size_t sdy_sfno_workspace_floats(const sdy_sfno* net, int B);
-/* Largest B one sdy_sfno_forward call takes (32-bit lane offsets inside the spectral workspace: 60 rows at 180 x 360,
- * embed 256); larger batches run as consecutive calls on row ranges, each with its own batch_offset (the Python module does). */
+/* Largest B one sdy_sfno_forward call takes (32-bit offsets inside the spectral workspace: 258 rows at 180 x 360, embed 256 on
+ * the default kernel path once the weights are loaded, 60 with row-major coefficient tensors); larger batches run as consecutive
+ * calls on row ranges, each with its own batch_offset (the Python module does). */
 int sdy_sfno_max_batch(const sdy_sfno* net);
 
 typedef struct sdy_sfno_fwd_args {

@@ -947,14 +947,29 @@ extern "C" size_t sdy_sfno_workspace_floats(const sdy_sfno* n, int B) {
   return ws_layout(n, B).total;
 }
 
-// Largest batch one sdy_sfno_forward call covers.  The kernels address rows as (wave-uniform 64-bit base) + (32-bit lane byte
-// offset); the widest lane offset is the Legendre synthesis reading up to 192 degree rows of the coefficient tensor
-// Cs[l][m][b][2E], whose row stride is mtr * 2 B E floats (leg_par.hip: sdy_leg_par_launch refuses larger strides).
+// Largest batch one sdy_sfno_forward call covers.  The kernels address rows as (wave-uniform 64-bit base) + (32-bit lane
+// offset).  On the default path of the production shape (tile-major spectral tensors: every block cs_tiled, below) the widest
+// 32-bit quantity is dh_h3's element offset inside a coefficient tensor, mtr * B * 8 * L * 64 < 2^32: 258 rows at 180 x 360
+// (sdy_dh_h3_launch refuses more).  With row-major coefficients (other shapes, the fallback switches) it is the Legendre
+// synthesis reading up to 192 degree rows of Cs[l][m][b][2E], whose row stride is mtr * 2 B E floats: 60 rows.
 extern "C" int sdy_sfno_max_batch(const sdy_sfno* n) {
   if (!n) return 0;
-  const int mtr = n->cfg.mmax < n->cfg.lmax ? n->cfg.mmax : n->cfg.lmax;
-  const long per_row = 192L * mtr * 2 * n->cfg.embed_dim * 4 + 2L * n->cfg.embed_dim * 4;   // bytes of lane offset per batch row
-  long b = ((1L << 32) - 1) / per_row;
+  const sdy_sfno_config& c = n->cfg;
+  const int mtr = c.mmax < c.lmax ? c.mmax : c.lmax;
+  bool all_tiled = c.gemm_mode == 1 && n->plan_data && n->plan_lg;
+  if (all_tiled) {
+    const int ilv = spec_ilv(c);
+    all_tiled = plan_tiled_ok(n->plan_data, c.embed_dim, ilv) && plan_tiled_ok(n->plan_lg, c.embed_dim, ilv) &&
+                n->plan_data->lmax == n->plan_lg->lmax && n->plan_data->mtr == n->plan_lg->mtr;
+    for (const BlockW& w : n->blk) all_tiled = all_tiled && w.fw.frag != nullptr;
+  }
+  long b;
+  if (all_tiled) {
+    b = ((1L << 32) - 1) / ((long)mtr * 8 * c.lmax * 64);
+  } else {
+    const long per_row = 192L * mtr * 2 * c.embed_dim * 4 + 2L * c.embed_dim * 4;   // bytes of lane offset per batch row
+    b = ((1L << 32) - 1) / per_row;
+  }
   if (b > 65535) b = 65535;
   return b < 1 ? 1 : (int)b;
 }

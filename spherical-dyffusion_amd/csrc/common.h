@@ -60,7 +60,7 @@ struct SdyOncePerDevice {                            // `static SdyOncePerDevice
 // trajectories (src/models/modules/drop_path.py:15-22) runs on the ACTIVE trajectories only.  Its per-block intermediates are
 // indexed compactly (j = 0 .. n_active - 1); the tensors that live across blocks keep their batch row idx[j].  Passed by value
 // in the kernel arguments (a uniform index into the kernarg segment: scalar loads); `on == 0` is the identity.
-constexpr int SDY_MAP_MAX = 64;
+constexpr int SDY_MAP_MAX = 128;
 struct SdyImgMap {
   int on;
   unsigned char idx[SDY_MAP_MAX];

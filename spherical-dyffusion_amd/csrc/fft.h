@@ -14,7 +14,7 @@ struct SdyFftDesc {
 // Polar cut-off (fused forward only): for latitude ring k only the orders m < mcut[k] are written (forward) / read (inverse);
 // the Legendre tables are negligible (< 1e-12 of their maximum) beyond it, see sdy_sht_plan::d_kdead.  nullptr = all orders.
 
-// x_rows (host, [B], or nullptr = identity; fft360 only, B <= 64): row b of Xf is the transform of batch row x_rows[b] of
+// x_rows (host, [B], or nullptr = identity; fft360 only, B <= 128): row b of Xf is the transform of batch row x_rows[b] of
 // x / a / d / xn_out -- the drop-path skip of the fused forward runs a block on its active trajectories only (common.h, SdyImgMap)
 int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                        int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream,

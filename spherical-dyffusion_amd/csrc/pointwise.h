@@ -29,7 +29,7 @@ int sdy_time_mlp_launch(const SdyTimeMlp& t, const float* time, int B, float* tr
                         uint32_t batch_offset, int rows_per_call, hipStream_t stream, float* scratch);
 int sdy_spec_to_torch_launch(const float* Cs, float* out, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);
 int sdy_torch_to_spec_launch(const float* in, float* Cs, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);
-// drop-path skip (capi.hip): out[b] = a[b] * x[b] + d[b] for the n_rows batch rows b = rows[i] (host array, <= 64 entries),
+// drop-path skip (capi.hip): out[b] = a[b] * x[b] + d[b] for the n_rows batch rows b = rows[i] (host array, <= 128 entries),
 // with the (sum, sum of squares) of every stored plane ADDED to stats[b] (dev double [B][C][2]) unless stats is null.
 // a, d null: a plain copy.  src_row0 >= 0: the source of rows[i] is row src_row0 + i of x (a tensor in the launch's own order).
 int sdy_affine_copy_stats_launch(const float* x, long x_bs, const float* a, const float* d, float* out, long out_bs,
