@@ -12,13 +12,17 @@ JSON line), and also under an external launcher:
 One "step" = one horizon-6 sampling pass (6 forecaster + 10 interpolator SFNO forwards, interpolator dropout stream
 on, cold-sampling updates, autoregressive feedback x0 <- t6) of the whole job.
 
-  --scaling strong (default; the BASELINE metric "25-member ensemble at 1/2/4/8 GPU"): ONE initial condition, 25 members
-      split over the ranks by `ensemble.partition` (N = 8: 4,3,3,3,3,3,3,3), every member keyed by its global index
-      (`batch_offset`), 150 member-forecast-steps per step in total.  At N > 1 a weak-scaling leg (25 members of its own
+  --scaling strong (default; the BASELINE metric "25-member ensemble at 1/2/4/8 GPU"): ONE initial condition, 25 members,
+      every member keyed by its global index (`batch_offset`) and every pass by its window (dropout call counters), 150
+      member-forecast-steps per step in total.  Each rank keeps 25 // N resident members; the 25 % N remainder members are
+      RELAYED (`ensemble.relay_plan`): each advances as a batch of one, hosted by one rank per slice of the timed windows and
+      handed to the next with a send / recv of its state (N = 8: 3 members per GPU + member 24 visiting every GPU for 1/8 of
+      the windows, instead of one GPU with 4 members setting the pace).  `--no-relay`: the static split of
+      `ensemble.partition` (N = 8: 4,3,3,3,3,3,3,3).  At N > 1 a weak-scaling leg (25 members of its own
       initial condition on every rank, the reference's IC sharding: src/ace_inference/core/data_loading/inference.py:110-113)
       is timed as well and reported under config.weak_scaling.
   --scaling weak: only that leg; value = N * 150 member-forecast-steps per step.
-There is no collective on the data path; RCCL serves the barriers and the max-over-ranks time.
+There is no collective on the data path; RCCL serves the barriers, the max-over-ranks time and the relay's hand-overs.
 
 Rank 0 prints ONE JSON line.  Beyond the contract keys:
   roofline      dominant kernel (`mlp_h3_kernel<true>`, the fused MLP with the Philox dropout of the interpolator), timed
