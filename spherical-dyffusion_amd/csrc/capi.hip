@@ -1265,41 +1265,41 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     const int Bf = scale_residual ? B : Bp;                // rows of the forward transform
 
     if (Bf > 0) {
-    SDY_STAGE_N(ST_FFT_FWD, Bf, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, Bf, E,
-                                                   pin->nlat, pin->mtr, tiled_in ? 2 : ilv, polar_in ? pin->d_mcut : nullptr, stream, rows));
-    SDY_STAGE_N(ST_LEG_FWD, Bf, legendre_fwd_impl(pin, Xf, Cs, Bf, E, polar_in, stream, tiled_in, cs_tiled));
-    if (scale_residual) {  // residual = inverse_transform(forward_transform(x)); in the order `perm` when rows were dropped
-      SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream, tiled_out, cs_tiled));
-      SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
-                                               polar_out ? pout->d_mcut : nullptr, stream));
-    }
+      SDY_STAGE_N(ST_FFT_FWD, Bf, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, Bf, E,
+                                                     pin->nlat, pin->mtr, tiled_in ? 2 : ilv, polar_in ? pin->d_mcut : nullptr, stream, rows));
+      SDY_STAGE_N(ST_LEG_FWD, Bf, legendre_fwd_impl(pin, Xf, Cs, Bf, E, polar_in, stream, tiled_in, cs_tiled));
+      if (scale_residual) {  // residual = inverse_transform(forward_transform(x)); in the order `perm` when rows were dropped
+        SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream, tiled_out, cs_tiled));
+        SDY_STAGE(ST_FFT_INV, sdy_fft_launch_inv(pout->fft, Xf, nullptr, xn, B, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
+                                                 polar_out ? pout->d_mcut : nullptr, stream));
+      }
     }
     if (Bp > 0) {
-    if (bw.fw.frag)
-      SDY_STAGE_N(ST_DHCONV, Bp, sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, Bp, ilv, (hipStream_t)stream,
-                                                  cs_tiled ? 1 : 0, Bf));
-    else if (c.gemm_mode == 1)
-      SDY_STAGE(ST_DHCONV, sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
-    else
-      SDY_STAGE(ST_DHCONV, sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
-    SDY_STAGE_N(ST_LEG_INV, Bp, legendre_inv_impl(pout, Cs2, Xf, Bp, E, polar_out, stream, tiled_out, cs_tiled));
-    SDY_STAGE_N(ST_FFT_INV, Bp, sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, Bp, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
-                                                   polar_out ? pout->d_mcut : nullptr, stream));
-    // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
-    conv_reset();
-    cv.B = Bp; cv.x_rows = lazy_norm ? rows : nullptr;   // (xn is in the launch's own row order)
-    cv.x = lazy_norm ? cur : xn; cv.x_bstride = lazy_norm ? cur_bs : (long)E * HW;
-    if (lazy_norm) { cv.pa = ca; cv.pd = cd; }
-    use_w(bw.skw); cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
-    cv.Cin = E; cv.Cout = E; cv.bias = bw.skb.p; cv.add = y; cv.add_bstride = (long)E * HW; cv.add_mode = 1; cv.act = 1; cv.kernel_tag = 3;
-    if (stats1) cv.stats = st1;
-    if (z_tiled) { cv.out = ws + w.zt; cv.out_bstride = zt_bs; cv.out_tiled = 1; }
-    SDY_STAGE_N(ST_SKIP_CONV, Bp, sdy_conv1x1(&cv, stream));
-    // norm1 (sfnonet.py:313-320) folded into the fc1 prologue; its statistics come from the convolution's epilogue
-    if (stats1)
-      SDY_STAGE_N(ST_NORM_COEFFS, Bp, sdy_instnorm_from_stats(st1, Bp, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
-    else
-      SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+      if (bw.fw.frag)
+        SDY_STAGE_N(ST_DHCONV, Bp, sdy_dh_h3_launch(Cs, bw.fw.frag, bw.fw.frag_scale, Cs2, c.lmax, pin->mtr, Bp, ilv, (hipStream_t)stream,
+                                                    cs_tiled ? 1 : 0, Bf));
+      else if (c.gemm_mode == 1)
+        SDY_STAGE(ST_DHCONV, sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
+      else
+        SDY_STAGE(ST_DHCONV, sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
+      SDY_STAGE_N(ST_LEG_INV, Bp, legendre_inv_impl(pout, Cs2, Xf, Bp, E, polar_out, stream, tiled_out, cs_tiled));
+      SDY_STAGE_N(ST_FFT_INV, Bp, sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, Bp, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
+                                                     polar_out ? pout->d_mcut : nullptr, stream));
+      // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
+      conv_reset();
+      cv.B = Bp; cv.x_rows = lazy_norm ? rows : nullptr;   // (xn is in the launch's own row order)
+      cv.x = lazy_norm ? cur : xn; cv.x_bstride = lazy_norm ? cur_bs : (long)E * HW;
+      if (lazy_norm) { cv.pa = ca; cv.pd = cd; }
+      use_w(bw.skw); cv.ldw = E; cv.out = y; cv.out_bstride = (long)E * HW;
+      cv.Cin = E; cv.Cout = E; cv.bias = bw.skb.p; cv.add = y; cv.add_bstride = (long)E * HW; cv.add_mode = 1; cv.act = 1; cv.kernel_tag = 3;
+      if (stats1) cv.stats = st1;
+      if (z_tiled) { cv.out = ws + w.zt; cv.out_bstride = zt_bs; cv.out_tiled = 1; }
+      SDY_STAGE_N(ST_SKIP_CONV, Bp, sdy_conv1x1(&cv, stream));
+      // norm1 (sfnonet.py:313-320) folded into the fc1 prologue; its statistics come from the convolution's epilogue
+      if (stats1)
+        SDY_STAGE_N(ST_NORM_COEFFS, Bp, sdy_instnorm_from_stats(st1, Bp, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+      else
+        SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
     }
     // MLP (layers.py:73-80): fc1 + GELU + dropout
     const bool no_stats = sw().no_fused_stats;
