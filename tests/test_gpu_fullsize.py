@@ -105,7 +105,8 @@ def test_c3_chain_error_against_a_float64_yardstick(weight_seeds):
     Philox stream replayed) three times on identical inputs and masks: the HIP path, the oracle's op sequence in float32 and
     in float64 (the yardstick; both evaluated by torch on the GPU, oracle.sfno.OracleSFNO(device="cuda") -- sixteen chained
     double-precision forwards take ten minutes on the host cores).  Two independent weight draws.  Asserted:
-      * relative L2 of the HIP path against the fp32 oracle <= 1e-4 (BASELINE.json north_star) at t1 .. t6;
+      * relative L2 of the HIP path against the float64 chain < 1e-4 (BASELINE.json north_star) at t1 .. t6, and against the fp32
+        oracle < 1e-4 wherever that oracle itself is within 0.6e-4 of the float64 chain (all but t6 of the second draw);
       * the HIP path is no further from the float64 chain than the reference's own fp32 arithmetic is
         (err(HIP, f64) <= 1.1 err(oracle32, f64)): what separates the two fp32 implementations is the chain's amplification of
         one forward's rounding (src/diffusion/dyffusion.py:457-567 chains sixteen forwards), not an error of either."""
@@ -156,9 +157,10 @@ def test_c3_chain_error_against_a_float64_yardstick(weight_seeds):
         # the HIP path against the exact chain: inside the bound, and no further out than the reference's own arithmetic
         assert e_hip64[k] < 1e-4, f"{k}: HIP path {e_hip64[k]:.3e} from the float64 chain (bound 1e-4); {report}"
         assert e_hip64[k] <= 1.1 * e_ref[k], f"{k}: HIP path {e_hip64[k]:.3e} from the float64 chain, the fp32 oracle {e_ref[k]:.3e}"
-        # against the fp32 oracle itself: 1e-4 wherever that oracle is within half the bound of the exact chain (two fp32
-        # implementations each e from the truth can be 2 e apart); beyond that, no further apart than their two distances
-        if e_ref[k] <= 0.5e-4:
+        # against the fp32 oracle itself: 1e-4 wherever that oracle is within 0.6e-4 of the exact chain (two fp32 implementations
+        # each e from the truth can be 2 e apart; measured: 1.2 e) -- t1 .. t5 of both draws and t6 of the first; beyond that, no
+        # further apart than their two distances
+        if e_ref[k] <= 0.6e-4:
             assert e_hip32[k] < 1e-4, f"{k}: rel L2 {e_hip32[k]:.3e} against the fp32 oracle (north_star bound 1e-4); {report}"
         assert e_hip32[k] <= 1.05 * (e_hip64[k] + e_ref[k]), report
     assert e_hip32["t5_preds"] < 1e-4 and e_ref["t6_preds"] > 3 * e_ref["t1_preds"], report   # the chain amplifies rounding
