@@ -426,3 +426,25 @@ def test_inference_log_plumbing_follows_the_reference(sdy):
     assert list(agg._aggregators) == ["mean", "mean_norm", "time_mean", "mean_step_20"]
     with pytest.raises(ValueError, match="target_data"):
         agg.record_batch(0.0, {}, {"a": w}, {}, {"a": w})
+
+
+def test_bench_reads_the_counter_traffic_of_the_newest_profile():
+    """`roofline.traffic` of the bench line is not a pasted constant: bench.measured_traffic() parses the newest
+    profiles/*/pmc_summary.txt for the dominant kernel's row (FETCH_SIZE x 2 + WRITE_SIZE per 25-row launch) and cites the file."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    traffic, src = bench.measured_traffic()
+    assert src is not None and os.path.exists(os.path.join(root, src)) and src.endswith("pmc_summary.txt")
+    newest = sorted(d for d in os.listdir(os.path.join(root, "profiles"))
+                    if os.path.exists(os.path.join(root, "profiles", d, "pmc_summary.txt")))[-1]
+    assert src == os.path.join("profiles", newest, "pmc_summary.txt")
+    algorithmic = 3 * 4.0 * 256 * 180 * 360 * 25            # x, residual, output: fp32 (25, 256, 180, 360) tensors
+    assert algorithmic <= traffic <= 1.15 * algorithmic, (traffic, algorithmic)
+    # the per-launch work of a stage scales with the rows its launches covered (drop-path skip)
+    w25, w20 = bench.stage_work(25)["mlp fused (dropout)"], bench.stage_work(20)["mlp fused (dropout)"]
+    assert abs(w20[0] / w25[0] - 0.8) < 1e-12 and abs(w20[1] / w25[1] - 0.8) < 1e-12
