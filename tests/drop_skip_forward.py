@@ -29,7 +29,7 @@ def main(out_path: str) -> None:
         for k in range(4):                                                                       # B = 1: whole blocks dropped
             outs[f"{grid}/b1_{k}"] = net(x[k:k + 1], time=t[k:k + 1], condition=cond[k:k + 1]).cpu()
         for k in range(6):      # the sampler's stacked pair: one trajectory, two calls (one kept row beside one dropped row)
-            outs[f"{grid}/pair_{k}"] = net(x[k:k + 1].repeat(2, 1, 1, 1), time=t[k:k + 2 if k < 5 else None][:2].repeat(2)[:2],
+            outs[f"{grid}/pair_{k}"] = net(x[k:k + 1].repeat(2, 1, 1, 1), time=torch.stack([t[k], t[(k + 1) % 6]]),
                                            condition=cond[k:k + 1].repeat(2, 1, 1, 1), rows_per_call=1).cpu()
     torch.save(outs, out_path)
 
