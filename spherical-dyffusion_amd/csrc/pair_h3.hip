@@ -64,6 +64,9 @@ struct PairCfg {
 #define SDY_PAIR_FC1_CHAIN 1
 #endif
 constexpr bool kChainInFc1 = SDY_PAIR_FC1_CHAIN != 0;
+#ifndef SDY_PAIR_EARLY_X
+#define SDY_PAIR_EARLY_X 1
+#endif
 
 struct PairParams {
   const float* x; long x_bs; int Cin;
@@ -218,21 +221,26 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
   // decoder's fc1 4.6k -> 8.9k cycles).
   bool x_ok = true;
   bool bad = false;   // a non-finite value met in some x tile: raised as SDY_FLAG_NONFINITE when the kernel leaves
-  auto load_x = [&](int t, int part) {
+  const float* lx_base = nullptr;   // (load_x in pieces: the decoder issues the next tile's first part between its chain pieces)
+  unsigned lx_pxo = 0u;
+  auto load_x_setup = [&](int t) {
     const int tu = __builtin_amdgcn_readfirstlane(t);   // (workgroup-uniform; the base below must sit in SGPRs)
     const int zz = tu / tpi, nn = (tu - zz * tpi) * PTN;
     const bool ok = nn + 4 * q0 < p.HW;
     x_ok = ok;
-    const float* xz = p.x + (long)zz * p.x_bs;
-    const unsigned pxo = (unsigned)(ok ? nn + 4 * q0 : 0);
+    lx_base = p.x + (long)zz * p.x_bs;
+    lx_pxo = (unsigned)(ok ? nn + 4 * q0 : 0);
+  };
+  auto load_x_piece = [&](int part, int idx) {   // idx = 8 i + e
+    const int i = idx >> 3, e = idx & 7;
+    int ch = 16 * KSP * part + 8 * (o0 + 16 * i) + e;
+    ch = ch < p.Cin ? ch : p.Cin - 1;
+    xr[i][e] = sdy_ld16s(lx_base, ((unsigned)ch * (unsigned)p.HW + lx_pxo) * 4u);
+  };
+  auto load_x = [&](int t, int part) {
+    load_x_setup(t);
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        int ch = 16 * KSP * part + 8 * (o0 + 16 * i) + e;
-        ch = ch < p.Cin ? ch : p.Cin - 1;
-        xr[i][e] = sdy_ld16s(xz, ((unsigned)ch * (unsigned)p.HW + pxo) * 4u);
-      }
+    for (int idx = 0; idx < 8 * NI; ++idx) load_x_piece(part, idx);
   };
   // DYNAMIC SCALE of the x tile (round 4).  The encoder and the decoder are where un-normalised tensors enter the network -- user
   // data, the last block's output -- so their x tile is not staged with the fixed pre-scale of the other kernels (overflow at
@@ -369,12 +377,18 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
         chain_store(s, c, j, g4);
       }
     };
-    auto chain_alone = [&](int c, int first_piece) {
+    // `lx0`, `lx_per`: the next tile's x loads lx0 + lx_per * (piece - first_piece) ... are issued behind this chain's pieces
+    auto chain_alone = [&](int c, int first_piece, int lx0 = 0, int lx_per = 0) {
 #pragma unroll
       for (int pc = first_piece; pc < 8; ++pc) {
         Piece s;
 #pragma unroll
         for (int st = 0; st < 12; ++st) chain_slot(s, st, c, pc & 1, pc >> 1);
+#pragma unroll
+        for (int k = 0; k < lx_per; ++k) {
+          const int idx = lx0 + lx_per * (pc - first_piece) + k;
+          if (idx < 8 * NI) load_x_piece(0, idx);
+        }
       }
     };
 
@@ -489,8 +503,24 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
       if (part + 1 < NPART) part_amax(part + 1);   // (its loads were issued in front of this part's MFMA loop)
     }
     stamp(4);
-    chain_alone(0, NPI);
-    if (MO != 8) chain_alone(1, 0);
+    // The decoder's fc2 is 48 MFMAs: issued in front of its second chunk, the next tile's pixels had 2.5k cycles to arrive and
+    // part_amax below waited 2.2k more for them (stamps).  Its x registers are free once the last part is split, and the two
+    // chains that follow touch neither the ring nor the vector-memory queue: the burst goes in front of them.
+    constexpr bool kEarlyX = SDY_PAIR_EARLY_X && MO != 8;
+    if (kEarlyX) {   // ... spread over the chain pieces: a burst stalls at issue for 2-3k cycles wherever it stands
+      const int nt = tile + 1;
+      load_x_setup(nt < t_end ? nt : tile);
+      constexpr int P0 = 8 - NPI, PER = (8 * NI + P0 + 8 - 1) / (P0 + 8);
+      chain_alone(0, NPI, 0, PER);
+      chain_alone(1, 0, PER * P0, PER);
+#pragma unroll
+      for (int idx = PER * (P0 + 8); idx < 8 * NI; ++idx) load_x_piece(0, idx);
+      // (the encoder keeps its burst in front of fc2's second chunk: its chain(1) rides beside fc2(0), and with the x registers
+      //  live across that phase the 128-channel instantiation spills -- measured: 1.442 -> 1.436 ms, nothing)
+    } else {
+      chain_alone(0, NPI);
+      if (MO != 8) chain_alone(1, 0);
+    }
     stamp(5);
     __syncthreads();
     stamp(6);
@@ -516,7 +546,8 @@ __global__ __launch_bounds__(256, 1) void pair_h3_kernel(const PairParams p) {
         stamp(7);
         if (MO == 8) __syncthreads();          // chain(1) wrote chunk 1 beside fc2(0)
         const int nt = tile + 1;
-        load_x(nt < t_end ? nt : tile, 0);     // next tile's pixels; past the end a harmless re-read keeps it branch-free
+        if (!(SDY_PAIR_EARLY_X && MO != 8))
+          load_x(nt < t_end ? nt : tile, 0);   // next tile's pixels; past the end a harmless re-read keeps it branch-free
         stamp(11);
       }
       if constexpr (MO == 8) {
