@@ -130,7 +130,28 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   // ---- x tile prefetch: thread = (pixel quad q, channel octets o and o + 16)
   int q0 = tid & 15, o0 = tid >> 4;
   f32x4 xr[2][8];
-  auto prefetch_x = [&](int t) {
+  // The next tile's 16 pixel loads and this tile's 16 residual rows are NOT issued as bursts (a burst in front of the last fc2
+  // made that phase 6.5-9.5k cycles for 3.7k of MFMA work: the wave stalls at issue while the vector-memory queue drains, and the
+  // ring refills behind it wait for HBM): two of each ride behind every one of the epilogue's eight (row tile, row group)
+  // rounds, a phase of plain VALU work that touches neither the ring nor vector memory (round 5: 3.006 -> 2.904 ms per launch
+  // with dropout, 2.980 -> 2.914 without, profiles/r5c/e2e_ab_mlp_prefetch_late2.txt; spread over the last fc2 instead they
+  // cost 1.3 %, e2e_ab_mlp_prefetch_spread.txt).
+  const float* pf_base = nullptr;
+  const float* res_base = nullptr;
+  unsigned pf_off = 0u;
+  int pf_rs = 0;
+  auto prefetch_setup = [&](int t) {
+    const int zz = t / tpi, nn = (t - zz * tpi) * TN;
+    const bool ok = nn + 4 * q0 < p.HW;
+    pf_base = p.x + (long)zz * p.x_bs + (p.x_tiled ? (long)(t - zz * tpi) * (ME * TN) : 0L);
+    pf_rs = p.x_tiled ? TN : p.HW;
+    pf_off = p.x_tiled ? (unsigned)(8 * o0 * TN + 4 * q0) * 4u : (unsigned)(8 * o0 * p.HW + (ok ? nn + 4 * q0 : 0)) * 4u;
+  };
+  auto prefetch_piece = [&](int piece) {   // piece = 8 oc + e
+    const int oc = piece >> 3, e = piece & 7;
+    xr[oc][e] = sdy_ld16s(pf_base + (long)(8 * 16 * oc + e) * pf_rs, pf_off);
+  };
+  auto prefetch_x = [&](int t) {   // (the workgroup's first tile: all at once)
     const int zz = t / tpi, nn = (t - zz * tpi) * TN;
     // ragged last slice of an image: clamp the address (branch-free loads keep exact vmcnt counts), zero at conversion
     const bool ok = nn + 4 * q0 < p.HW;
@@ -663,16 +684,14 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
   asm volatile("" : "+v"(wp));   // (laundered: otherwise the 16 refill addresses become loop invariants in VGPRs)
   {
     const int nt = tile + 1;
-    prefetch_x(nt < t_end ? nt : tile);   // next tile's pixels; past the end a harmless re-read keeps it branch-free
+    prefetch_setup(nt < t_end ? nt : tile);   // next tile's pixels (issued in the epilogue); past the end a harmless re-read
   }
   fc2(NCH - 1, F_{});
   stamp(12);
   {
-    // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested before
-    // the epilogue arithmetic, which covers most of their latency
-    const float* az = p.add ? p.add + (long)(p.add_local ? z : zo) * p.add_bs : p.x + (long)z * p.x_bs;   // uniform
-#pragma unroll
-    for (int i = 0; i < 16; ++i) rres[i] = sdy_ld16s(az + (long)(16 * i) * p.HW, e_ro);
+    // residual rows for the final store phase (thread = pixel quad q, rows tid / 16 + 16 i): requested two per round of the
+    // epilogue arithmetic below, in front of the next tile's pixels
+    res_base = p.add ? p.add + (long)(p.add_local ? z : zo) * p.add_bs : p.x + (long)z * p.x_bs;   // uniform
   }
 
   // ---- epilogue: bias, dropout, drop-path scale in accumulator layout -> LDS [256 rows][64 px] (the x tile's storage:
@@ -720,6 +739,13 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
             Os[(row0 + 8 * g4 + r4) * TN + px] = o.x;
             Os[(row0 + 8 * g4 + r4 + 1) * TN + px] = o.y;
           }
+        }
+        {   // two residual rows and two pixel pieces of the next tile behind this round
+          const int i0 = 2 * (4 * mi + g4);
+          rres[i0] = sdy_ld16s(res_base + (long)(16 * i0) * p.HW, e_ro);
+          rres[i0 + 1] = sdy_ld16s(res_base + (long)(16 * (i0 + 1)) * p.HW, e_ro);
+          prefetch_piece(i0);
+          prefetch_piece(i0 + 1);
         }
       }
     }
