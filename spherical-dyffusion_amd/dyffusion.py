@@ -185,6 +185,15 @@ class DYffusion(torch.nn.Module):
     def _time_tensor(value: float, like: Tensor) -> Tensor:
         return torch.full((like.shape[0],), float(value), dtype=torch.float32, device=like.device)
 
+    @staticmethod
+    def _check_time_range(net, value: float) -> None:
+        """The network's own range check (`sfnonet.py:780-782`, a device assert there) on the host scalar the time tensor is
+        built from: sampling with artificial steps asks an interpolator for times in (0, 1), which one whose range
+        `InterpolationExperiment` pinned to the data steps [1, horizon - 1] (`interpolation.py:24-31`) refuses."""
+        lo, hi = getattr(net, "min_time", None), getattr(net, "max_time", None)
+        if lo is not None and hi is not None:
+            assert lo <= value <= hi, f"time must be in [{lo}, {hi}], but time is {value}"
+
     def q_sample(self, x0, x_end, t, interpolation_time=None, is_artificial_step: bool = True, _keep_packed=None,
                  **kwargs) -> Tensor:
         """Interpolator call (dyffusion.py:190-240).  `t` is a host scalar diffusion step.  `_keep_packed`: a list that
@@ -195,6 +204,7 @@ class DYffusion(torch.nn.Module):
         if dyn is not None:
             kwargs["condition"] = self.interpolator.get_dynamical_condition(dyn, i_n)
         time = self._time_tensor(i_n, x0)
+        self._check_time_range(getattr(self.interpolator, "model", None), float(i_n))
         do_enable = bool(
             self.enable_interpolator_dropout in [True, "always"]
             or (self.enable_interpolator_dropout == "except_dynamical_steps" and is_artificial_step)
@@ -254,6 +264,7 @@ class DYffusion(torch.nn.Module):
         i_a, i_b = (self.diffusion_step_to_interpolation_step(t) for t in (t_first, t_second))
         for i_n in (i_a, i_b):
             assert 0 < i_n < self.interpolator_horizon, f"interpolate time must be in (0, {self.interpolator_horizon}), got {i_n}"
+            self._check_time_range(getattr(self.interpolator, "model", None), float(i_n))
         kwargs.pop("num_predictions", None)
         dyn = kwargs.pop("dynamical_condition", None)
         two = lambda v: torch.cat([v, v], dim=0)  # noqa: E731
@@ -292,6 +303,7 @@ class DYffusion(torch.nn.Module):
                 raise ValueError(f"Invalid dynamic_cond_from_t: {sel}")
         time_v = t if self.hparams.time_encoding == "discrete" else self.diffusion_step_to_interpolation_step(t)
         time = self._time_tensor(time_v, x_t)
+        self._check_time_range(self.model, float(time_v))
         return self.model.predict_forward(x_t, time=time, condition=cond, **kwargs)
 
     # ---- sampler (dyffusion.py:457-577) -----------------------------------------------------------------------------

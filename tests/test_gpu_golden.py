@@ -146,6 +146,76 @@ def test_sampler_vs_reference(name):
         assert err < TOL_TIGHT, f"{name}/{k}: rel L2 {err:.3e}"
 
 
+@pytest.mark.parametrize("name", ["fx_sample_tiny_k2", "fx_sample_tiny_k2_every2nd", "fx_sample_tiny_naive"])
+def test_sampler_outside_k0_vs_reference(name):
+    """The product sampler OUTSIDE the shipped k = 0 configuration against the reference's own `DYffusion.sample`
+    (src/diffusion/dyffusion.py:134-188 step map, :226-235 per-call dropout rule, :367-455 named schedules, :467-520 loop):
+    additional_interpolation_steps = 2 with the full schedule and with "every2nd", `enable_interpolator_dropout=
+    "except_dynamical_steps"` (the reference's recorded masks are injected into exactly the calls whose dropout it had on),
+    and `sampling_type="naive"` with one artificial step.  The call trace (network, time, dropout on) equals the reference's."""
+    import sdy_amd
+
+    z = gu.load(name)
+    fcfg = SFNOConfig(**json.loads(str(z["fcfg"])))
+    icfg = SFNOConfig(**json.loads(str(z["icfg"])))
+    extra = json.loads(str(z["diffusion_extra"]))
+    per_call = extra.get("enable_interpolator_dropout") == "except_dynamical_steps"
+    n_forc = 2
+    fnet = _net(fcfg, fcfg.in_chans - n_forc, n_forc, gu.state_dict(z, "f::"))
+    inet = _net(icfg, icfg.in_chans - n_forc, n_forc, gu.state_dict(z, "i::"))
+    per_fwd = gu.masks_per_forward(gu.recorded_masks(z), icfg)
+    used = {"n": 0}
+
+    def inject(call):      # called only by forwards whose dropout is on: the recorded sets are consumed in that order
+        d = per_fwd[used["n"]]
+        used["n"] += 1
+        return _injector([d], icfg, first_call=call)(call)
+
+    inet.mask_injector = inject
+    trace = []
+    for tag, net in (("F", fnet), ("I", inet)):
+        def hook(fwd, tag=tag, net=net):
+            def run(inputs, time=None, **kw):
+                trace.append([tag, float(time[0])] + ([bool(net.inference_dropout)] if (tag == "I" and per_call) else []))
+                return fwd(inputs, time=time, **kw)
+            return run
+        net.forward = hook(net.forward)
+    ipol = sdy_amd.InterpolationExperiment(inet, horizon=6)
+    # (the experiment pins the interpolator's valid times to the data steps [1, 5] like the reference's; the fixture's
+    #  interpolator had its range opened to [0, 5] for the artificial steps -- tools/gen_golden.py, build_experiments)
+    inet.set_min_max_time(icfg.min_time, icfg.max_time)
+    exp = sdy_amd.MultiHorizonForecastingDYffusion(
+        fnet, ipol, horizon=6,
+        diffusion_config=dict(hack_for_imprecise_interpolation=True, **{"enable_interpolator_dropout": True, **extra}))
+    out = exp.model.sample(_cu(_t(z, "x0")), static_condition=_cu(_t(z, "static_condition")))
+    assert trace == json.loads(str(z["trace"])), "network call order / times / dropout flags differ from the reference's"
+    assert used["n"] == len(per_fwd)
+    ref = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out::")}
+    assert sorted(out) == sorted(ref)
+    for k in ref:
+        err = rel_l2(out[k], ref[k])
+        assert err < TOL_TIGHT, f"{name}/{k}: rel L2 {err:.3e}"
+
+
+def test_sampler_refuses_artificial_times_outside_the_interpolators_range():
+    """An interpolator whose time range is the data steps [1, horizon - 1] (what `InterpolationExperiment` sets,
+    src/experiment_types/interpolation.py:24-31) fails the network's range assert (sfnonet.py:780-782) when a sampler with
+    artificial steps asks for time 1/3; here the same AssertionError comes from the host scalar, without a device sync."""
+    import sdy_amd
+
+    z = gu.load("fx_sample_tiny_k2")
+    fcfg = SFNOConfig(**json.loads(str(z["fcfg"])))
+    icfg = SFNOConfig(**json.loads(str(z["icfg"])))
+    fnet = _net(fcfg, fcfg.in_chans - 2, 2, gu.state_dict(z, "f::"))
+    inet = _net(icfg, icfg.in_chans - 2, 2, gu.state_dict(z, "i::"))
+    exp = sdy_amd.MultiHorizonForecastingDYffusion(
+        fnet, sdy_amd.InterpolationExperiment(inet, horizon=6), horizon=6,       # (pins the range to [1, 5])
+        diffusion_config=dict(hack_for_imprecise_interpolation=True, enable_interpolator_dropout=False,
+                              additional_interpolation_steps=2))
+    with pytest.raises(AssertionError, match="time must be in"):
+        exp.model.sample(_cu(_t(z, "x0")), static_condition=_cu(_t(z, "static_condition")))
+
+
 def test_stepper_vs_reference():
     """MultiStepStepper.run_on_batch vs the reference's own run_on_batch_multistep (normalise, pack, 8 autoregressive
     steps across a window boundary, prescriber, HGTsfc carry-over, denormalise, LpLoss metrics)."""

@@ -91,13 +91,19 @@ def _sampler(z, masks=None):
         trace.append(["F", float(time[0])])
         return fnet(x, time=time, condition=condition, static_condition=static_condition)
 
+    extra = json.loads(str(z["diffusion_extra"])) if "diffusion_extra" in z.files else {}
+    per_call = extra.get("enable_interpolator_dropout") == "except_dynamical_steps"
+    smp = None
+
     def i(x, time, condition=None, static_condition=None):
-        trace.append(["I", float(time[0])])
-        mf = gu.mask_fn_from(per_fwd[n["i"]]) if per_fwd is not None else None
-        n["i"] += 1
+        on = per_fwd is not None and smp.dropout_on        # a mask set exists for exactly the calls whose dropout was on
+        trace.append(["I", float(time[0])] + ([bool(on)] if per_call else []))
+        mf = gu.mask_fn_from(per_fwd[n["i"]]) if on else None
+        n["i"] += int(on)
         return inet(x, time=time, condition=condition, static_condition=static_condition, mask_fn=mf)
 
-    return OracleDYffusion(f, i, timesteps=6, hack_for_imprecise_interpolation=bool(int(z["hack"]))), trace
+    smp = OracleDYffusion(f, i, timesteps=6, hack_for_imprecise_interpolation=bool(int(z["hack"])), **extra)
+    return smp, trace
 
 
 @pytest.mark.parametrize("name", ["fx_sample_tiny", "fx_sample_tiny_hack", "fx_sample_tiny_masks"])
@@ -115,6 +121,25 @@ def test_sampler_matches_reference(name):
     assert trace == json.loads(str(z["trace"]))
     if masks is not None:
         assert len(gu.masks_per_forward(masks, SFNOConfig(**json.loads(str(z["icfg"]))))) == 10
+
+
+@pytest.mark.parametrize("name,n_dropout_calls", [("fx_sample_tiny_k2", 3), ("fx_sample_tiny_k2_every2nd", 1),
+                                                   ("fx_sample_tiny_naive", 6)])
+def test_sampler_outside_k0_matches_reference(name, n_dropout_calls):
+    """The sampler with artificial diffusion steps (additional_interpolation_steps = 2: interpolation times 1/3, 2/3 before the
+    first data step), the named schedule "every2nd", per-call dropout "except_dynamical_steps", and naive sampling -- fixtures
+    from the reference's own DYffusion.sample (src/diffusion/dyffusion.py:134-188,226-235,367-455,467-520), masks recorded."""
+    z = gu.load(name)
+    masks = gu.recorded_masks(z)
+    smp, trace = _sampler(z, masks)
+    out = smp.sample(_t(z, "x0"), static_condition=_t(z, "static_condition"))
+    ref = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out::")}
+    assert sorted(out) == sorted(ref)
+    assert trace == json.loads(str(z["trace"]))
+    for k in ref:
+        err = rel_l2(out[k], ref[k])
+        assert err < 5e-6, f"{name}/{k}: rel L2 {err:.3e}"
+    assert len(gu.masks_per_forward(masks, SFNOConfig(**json.loads(str(z["icfg"]))))) == n_dropout_calls
 
 
 def test_call_trace_fixture():

@@ -4,7 +4,7 @@ os.environ["SDY_DH_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sdy_amd
 from sdy_amd._lib import lib, ptr, check, current_stream
-B, E, L, mtr = 25, 256, 180, 180
+B, E, L, mtr = (int(sys.argv[1]) if len(sys.argv) > 1 else 25), 256, 180, 180
 dev = torch.device("cuda")
 Cs = torch.randn(L * mtr * B * 2 * E, device=dev); Cs2 = torch.zeros_like(Cs)
 w = torch.randn(E, E, L, 2) / 16

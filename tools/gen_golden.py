@@ -191,7 +191,7 @@ def gen_sfno_wide_masks(tag="fx_sfno_wide_masks"):
           f"{len(rec.records)} masks, saved")
 
 
-def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i, extra=None):
+def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i, extra=None, ipol_min_time=1.0):
     import src.experiment_types._base_experiment as be
     from src.experiment_types.forecasting_multi_horizon import MultiHorizonForecastingDYffusion
     from src.experiment_types.interpolation import InterpolationExperiment
@@ -214,13 +214,20 @@ def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i, extr
                                    datamodule_config=dm, enable_inference_dropout=True, verbose=False)
     icfg = SFNOConfig(in_chans=2 * cs + n_forc, out_chans=C, nlat=H, nlon=W, embed_dim=E, num_layers=L,
                       with_time_emb=True, dropout_mlp=0.1 if dropout else 0.0, drop_path_rate=0.1 if dropout else 0.0,
-                      min_time=1.0, max_time=5.0)
+                      min_time=ipol_min_time, max_time=5.0)
+    if ipol_min_time != 1.0:
+        # InterpolationExperiment.__init__ pins the network's valid time range to the data time steps [1, horizon - 1]
+        # (src/experiment_types/interpolation.py:24-25,27-31) and the network asserts it (sfnonet.py:780-782): sampling with
+        # artificial steps (interpolation times in (0, 1)) needs an interpolator whose range was opened, as a user with a
+        # continuous-time interpolator would do
+        ipol.model.set_min_max_time(min_time=ipol_min_time, max_time=5.0)
     assert ipol.model.in_chans == icfg.in_chans and ipol.model.out_chans == C
     isd = make_state_dict(icfg, seed=seed_i)
     ipol.model.load_state_dict(isd, strict=False)
     dcfg = AttrDict(_target_="src.diffusion.dyffusion.DYffusion", timesteps=6, forward_conditioning="none",
                     interpolator=ipol, interpolator_local_checkpoint_path=None, time_encoding="dynamics",
-                    hack_for_imprecise_interpolation=hack, enable_interpolator_dropout=bool(dropout), **(extra or {}))
+                    hack_for_imprecise_interpolation=hack,
+                    **{"enable_interpolator_dropout": bool(dropout), **(extra or {})})
     fc = MultiHorizonForecastingDYffusion(model_config=mcfg(), datamodule_config=dm, diffusion_config=dcfg,
                                           verbose=False)
     fcfg = SFNOConfig(in_chans=cs + n_forc, out_chans=C, nlat=H, nlon=W, embed_dim=E, num_layers=L,
@@ -233,9 +240,10 @@ def build_experiments(C, n_forc, H, W, E, L, hack, dropout, seed_f, seed_i, extr
     return fc, ipol, fcfg, icfg, fsd, isd, cs
 
 
-def gen_sample(tag, hack, dropout, extra=None):
+def gen_sample(tag, hack, dropout, extra=None, ipol_min_time=1.0):
     C, n_forc, H, W, E, L = 6, 2, 32, 64, 16, 2
-    fc, ipol, fcfg, icfg, fsd, isd, cs = build_experiments(C, n_forc, H, W, E, L, hack, dropout, 11, 22, extra)
+    fc, ipol, fcfg, icfg, fsd, isd, cs = build_experiments(C, n_forc, H, W, E, L, hack, dropout, 11, 22, extra,
+                                                           ipol_min_time=ipol_min_time)
     g = torch.Generator(device="cpu").manual_seed(1234)
     B = 2
     x0 = torch.randn(B, cs, H, W, generator=g)
@@ -246,7 +254,11 @@ def gen_sample(tag, hack, dropout, extra=None):
     trace = []
     f_net, i_net = fc.model.model, ipol.model
     hf = f_net.register_forward_pre_hook(lambda m, a, k: trace.append(["F", float(k["time"][0])]), with_kwargs=True)
-    hi = i_net.register_forward_pre_hook(lambda m, a, k: trace.append(["I", float(k["time"][0])]), with_kwargs=True)
+    # (the third entry -- is the interpolator's dropout on for this call -- only where a fixture switches it per call)
+    per_call_dropout = (extra or {}).get("enable_interpolator_dropout") == "except_dynamical_steps"
+    hi = i_net.register_forward_pre_hook(
+        lambda m, a, k: trace.append(["I", float(k["time"][0])] + ([bool(m.blocks[0].mlp.fwd[2].training)] if per_call_dropout else [])),
+        with_kwargs=True)
     rec = MaskRecorder(i_net) if dropout else None
     torch.manual_seed(4242)
     res = fc.model.sample(x0, **kw)     # DYffusion.sample (dyffusion.py:569-572)
@@ -279,6 +291,23 @@ def gen_sample_refine():
     """`refine_intermediate_predictions=True` (src/diffusion/dyffusion.py:551-563: a second interpolator sweep from the last
     forecast) with the carried input-only channel; 6 + 10 + 5 network calls."""
     return gen_sample("fx_sample_tiny_refine", hack=True, dropout=False, extra=dict(refine_intermediate_predictions=True))
+
+
+def gen_sample_artificial():
+    """The sampler OUTSIDE the shipped k = 0 configuration (src/diffusion/dyffusion.py:134-188 step map, :226-235 per-call
+    dropout rule, :363-455 named schedules, :467-520 loop): additional_interpolation_steps = 2 puts two artificial diffusion
+    steps (interpolation times 1/3, 2/3) in front of the first data step.
+      fx_sample_tiny_k2          full schedule [0 .. 7], dropout "except_dynamical_steps" (on only for the calls of a step that
+                                 lands on an artificial time), masks recorded
+      fx_sample_tiny_k2_every2nd the same with sampling_schedule="every2nd" (artificial step 1 of [1, 2] joins)
+      fx_sample_tiny_naive       sampling_type="naive", one artificial step, dropout always on, masks recorded"""
+    k2 = dict(additional_interpolation_steps=2, enable_interpolator_dropout="except_dynamical_steps")
+    t1 = gen_sample("fx_sample_tiny_k2", hack=True, dropout=True, extra=k2, ipol_min_time=0.0)
+    t2 = gen_sample("fx_sample_tiny_k2_every2nd", hack=True, dropout=True, extra=dict(k2, sampling_schedule="every2nd"),
+                    ipol_min_time=0.0)
+    t3 = gen_sample("fx_sample_tiny_naive", hack=True, dropout=True,
+                    extra=dict(additional_interpolation_steps=1, sampling_type="naive"), ipol_min_time=0.0)
+    return t1, t2, t3
 
 
 def gen_stepper(tag="fx_stepper_tiny"):
@@ -572,6 +601,7 @@ if __name__ == "__main__":
     gen_sample("fx_sample_tiny_hack", hack=True, dropout=False)
     gen_sample("fx_sample_tiny_masks", hack=True, dropout=True)
     gen_sample_refine()
+    gen_sample_artificial()
     with open(os.path.join(OUT, "fx_trace.json"), "w") as f:
         json.dump(t1, f)
     gen_stepper()
