@@ -301,9 +301,9 @@ int sdy_sfno_set_param(sdy_sfno* net, const char* name, const float* host, size_
 int sdy_sfno_ready(const sdy_sfno* net);
 const char* sdy_sfno_missing(const sdy_sfno* net);
 size_t sdy_sfno_workspace_floats(const sdy_sfno* net, int B);
-/* Largest B one sdy_sfno_forward call takes (32-bit offsets inside the spectral workspace: 258 rows at 180 x 360, embed 256 on
- * the default kernel path once the weights are loaded, 60 with row-major coefficient tensors); larger batches run as consecutive
- * calls on row ranges, each with its own batch_offset (the Python module does). */
+/* Largest B one sdy_sfno_forward call takes: 128 on the default kernel path (the drop-path row maps; the 32-bit offsets inside
+ * the spectral workspace would allow 258 rows at 180 x 360, embed 256), 60 there with row-major coefficient tensors; larger
+ * batches run as consecutive calls on row ranges, each with its own batch_offset (the Python module does). */
 int sdy_sfno_max_batch(const sdy_sfno* net);
 
 typedef struct sdy_sfno_fwd_args {

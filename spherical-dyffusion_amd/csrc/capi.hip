@@ -950,7 +950,7 @@ extern "C" size_t sdy_sfno_workspace_floats(const sdy_sfno* n, int B) {
 // Largest batch one sdy_sfno_forward call covers.  The kernels address rows as (wave-uniform 64-bit base) + (32-bit lane
 // offset).  On the default path of the production shape (tile-major spectral tensors: every block cs_tiled, below) the widest
 // 32-bit quantity is dh_h3's element offset inside a coefficient tensor, mtr * B * 8 * L * 64 < 2^32: 258 rows at 180 x 360
-// (sdy_dh_h3_launch refuses more).  With row-major coefficients (other shapes, the fallback switches) it is the Legendre
+// (sdy_dh_h3_launch refuses more; the offset is unsigned arithmetic).  With row-major coefficients (other shapes, the fallback switches) it is the Legendre
 // synthesis reading up to 192 degree rows of Cs[l][m][b][2E], whose row stride is mtr * 2 B E floats: 60 rows.
 extern "C" int sdy_sfno_max_batch(const sdy_sfno* n) {
   if (!n) return 0;
@@ -970,7 +970,10 @@ extern "C" int sdy_sfno_max_batch(const sdy_sfno* n) {
     const long per_row = 192L * mtr * 2 * c.embed_dim * 4 + 2L * c.embed_dim * 4;   // bytes of lane offset per batch row
     b = ((1L << 32) - 1) / per_row;
   }
-  if (b > 65535) b = 65535;
+  // No more rows than the drop-path row maps cover (SDY_MAP_MAX = 128): beyond it a forward would run unskipped, its workspace
+  // (0.8 GB per row at 180 x 360) outgrows what a window driver should hold at once, and no test runs a single native call
+  // there -- the Python network splits larger batches into near-equal calls (same call number, batch_offset + first row).
+  if (b > SDY_MAP_MAX) b = SDY_MAP_MAX;
   return b < 1 ? 1 : (int)b;
 }
 
