@@ -399,6 +399,7 @@ def main():
         torch.cuda.synchronize(device)
 
     digests = {}
+    relay_info = {}
 
     def digest(first_unit, x):
         """(sum, L2 norm) in float64 of every trajectory's final state: what `--digests` prints, so that runs with different
@@ -454,14 +455,11 @@ def main():
         for w in range(args.warmup):
             if q:
                 xr = run(xr, forc_r, plan.start, w)
-        if world > 1:                                  # the ring the hand-overs use: connections are set up outside the timed region
-            # (one batched send + receive: issued one after the other, two ranks that each send first would wait for each
-            #  other's receive on RCCL's per-pair stream)
-            ping, pong = torch.zeros(8, device=red_dev), torch.empty(8, device=red_dev)
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, ping, (rank + 1) % world),
-                                               dist.P2POp(dist.irecv, pong, (rank - 1) % world)]):
-                req.wait()
-        sends = []
+        # hand-overs: torch.distributed send / recv announced through the store (ensemble.RelayComm); the ring's pairs are
+        # connected outside the timed region with the same unbatched send / recv the hand-overs use
+        comm = ensemble.RelayComm(device=device) if world > 1 else None
+        if comm is not None:
+            comm.warm_up()
         state = {"res": xr}
 
         def resident_step(w):
@@ -476,27 +474,19 @@ def main():
                 x = run(x, forc1, unit, w)
             return x
 
-        def recv(task):
-            buf = torch.empty(x1.shape, dtype=x1.dtype, device=red_dev)
-            dist.recv(buf, src=task.src)
-            return buf.to(device)
-
-        def send(task, x):
-            t = x.to(red_dev).contiguous()
-            sends.append((dist.isend(t, dst=task.dst), t))
-
         firsts = {t.unit: initial_state(t.unit) for t in plan.tasks if t.src is None}
         barrier()
         t0 = time.perf_counter()
-        finals = ensemble.run_relay(plan, args.steps, resident_step, relay_step, lambda u: firsts[u], recv, send)
-        for req, _ in sends:
-            req.wait()
+        # the product's schedule (ensemble.RelayRunner, the one loop.run_inference(relay=) drives): a host advances a relay
+        # trajectory through the windows its resident batch has passed, as soon as the state is there
+        finals = ensemble.run_relay(plan, args.steps, resident_step, relay_step, lambda u: firsts[u], comm, like=lambda t: x1)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], device=red_dev, dtype=torch.float64)
+            tt = torch.tensor([dt, comm.recv_wait_s], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            dt = float(tt[0].item())
+            relay_info["recv_wait_s_max_over_ranks"] = round(float(tt[1].item()), 4)
         if q:
             assert torch.isfinite(state["res"]).all(), "non-finite state after the rollout"
             digest(plan.start, state["res"])
@@ -528,7 +518,8 @@ def main():
             all_digests = {str(k): v for k, v in digests.items()}
 
     if rank == 0:
-        B0 = parts[0][1] if args.scaling == "strong" else M
+        # the batch rank 0 actually ran: its resident block when the remainder is relayed (25 over 8: 3, not the 4 of a static split)
+        B0 = (M // world if relay else parts[0][1]) if args.scaling == "strong" else M
         res = {
             "metric": "forecast-steps/sec (180x360, 63ch), 25-member ensemble DYffusion sampling, whole job",
             "value": round(value, 3),
@@ -553,6 +544,7 @@ def main():
                 "members_per_gpu": ([M // world] * world if relay else [c for _, c in parts]) if args.scaling == "strong"
                 else [M] * world,
                 "relayed_members": (M % world) if (relay and args.scaling == "strong") else 0,
+                **({"relay": relay_info} if relay_info else {}),
                 "forecast_steps_per_step": n_traj * HORIZON,
                 "per_gpu_forecast_steps_per_s": round(value / world, 3),
                 "ensemble_steps_per_s": round(value / n_traj, 4),

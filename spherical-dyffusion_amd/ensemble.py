@@ -118,37 +118,177 @@ def relay_plan(n_units: int, world_size: int, n_windows: int, rank: int) -> Rela
     return RelayPlan(rank * q, q, tuple(tasks))
 
 
-def relay_due(task: RelayTask, resident: int) -> int:
-    """Resident window index before which a rank turns to a relay slice.  The slice's state arrives when its previous hosts
-    have advanced the trajectory through w_begin windows as a batch of ONE, which costs at most ~1.5 x a single trajectory's
-    share of a resident window; turning to it any earlier would only wait for the hand-over."""
-    return int(task.w_begin * min(1.0, 1.5 / max(resident, 1)))
+class RelayComm:
+    """Hand-over of a relay trajectory's state between ranks over `torch.distributed` point-to-point (RCCL over xGMI with the
+    "nccl" backend and device tensors; gloo with host tensors in the CPU tests and in `--share-gpu` test runs).
+
+    A receive is never posted before its send exists: the sender announces every message in the process group's store right
+    after `isend`, `ready(task, like)` is a non-blocking `store.check` of the next announcement (and takes the message when
+    it is there), and a blocking `recv(task, like)` only happens at the end of the job, when there is nothing left to overlap.  An early-posted RCCL receive would sit on the GPU
+    spinning for the whole time its sender needs to get there; this way the only wait is the sender's `isend`, which the
+    receiver picks up at its next window boundary.  `job` keys one run (ranks must agree on it: a counter per process).
+    """
+    _jobs = 0
+
+    def __init__(self, device=None, job=None):
+        import torch
+        import torch.distributed as dist
+
+        assert dist.is_initialized(), "RelayComm needs an initialised torch.distributed process group"
+        self._torch, self._dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.on_device = dist.get_backend() == "nccl"
+        self.device = torch.device(device) if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if self.on_device else torch.device("cpu"))
+        self.store = dist.distributed_c10d._get_default_store()
+        if job is None:
+            job = RelayComm._jobs
+            RelayComm._jobs += 1
+        self.job = job
+        self._sends = []
+        self._seq_out, self._seq_in, self._inbox = {}, {}, {}
+        self.recv_wait_s = 0.0        # time spent blocked in recv (the schedule's idle time on this rank)
+
+    def _key(self, src: int, dst: int, seq: int) -> str:
+        return f"sdy_relay/{self.job}/{src}>{dst}/{seq}"
+
+    def warm_up(self) -> None:
+        """Connects every (rank, rank + 1) pair of the ring with the SAME unbatched send / recv the hand-overs use (RCCL
+        creates a two-rank communicator per pair on first use: that belongs in front of a timed region).  Even ranks send
+        first, odd ranks receive first, so no two ranks wait for each other."""
+        if self.world < 2:
+            return
+        t, dist = self._torch, self._dist
+        dev = self.device if self.on_device else t.device("cpu")
+        ping, pong = t.zeros(8, device=dev), t.empty(8, device=dev)
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        if self.rank % 2 == 0:
+            dist.send(ping, nxt)
+            dist.recv(pong, prv)
+        else:
+            dist.recv(pong, prv)
+            dist.send(ping, nxt)
+
+    def send(self, task: "RelayTask", state) -> None:
+        """Non-blocking: the tensor is handed to the backend (a private copy) and announced in the store.  Messages of one
+        (source, destination) pair are numbered, and the announcement names the trajectory: the receiver takes them in the
+        order they were sent (RCCL matches point-to-point messages of a pair in order; it has no tags)."""
+        buf = state.detach().to(self.device if self.on_device else "cpu").contiguous().clone()
+        req = self._dist.isend(buf, dst=task.dst)
+        self._sends.append((req, buf))
+        seq = self._seq_out.get(task.dst, 0)
+        self._seq_out[task.dst] = seq + 1
+        self.store.set(self._key(self.rank, task.dst, seq), f"{task.unit},{task.w_end}")
+
+    def _take(self, src: int, like, block: bool) -> bool:
+        """Receives the next announced message of `src` into the inbox; False when none is announced (and not `block`)."""
+        import time
+
+        seq = self._seq_in.get(src, 0)
+        key = self._key(src, self.rank, seq)
+        if not block and not self.store.check([key]):
+            return False
+        t0 = time.perf_counter()
+        unit, w = (int(v) for v in self.store.get(key).decode().split(","))      # (store.get waits for the key)
+        buf = self._torch.empty(like.shape, dtype=like.dtype, device=self.device if self.on_device else "cpu")
+        self._dist.recv(buf, src=src)
+        self.recv_wait_s += time.perf_counter() - t0
+        self._seq_in[src] = seq + 1
+        self._inbox[(unit, w)] = buf
+        return True
+
+    def ready(self, task: "RelayTask", like) -> bool:
+        while (task.unit, task.w_begin) not in self._inbox and self._take(task.src, like, block=False):
+            pass
+        return (task.unit, task.w_begin) in self._inbox
+
+    def recv(self, task: "RelayTask", like):
+        """The state `task.src` sent for this slice (blocking until it has been announced and received); `like` gives shape /
+        dtype / device of the result."""
+        while (task.unit, task.w_begin) not in self._inbox:
+            self._take(task.src, like, block=True)
+        return self._inbox.pop((task.unit, task.w_begin)).to(like.device)
+
+    def finish(self) -> None:
+        for req, _ in self._sends:
+            req.wait()
+        self._sends.clear()
+
+
+class RelayRunner:
+    """One rank's relay work, driven from its window loop.  Policy: LOCKSTEP WITH CATCH-UP -- after the rank has seen window
+    w (its data has been loaded and its resident batch advanced), every hosted relay trajectory whose state is here is
+    advanced through all of its windows <= w; one whose state has not arrived yet is simply skipped (the resident batch goes
+    on) and catches up in one burst when it does.  No rank ever idles before the end of the job, nothing needs window data
+    the loader has not delivered yet, and a rank's total is q windows of the resident batch plus its slices of the relay
+    trajectories: the makespan of the ideal balanced schedule (tools/relay_projection.py simulates it).
+
+    `step(task, w, state) -> state` advances the trajectory through window w; `initial_state(task)` starts one;
+    `comm` is a `RelayComm` (or anything with send(task, state) / ready(task, like) / recv(task, like) / finish());
+    `like(task)` describes the state tensor a receive produces.  `pending_windows()` tells the caller which windows' data it still has to keep."""
+
+    def __init__(self, plan: RelayPlan, comm, step: Callable, initial_state: Callable, like: Callable):
+        self.plan, self.comm, self.step, self.initial_state, self.like = plan, comm, step, initial_state, like
+        self._todo = [{"task": t, "next": t.w_begin, "state": None, "have": False} for t in plan.tasks]
+        self.finals = {}
+        self.log: List[Tuple[int, int]] = []          # (unit, window) in the order they were advanced
+
+    def pending_windows(self) -> set:
+        return {w for e in self._todo for w in range(e["next"], e["task"].w_end)}
+
+    def _acquire(self, e, block: bool) -> bool:
+        if e["have"]:
+            return True
+        t = e["task"]
+        if t.src is None:
+            e["state"] = self.initial_state(t)
+        elif block or self.comm.ready(t, self.like(t)):
+            e["state"] = self.comm.recv(t, self.like(t))
+        else:
+            return False
+        e["have"] = True
+        return True
+
+    def _advance(self, e, upto: int) -> None:
+        t = e["task"]
+        while e["next"] <= min(upto, t.w_end - 1):
+            e["state"] = self.step(t, e["next"], e["state"])
+            self.log.append((t.unit, e["next"]))
+            e["next"] += 1
+        if e["next"] >= t.w_end:
+            if t.dst is None:
+                self.finals[t.unit] = e["state"]
+            else:
+                self.comm.send(t, e["state"])
+            e["state"] = None
+
+    def after_window(self, w: int) -> None:
+        """The caller has loaded window w (and advanced its resident batch through it)."""
+        for e in list(self._todo):
+            if e["task"].w_begin <= w and self._acquire(e, block=False):
+                self._advance(e, w)
+                if e["next"] >= e["task"].w_end:
+                    self._todo.remove(e)
+
+    def drain(self, last_window: int) -> dict:
+        """End of the job: whatever is still outstanding, in the order of the slices, with blocking receives."""
+        for e in sorted(self._todo, key=lambda e: (e["task"].w_begin, e["task"].unit)):
+            self._acquire(e, block=True)
+            self._advance(e, last_window)
+        self._todo.clear()
+        self.comm.finish()
+        return self.finals
 
 
 def run_relay(plan: RelayPlan, n_windows: int, resident_step: Callable[[int], None],
               relay_step: Callable[[RelayTask, int, object], object], initial_state: Callable[[int], object],
-              recv: Callable[[RelayTask], object], send: Callable[[RelayTask, object], None]) -> dict:
-    """Drives one rank through its plan: `resident_step(w)` advances the resident batch through window w;
-    `relay_step(task, w, state) -> state` advances a relay trajectory through window w; `recv(task)` / `send(task, state)`
-    move a relay trajectory's state between ranks (blocking receive, non-blocking send); `initial_state(unit)` starts one.
-    Returns {unit: final state} for the relay trajectories that END on this rank."""
-    finals = {}
-    pending = list(plan.tasks)
-
-    def run(task: RelayTask):
-        state = initial_state(task.unit) if task.src is None else recv(task)
-        for w in range(task.w_begin, task.w_end):
-            state = relay_step(task, w, state)
-        if task.dst is None:
-            finals[task.unit] = state
-        else:
-            send(task, state)
-
+              comm, like: Optional[Callable] = None) -> dict:
+    """Drives one rank through its plan when windows need no loader (bench.py's sampler-only job, tests): `resident_step(w)`
+    advances the resident batch through window w, the `RelayRunner` policy does the rest.  Returns {unit: final state} for
+    the relay trajectories that END on this rank."""
+    runner = RelayRunner(plan, comm, relay_step, lambda t: initial_state(t.unit), like or (lambda t: None))
     for w in range(n_windows):
-        while pending and (plan.count == 0 or relay_due(pending[0], plan.count) <= w):
-            run(pending.pop(0))
         if plan.count > 0:
             resident_step(w)
-    while pending:
-        run(pending.pop(0))
-    return finals
+        runner.after_window(w)
+    return runner.drain(n_windows - 1)

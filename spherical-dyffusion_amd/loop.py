@@ -265,7 +265,7 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
                   n_ensemble_members: int = 1, eval_device=None, writer=None, derive: Optional[Callable] = None,
                   host_outputs: bool = False, trajectory_offset: int = 0,
                   unit_range: Optional[Tuple[int, int]] = None, prefetch: int = 2,
-                  max_batch: Optional[int] = None) -> Dict[str, float]:
+                  max_batch: Optional[int] = None, relay=None, relay_comm=None) -> Dict[str, float]:
     """`data`: an object with `.loader` (iterable of windows with `.data`: name -> (n_sample, steps + 1, H, W) and
     `.times`) or such an iterable.
 
@@ -276,8 +276,18 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
         initial conditions over ranks, `data_loading/inference.py:110-113`);
       * `unit_range=(start, count)`: run only global trajectories start ... start + count - 1 (`ensemble.shard`) - members of
         ONE initial condition split over ranks, or any ragged share of ICs x members.  Writer / aggregator then receive
-        flat `(count, time, H, W)` predictions with `start_sample=start`, targets for the initial conditions touched.
-    Without `unit_range` every member of every initial condition present runs and predictions are presented as the
+        flat `(count, time, H, W)` predictions with `start_sample=start`, targets for the initial conditions touched;
+      * `relay=ensemble.relay_plan(n_trajectories, world, n_windows, rank)` (+ `relay_comm`, default
+        `ensemble.RelayComm()` over the initialised process group): the job's trajectories do not divide by the ranks (25
+        members over 8 GPUs).  This rank runs the plan's resident block like a `unit_range` share for the whole job; each
+        remainder trajectory is RELAYED: it visits the ranks in turn, every host advancing it through its slice of the windows
+        as a batch of one (own `batch_offset`, the window's own dropout call numbers: the samples are those of the unsharded
+        job) and handing the stitcher's carried state to the next host with one send / recv.  A host turns to a relay window
+        once it has loaded that window itself and the state is there (`ensemble.RelayRunner`: lockstep with catch-up), so the
+        loader is consumed in order and no rank waits before the end of the job.  Relay rows reach writer / aggregator as
+        flat one-row batches (`start_sample` = the trajectory's global index), window by window, from whichever rank hosts
+        them; the windows must hold the relay trajectories' initial conditions as well.
+    Without `unit_range` / `relay` every member of every initial condition present runs and predictions are presented as the
     reference stacks them: `(members, n_sample, time, H, W)`.
 
     `prefetch`: windows pulled ahead of the compute on a background thread (0 = pull each window on the calling thread, after
@@ -298,6 +308,12 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
         raise RuntimeError("sdy_amd.run_inference runs on the GPU only (no CPU fallback)")
     if max_batch is not None and max_batch < 1:
         raise ValueError(f"max_batch must be >= 1, got {max_batch}")
+    if relay is not None:
+        if unit_range is not None:
+            raise ValueError("relay= carries the rank's resident block: do not pass unit_range as well")
+        if not hasattr(stepper.module, "set_dropout_calls"):
+            raise ValueError("relay= needs a module whose dropout call counters can be set (set_dropout_calls)")
+        unit_range = (relay.start, relay.count)
     if host_outputs:
         writer = _DeferredHostWriter(writer, dev)
     stitcher = WindowStitcher(n_forward_steps, writer, is_ensemble=ens)
@@ -305,17 +321,15 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
     timers: Dict[str, float] = defaultdict(float)
     t_begin = now = time.time()
     module = stepper.module
-    n_rows = 0
     prefetcher = _WindowPrefetcher(loader, dev, prefetch) if prefetch > 0 else None
     windows = prefetcher if prefetcher is not None else _sync_windows(loader, dev)
-    device_spans = []          # (start event, end event) around each window's device work
-    pending = None             # the previous window's record_batch, issued once ITS loss has arrived (no drain of this one)
+    device_spans = []          # (start event, end event) around each batch's device work
+    pending: List[tuple] = []  # record_batch calls waiting for THEIR loss terms (flushed one batch later: no drain)
+    unit_steps = 0             # trajectories x forecast steps advanced by this process
 
     def flush(p):
         # A window reaches the writer and the aggregator only after its loss terms and the device's sticky status word have
         # arrived: a window a kernel flagged (fp16 range overflow, non-finite statistics) raises HERE, before either sees it.
-        if p is None:
-            return
         out, i_time_agg, weights, write = p
         loss = float(out.metrics["loss"])      # waits for the window's read-back; raises SdyError on a flagged window
         write()
@@ -325,99 +339,178 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
                                 target_data_norm=out.target_data_norm, gen_data_norm=out.gen_data_norm,
                                 i_time_start=i_time_agg, **kw)
 
+    def hand_over(entry):
+        # batch k - 1: its loss arrived long ago; the device is busy with batch k meanwhile
+        pending.append(entry)
+        while len(pending) > (1 if prefetch > 0 else 0):
+            flush(pending.pop(0))
+
+    def advance(window, win, i, rows_range, stitch, calls0):
+        """One device batch of window i: the global trajectories `rows_range` (None: every member of every initial condition
+        present) through the stepper, stitched by `stitch`; `calls0`: the dropout call counters window i starts from."""
+        nonlocal unit_steps
+        i_time = i * forward_steps_in_memory
+        cur = torch.cuda.current_stream(dev)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(cur)
+        n_sample = next(iter(win.values())).shape[0]
+        start, n_rows, ic_list, _, rect = plan_rows(n_sample, members, trajectory_offset, rows_range)
+        ic_rows = torch.tensor(ic_list, dtype=torch.long, device=dev)
+        # IC-major batch: row r is global trajectory start + r = (IC ic_rows[r], member (start + r) % members)
+        batch = {k: v.index_select(0, ic_rows) for k, v in win.items()}
+        # the stitcher carries targets for the initial conditions this process touches (all of them unless ragged)
+        stitch.apply_initial_condition(batch, ic_rows if rect else ic_rows - ic_list[0])
+        step = n_rows if max_batch is None else min(n_rows, int(max_batch))
+        parts = []
+        for r0 in range(0, n_rows, step):
+            r1 = min(n_rows, r0 + step)
+            if hasattr(module, "set_batch_offset"):
+                module.set_batch_offset(start + r0)
+            if calls0 is not None:      # every chunk of the window replays the same call numbers of the dropout streams
+                module.set_dropout_calls(calls0)
+            chunk = batch if (r0 == 0 and r1 == n_rows) else {k: v[r0:r1] for k, v in batch.items()}
+            parts.append((r1 - r0, stepper.run_on_batch(chunk, None, n_forward_steps=forward_steps_in_memory,
+                                                        defer_metrics=True)))
+        if len(parts) == 1:
+            stepped = parts[0][1]
+        else:
+            cat = lambda name: {k: torch.cat([getattr(s, name)[k] for _, s in parts], dim=0)  # noqa: E731
+                                for k in getattr(parts[0][1], name)}
+            stepped = SteppedData(metrics=_ChunkedMetrics([(r, s.metrics) for r, s in parts]), gen_data=cat("gen_data"),
+                                  target_data=batch, gen_data_norm=cat("gen_data_norm"),
+                                  target_data_norm=cat("target_data_norm"))
+        del parts
+        last_state = {k: v[:, -1] for k, v in stepped.gen_data.items()}
+        weights = None
+        if rect:       # present like the reference: members on a leading axis (a strided view, no copy)
+            ics = slice(None)
+            unfold = (lambda d: {k: v.view(n_sample, members, *v.shape[1:]).transpose(0, 1) for k, v in d.items()}) \
+                if ens else (lambda d: d)
+            first = slice(0, n_rows, members)
+        else:          # a ragged share: flat rows, targets of the initial conditions touched
+            ics = slice(ic_list[0], ic_list[-1] + 1)
+            unfold = lambda d: d  # noqa: E731
+            touched = list(range(ic_list[0], ic_list[-1] + 1))
+            first = torch.tensor([ic_list.index(c) for c in touched], device=dev)
+            # share of each touched initial condition's members that runs in THIS batch: what its targets weigh in a mean
+            # over batches and ranks (an initial condition cut by a shard boundary is touched more than once)
+            weights = [ic_list.count(c) / members for c in touched]
+        flat = not rect
+        win_t = {k: v[ics] for k, v in win.items()}
+        target_data = derive(win_t) if derive is not None else win_t
+        gen_data, gen_norm = unfold(stepped.gen_data), unfold(stepped.gen_data_norm)
+        if derive is not None:
+            gen_data = derive(gen_data)
+        tgt_norm = {k: v[first] for k, v in stepped.target_data_norm.items()}
+        out = SteppedData(metrics=stepped.metrics, gen_data=gen_data, target_data=target_data, gen_data_norm=gen_norm,
+                          target_data_norm=tgt_norm)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(cur)
+        device_spans.append((ev0, ev1))
+        unit_steps += n_rows * forward_steps_in_memory
+        # ---- _inference_internal_loop (loop.py:120-153)
+        times = window.times
+        stacked = ens and not flat
+        if i_time > 0:
+            out = SteppedData(metrics=out.metrics, gen_data=_remove_ic(out.gen_data, stacked),
+                              target_data={k: v[:, 1:] for k, v in out.target_data.items()},
+                              gen_data_norm=_remove_ic(out.gen_data_norm, stacked),
+                              target_data_norm={k: v[:, 1:] for k, v in out.target_data_norm.items()})
+            if times is not None and hasattr(times, "isel"):
+                times = times.isel(time=slice(1, None))
+            i_time_agg = i_time + 1
+        else:
+            i_time_agg = i_time
+        # the carry-over for window i + 1 is taken now; the hand-off to the writer waits for the window's status word
+        write = stitch.append(out.target_data, out.gen_data, times, last_state=last_state,
+                              start_sample=start if flat else 0, defer_write=True)
+        return out, i_time_agg, weights, write
+
+    # ---- relayed remainder trajectories (ensemble.RelayRunner drives relay_step at window boundaries)
+    runner = None
+    retained: Dict[int, tuple] = {}        # window index -> (window, device tensors, last time step of the window before)
+    calls_base = module.dropout_calls() if hasattr(module, "dropout_calls") else None
+    calls_per_window = None
+
+    def calls_at(w):
+        return tuple(b + w * d for b, d in zip(calls_base, calls_per_window)) if w > 0 else tuple(calls_base)
+
+    if relay is not None and relay.tasks:
+        from . import ensemble
+
+        comm = relay_comm if relay_comm is not None else ensemble.RelayComm(device=dev)
+        relay_stitch: Dict[int, WindowStitcher] = {}
+        gen_names: List[str] = list(stepper.out_names)
+
+        def pack_state(st):        # the stitcher's carried generated state of a one-row batch: (variables, H, W)
+            return torch.stack([st._carry_gen[k][0] for k in gen_names], dim=0)
+
+        def state_like(task):
+            any_win = next(iter(retained.values()))[1]
+            h, wd = next(iter(any_win.values())).shape[-2:]
+            return torch.empty(len(gen_names), h, wd, dtype=torch.float32, device=dev)
+
+        def relay_step(task, w, state):
+            window, win, prev_last = retained[w]
+            st = relay_stitch.get(task.unit)
+            if st is None:          # the trajectory arrives here: a stitcher that stands where window w begins
+                st = relay_stitch[task.unit] = WindowStitcher(n_forward_steps, writer, is_ensemble=ens)
+                if w > 0:
+                    ic = task.unit // members - trajectory_offset
+                    st.i_time = w * forward_steps_in_memory + 1
+                    st._carry_gen = {k: state[j:j + 1] for j, k in enumerate(gen_names)}
+                    st._carry_target = {k: v[ic:ic + 1] for k, v in prev_last.items()}
+            # (the window's own call numbers; the resident batch sets its own again at its next window)
+            hand_over(advance(window, win, w, (task.unit, 1), st, calls_at(w)))
+            if w + 1 >= task.w_end:          # the slice ends: what travels is the stitcher's carried generated state
+                relay_stitch.pop(task.unit)
+                return pack_state(st) if w + 1 < n_windows else None
+            return state
+
+        runner = ensemble.RelayRunner(relay, comm, relay_step, lambda task: None, state_like)
+    n_windows = n_forward_steps // forward_steps_in_memory
+    last_step = None           # last time step of the previous window's data (a relay trajectory's carried targets)
+
     try:
         for i, (window, win) in enumerate(windows):
             timers["data_loading"] += time.time() - now
             now = time.time()
-            i_time = i * forward_steps_in_memory
-            cur = torch.cuda.current_stream(dev)
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev0.record(cur)
-            n_sample = next(iter(win.values())).shape[0]
-            start, n_rows, ic_list, _, rect = plan_rows(n_sample, members, trajectory_offset, unit_range)
-            ic_rows = torch.tensor(ic_list, dtype=torch.long, device=dev)
-            # IC-major batch: row r is global trajectory start + r = (IC ic_rows[r], member (start + r) % members)
-            batch = {k: v.index_select(0, ic_rows) for k, v in win.items()}
-            # the stitcher carries targets for the initial conditions this process touches (all of them unless ragged)
-            stitcher.apply_initial_condition(batch, ic_rows if rect else ic_rows - ic_list[0])
-            step = n_rows if max_batch is None else min(n_rows, int(max_batch))
-            parts = []
-            calls0 = module.dropout_calls() if hasattr(module, "dropout_calls") else None
-            for r0 in range(0, n_rows, step):
-                r1 = min(n_rows, r0 + step)
-                if hasattr(module, "set_batch_offset"):
-                    module.set_batch_offset(start + r0)
-                if calls0 is not None:      # every chunk of the window replays the same call numbers of the dropout streams
-                    module.set_dropout_calls(calls0)
-                chunk = batch if (r0 == 0 and r1 == n_rows) else {k: v[r0:r1] for k, v in batch.items()}
-                parts.append((r1 - r0, stepper.run_on_batch(chunk, None, n_forward_steps=forward_steps_in_memory,
-                                                            defer_metrics=True)))
-            if len(parts) == 1:
-                stepped = parts[0][1]
+            calls0 = None
+            if calls_base is not None:
+                # (relay work in between moves the module's counters: with a relay every window starts from its own call
+                #  numbers, base + i x the calls of one window)
+                calls0 = calls_at(i) if (runner is not None and (calls_per_window is not None or i == 0)) \
+                    else module.dropout_calls()
+            if unit_range is None or unit_range[1] > 0:
+                entry = advance(window, win, i, unit_range, stitcher, calls0)
             else:
-                cat = lambda name: {k: torch.cat([getattr(s, name)[k] for _, s in parts], dim=0)  # noqa: E731
-                                    for k in getattr(parts[0][1], name)}
-                stepped = SteppedData(metrics=_ChunkedMetrics([(r, s.metrics) for r, s in parts]), gen_data=cat("gen_data"),
-                                      target_data=batch, gen_data_norm=cat("gen_data_norm"),
-                                      target_data_norm=cat("target_data_norm"))
-            del parts
-            last_state = {k: v[:, -1] for k, v in stepped.gen_data.items()}
-            weights = None
-            if rect:       # present like the reference: members on a leading axis (a strided view, no copy)
-                ics = slice(None)
-                unfold = (lambda d: {k: v.view(n_sample, members, *v.shape[1:]).transpose(0, 1) for k, v in d.items()}) \
-                    if ens else (lambda d: d)
-                first = slice(0, n_rows, members)
-            else:          # a ragged share: flat rows, targets of the initial conditions touched
-                ics = slice(ic_list[0], ic_list[-1] + 1)
-                unfold = lambda d: d  # noqa: E731
-                touched = list(range(ic_list[0], ic_list[-1] + 1))
-                first = torch.tensor([ic_list.index(c) for c in touched], device=dev)
-                # share of each touched initial condition's members that runs HERE: what its targets weigh in a mean over
-                # ranks (an initial condition cut by the shard boundary is touched by two ranks)
-                weights = [ic_list.count(c) / members for c in touched]
-            flat = not rect
-            win = {k: v[ics] for k, v in win.items()}
-            target_data = derive(win) if derive is not None else win
-            gen_data, gen_norm = unfold(stepped.gen_data), unfold(stepped.gen_data_norm)
-            if derive is not None:
-                gen_data = derive(gen_data)
-            tgt_norm = {k: v[first] for k, v in stepped.target_data_norm.items()}
-            out = SteppedData(metrics=stepped.metrics, gen_data=gen_data, target_data=target_data, gen_data_norm=gen_norm,
-                              target_data_norm=tgt_norm)
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev1.record(cur)
-            device_spans.append((ev0, ev1))
+                entry = None
+            if calls_base is not None and calls_per_window is None and entry is not None:
+                calls_per_window = tuple(b - a for a, b in zip(calls0, module.dropout_calls()))
             if prefetch <= 0:      # the reference's timer semantics: the window is complete when the clock is read
-                cur.synchronize()
+                torch.cuda.current_stream(dev).synchronize()
             timers["run_on_batch_host"] += time.time() - now
             now = time.time()
-            # ---- _inference_internal_loop (loop.py:120-153)
-            times = window.times
-            stacked = ens and not flat
-            if i_time > 0:
-                out = SteppedData(metrics=out.metrics, gen_data=_remove_ic(out.gen_data, stacked),
-                                  target_data={k: v[:, 1:] for k, v in out.target_data.items()},
-                                  gen_data_norm=_remove_ic(out.gen_data_norm, stacked),
-                                  target_data_norm={k: v[:, 1:] for k, v in out.target_data_norm.items()})
-                if times is not None and hasattr(times, "isel"):
-                    times = times.isel(time=slice(1, None))
-                i_time_agg = i_time + 1
-            else:
-                i_time_agg = i_time
-            # the carry-over for window i + 1 is taken now; the hand-off to the writer waits for the window's status word
-            write = stitcher.append(out.target_data, out.gen_data, times, last_state=last_state,
-                                    start_sample=start if flat else 0, defer_write=True)
-            flush(pending)         # window i - 1: its loss arrived long ago; the device is busy with window i meanwhile
-            pending = (out, i_time_agg, weights, write)
-            if prefetch <= 0:
-                flush(pending)
-                pending = None
-            del stepped, out
+            if entry is not None:
+                hand_over(entry)
+                del entry
+            if runner is not None:
+                # a window some hosted slice still has to go through stays (its device tensors; a slice whose state has not
+                # arrived yet catches up later), with the last time step of the window before it
+                if i in runner.pending_windows():
+                    retained[i] = (window, win, last_step)
+                last_step = {k: v[:, -1].clone() for k, v in win.items()}
+                runner.after_window(i)
+                keep = runner.pending_windows()
+                for w in [w for w in retained if w not in keep]:
+                    del retained[w]
             timers["writer_and_aggregator"] += time.time() - now
             now = time.time()
-        flush(pending)
-        pending = None
+        if runner is not None:
+            runner.drain(n_windows - 1)
+            timers["relay_recv_wait"] = getattr(runner.comm, "recv_wait_s", 0.0)
+        while pending:
+            flush(pending.pop(0))
     finally:
         if prefetcher is not None:
             prefetcher.close()
@@ -425,15 +518,15 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
         writer.flush()
     torch.cuda.current_stream(dev).synchronize()
     timers["writer_and_aggregator"] += time.time() - now
-    timers["run_on_batch"] = sum(a.elapsed_time(b) for a, b in device_spans) * 1e-3     # device time of the windows
+    timers["run_on_batch"] = sum(a.elapsed_time(b) for a, b in device_spans) * 1e-3     # device time of the batches
     wall = time.time() - t_begin
     timers["wall"] = wall
-    units = stitcher.i_time * max(n_rows, 1)
+    timers["trajectory_steps"] = float(unit_steps)         # trajectories x forecast steps this process advanced
     if wall > 0:
         # the reference logs n_forward_steps x n_ICs over the whole duration (inference.py:294-298); here: x trajectories
-        timers["forecast_steps_per_second"] = units / wall
+        timers["forecast_steps_per_second"] = unit_steps / wall
     if timers["run_on_batch"] > 0:
-        timers["forecast_steps_per_second_run_on_batch"] = units / timers["run_on_batch"]
+        timers["forecast_steps_per_second_run_on_batch"] = unit_steps / timers["run_on_batch"]
     for name, duration in timers.items():
-        print(f"{name}: {duration:.2f}" + ("" if "per_second" in name else "s"))
+        print(f"{name}: {duration:.2f}" + ("" if ("per_second" in name or name == "trajectory_steps") else "s"))
     return dict(timers)

@@ -182,41 +182,38 @@ def _advance(x, unit, w):
     return x * 1.0001 + torch.sin(torch.arange(4, dtype=torch.float64) + 7.0 * unit + 0.37 * w) * (1.0 + x.abs().sum())
 
 
-def _relay_worker(rank, world, port, n_units, n_windows, ret):
+def _relay_worker(rank, world, port, n_units, n_windows, delays, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
+    import time
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from sdy_amd import ensemble
 
     plan = ensemble.relay_plan(n_units, world, n_windows, rank)
     res = {u: torch.full((4,), float(u), dtype=torch.float64) for u in range(plan.start, plan.start + plan.count)}
-    log, sends = [], []
+    log = []
 
     def resident_step(w):
         for u in res:
             res[u] = _advance(res[u], u, w)
         log.append(("res", w))
+        if delays:                      # skewed ranks: some run ahead of their neighbours, some behind
+            time.sleep(delays[rank])
 
     def relay_step(task, w, x):
+        assert ("res", w) in log or plan.count == 0, "a relay window is advanced only after the rank has seen that window"
         log.append(("relay", task.unit, w))
         return _advance(x, task.unit, w)
 
-    def recv(task):
-        buf = torch.empty(4, dtype=torch.float64)
-        dist.recv(buf, src=task.src)
-        return buf
-
-    def send(task, x):
-        sends.append((dist.isend(x.clone(), dst=task.dst), x))
-
+    comm = ensemble.RelayComm()         # the product's transport: isend / recv announced through the group's store (gloo here)
+    comm.warm_up()
     finals = ensemble.run_relay(plan, n_windows, resident_step, relay_step,
-                                lambda u: torch.full((4,), float(u), dtype=torch.float64), recv, send)
-    for req, _ in sends:
-        req.wait()
+                                lambda u: torch.full((4,), float(u), dtype=torch.float64), comm,
+                                like=lambda task: torch.empty(4, dtype=torch.float64))
     out = dict(res)
     out.update(finals)
-    ret[rank] = (plan, out, log)
+    ret[rank] = (plan, out, log, comm.recv_wait_s)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -232,19 +229,23 @@ def _serial(n_units, n_windows):
 
 
 def test_relayed_remainder_trajectories_equal_the_unsharded_run():
-    """ensemble.relay_plan / run_relay: 5 trajectories over 2 ranks = 2 resident each + ONE relayed in two time slices (the
-    25-over-8 case in miniature: 3 resident each + one relayed through 8 slices); 7 over 3 = 2 each + one relayed; with real
-    send / recv between the ranks (gloo).  Every trajectory's final state equals the serial run bit for bit, every
-    (trajectory, window) is advanced exactly once, and the work is even."""
-    for world, n_units, n_windows in ((2, 5, 6), (3, 7, 7), (3, 8, 5)):
+    """ensemble.relay_plan / RelayRunner / RelayComm: 5 trajectories over 2 ranks = 2 resident each + ONE relayed in two time
+    slices (the 25-over-8 case in miniature: 3 resident each + one relayed through 8 slices); 7 over 3 = 2 each + one relayed;
+    8 over 3 = 2 each + TWO relayed (their chains start on different ranks and wrap around the ring); with the product's
+    transport between the ranks (gloo here, RCCL on GPUs) and with ranks that run at different speeds, so that states arrive
+    early on some hosts and late on others.  Every trajectory's final state equals the serial run bit for bit, every
+    (trajectory, window) is advanced exactly once -- a relay window never before its host has seen that window -- and the
+    work is even."""
+    for world, n_units, n_windows, delays in ((2, 5, 6, None), (3, 7, 7, None), (3, 8, 5, None), (3, 7, 6, (0.0, 0.03, 0.0)),
+                                              (3, 8, 6, (0.03, 0.0, 0.01))):
         port = _free_port()
         mgr = mp.Manager()
         ret = mgr.dict()
-        mp.spawn(_relay_worker, args=(world, port, n_units, n_windows, ret), nprocs=world, join=True)
+        mp.spawn(_relay_worker, args=(world, port, n_units, n_windows, delays, ret), nprocs=world, join=True)
         want = _serial(n_units, n_windows)
         got, seen, load = {}, [], []
         for r in range(world):
-            plan, out, log = ret[r]
+            plan, out, log, _ = ret[r]
             assert plan.count == n_units // world
             got.update(out)
             seen += [(u, w) for kind, *rest in log if kind == "res" for w in rest for u in range(plan.start, plan.start + plan.count)]
@@ -255,6 +256,26 @@ def test_relayed_remainder_trajectories_equal_the_unsharded_run():
             assert torch.equal(got[u], want[u]), (world, n_units, u)
         assert sorted(seen) == [(u, w) for u in range(n_units) for w in range(n_windows)]
         assert max(load) - min(load) <= (n_units % world) * (-(-n_windows // world)), load
+
+
+def test_relay_schedule_reaches_the_balanced_makespan():
+    """The lockstep-with-catch-up policy of RelayRunner, simulated with the measured one-GPU pass times (tools/relay_projection.py):
+    no rank idles before the end of the job, so the job takes what the most loaded rank's own work takes -- q resident windows
+    each plus its slices of the relay trajectory -- against the 4-member rank's 20 windows of a static split."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(
+        "relay_projection", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "relay_projection.py"))
+    rp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rp)
+    t = {1: 51.0, 3: 126.6, 4: 164.1, 6: 239.0, 7: 277.3, 12: 466.9, 13: 502.9}
+    for world in (2, 4, 8):
+        makespan, finish = rp.simulate(25, world, 20, t)
+        q = 25 // world
+        own = [20 * t[q] + sum(tk.w_end - tk.w_begin for tk in rp.ensemble.relay_plan(25, world, 20, r).tasks) * t[1]
+               for r in range(world)]
+        assert abs(makespan - max(own)) < 1e-6 * makespan, (world, makespan, max(own))
+        assert makespan < 20 * t[q + 1]                      # the static split's pace
 
 
 def test_relay_plan_of_the_headline_job():

@@ -643,6 +643,27 @@ def test_interpolator_pair_with_shared_encoder_equals_two_full_forwards(hack):
         net2(torch.zeros(1, 4, 32, 64).cuda(), reuse_encoder=True)
 
 
+class _MailboxComm:
+    """RelayComm stand-in for ranks played one after the other in ONE process (the hosts of a single relay trajectory follow
+    the rank order, so every state is in the box before its receiver runs); the transport itself -- torch.distributed send /
+    recv with the store handshake -- is covered by tests/test_distributed_cpu.py."""
+
+    def __init__(self, box):
+        self.box = box
+
+    def send(self, task, state):
+        self.box[(task.unit, task.w_end)] = state.clone()
+
+    def ready(self, task, like):
+        return (task.unit, task.w_begin) in self.box
+
+    def recv(self, task, like):
+        return self.box.pop((task.unit, task.w_begin))
+
+    def finish(self):
+        pass
+
+
 def test_relayed_remainder_member_equals_the_unsharded_ensemble():
     """ensemble.relay_plan / run_relay with the REAL sampler (dropout and drop path on): 7 members x 6 windows as one batch of
     seven, and as three ranks' plans -- two resident members each and member 6 relayed through the ranks in slices of two
@@ -694,10 +715,73 @@ def test_relayed_remainder_member_equals_the_unsharded_ensemble():
             return xs
 
         finals = ensemble.run_relay(plan, n_windows, resident_step, relay_step, lambda u: x0[u:u + 1].clone(),
-                                    lambda task: mailbox.pop((task.src, rank, task.unit)),
-                                    lambda task, xs: mailbox.__setitem__((rank, task.dst, task.unit), xs.clone()))
+                                    _MailboxComm(mailbox), like=lambda task: x0[:1])
         assert (rank == world - 1) == (6 in finals)
     assert not mailbox and sorted(seen) == [(u, w) for u in range(n_units) for w in range(n_windows)]
     for (u, w), v in seen.items():
         e = rel_l2(v[0], full[w][u])
         assert e < 2e-5 * (4 ** w), f"trajectory {u}, window {w}: rel L2 {e:.3e}"
+
+
+def test_window_driver_relays_the_remainder_trajectory():
+    """The relay in the PRODUCT driver: `run_inference(relay=ensemble.relay_plan(...))` -> stepper -> sampler (dropout and drop
+    path on) -> SFNO, 7 members of one initial condition over 6 windows of 6 steps, as the unsharded job and as three ranks'
+    plans (two resident members each, member 6 relayed through the ranks in slices of two windows: the 25-over-8 schedule in
+    miniature).  Every prediction any rank's writer receives -- resident rows and relay rows, window by window -- must be the
+    unsharded job's field of that (trajectory, time step); every (trajectory, window) is written exactly once; and the ranks'
+    time-mean sums add up to the unsharded aggregator's.  Ranks are played one after the other with a mailbox for the
+    hand-overs; tools/c4_rollout.py --gpus N runs the same call over torch.distributed (tests/test_gpu_fullsize.py)."""
+    import sdy_amd
+    from sdy_amd import ensemble, synthetic
+
+    dev = torch.device("cuda", 0)
+    n_out, n_forc, nlat, nlon, window, n_windows, members, world = 4, 2, 32, 64, 6, 6, 7, 3
+    exp, _, _ = synthetic.build_sampler(dev, state_chans=n_out, forcing_chans=n_forc, nlat=nlat, nlon=nlon, embed=16, layers=2,
+                                        horizon=6, carried_input_only_channel=True)
+    stepper, names, out_names = synthetic.build_stepper(exp, n_out, n_forc, carried_input_only_channel=True)
+    steps = window * n_windows
+    area = sdy_amd.metrics.spherical_area_weights(torch.linspace(-89.5, 89.5, nlat), nlon)
+
+    class Writer:
+        def __init__(self):
+            self.fields, self.targets = {}, {}
+
+        def append_batch(self, target, prediction, start_timestep, start_sample, batch_times=None):
+            v = prediction[out_names[1]]
+            if v.dim() == 5:                       # (members, n_sample, time, H, W): the unsharded presentation
+                v = v[:, 0]
+            for r in range(v.shape[0]):
+                for t in range(v.shape[1]):
+                    key = (start_sample + r, start_timestep + t)
+                    assert key not in self.fields, f"trajectory / time step {key} written twice"
+                    self.fields[key] = v[r, t].clone()
+
+    def job(**kw):
+        exp.set_dropout_calls((0, 0))
+        wr = Writer()
+        agg = sdy_amd.metrics.TimeMeanAggregator(area, is_ensemble=True)
+        t = sdy_amd.run_inference(agg, stepper, synthetic.windows(names, n_windows, window, nlat, nlon, seed=5), steps, window,
+                                  n_ensemble_members=members, eval_device=dev, writer=wr, **kw)
+        return wr, agg, t
+
+    full, agg_full, _ = job()
+    assert len(full.fields) == members * (steps + 1)
+    box, seen, gen_sum, gen_rows = {}, {}, None, 0.0
+    for rank in range(world):
+        plan = ensemble.relay_plan(members, world, n_windows, rank)
+        assert plan.count == 2 and [t.unit for t in plan.tasks] == [6]
+        wr, agg, timers = job(relay=plan, relay_comm=_MailboxComm(box))
+        assert timers["forecast_steps_per_second"] > 0
+        assert not (set(wr.fields) & set(seen))
+        seen.update(wr.fields)
+        gen_sum = agg._gen_data[out_names[1]].double() if gen_sum is None else gen_sum + agg._gen_data[out_names[1]].double()
+        gen_rows += agg._gen_rows
+    assert not box
+    assert sorted(seen) == sorted(full.fields)                       # every (trajectory, time step) exactly once
+    worst = 0.0
+    for (u, t), v in seen.items():
+        e = rel_l2(v, full.fields[(u, t)])
+        worst = max(worst, e)
+        assert e < 2e-5 * (4 ** (t // window)), f"trajectory {u}, time step {t}: rel L2 {e:.3e}"
+    assert gen_rows == agg_full._gen_rows
+    assert rel_l2(gen_sum, agg_full._gen_data[out_names[1]].double()) < 1e-4

@@ -350,23 +350,36 @@ def test_rccl_path_when_two_devices_are_visible():
     assert "TEST MODE" not in res["data"]
 
 
-def test_c4_rollout_two_ranks_shared_gpu():
-    """`tools/c4_rollout.py --gpus 2 --share-gpu`: the C4 / C5 runner's own N > 1 path (run_inference(unit_range=shard),
-    TimeMeanAggregator combined over ranks) as a fresh self-launching subprocess on a small network."""
+def test_c4_rollout_two_and_three_ranks_shared_gpu():
+    """`tools/c4_rollout.py --gpus N --share-gpu`: the C4 / C5 runner's own N > 1 path as fresh self-launching subprocesses on a
+    small network -- `run_inference(relay=ensemble.relay_plan(...))` with the hand-overs over torch.distributed (gloo here,
+    RCCL on N GPUs): 5 members over 2 ranks = 2 resident each + one relayed, 7 over 3 = 2 each + one relayed through three
+    hosts; `--no-relay` = `run_inference(unit_range=shard)`, the static 3 + 2 split.  The ranks' time-mean maps, summed over
+    ranks with their row counts, reproduce the one-process statistics whatever the schedule."""
     import json
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    base = [sys.executable, os.path.join(root, "tools", "c4_rollout.py"), "--steps", "12", "--members", "5", "--layers", "2",
-            "--embed", "16", "--grid", "32", "64"]
-    one = subprocess.run(base, cwd=root, capture_output=True, text=True, timeout=900)
-    assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run(base + ["--gpus", "2", "--share-gpu"], cwd=root, capture_output=True, text=True, timeout=900)
-    assert two.returncode == 0, two.stderr[-2000:]
-    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
-    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
-    assert r1["finite"] and r2["finite"] and r2["n_gpus"] == 2 and r2["rows"] == 3 and r1["rows"] == 5
-    # the ranks' time-mean maps, weighted by their row counts (3 + 2), reproduce the one-process statistics
-    assert abs(r1["time_mean_rmse_channel_mean"] - r2["time_mean_rmse_channel_mean"]) < 2e-4 * r1["time_mean_rmse_channel_mean"]
+
+    def run(steps, members, *extra):
+        cmd = [sys.executable, os.path.join(root, "tools", "c4_rollout.py"), "--steps", str(steps), "--members", str(members),
+               "--layers", "2", "--embed", "16", "--grid", "32", "64", *extra]
+        p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+    r1 = run(12, 5)
+    r2 = run(12, 5, "--gpus", "2", "--share-gpu")
+    rs = run(12, 5, "--gpus", "2", "--share-gpu", "--no-relay")
+    assert r1["finite"] and r2["finite"] and rs["finite"] and r1["rows"] == 5
+    assert r2["n_gpus"] == 2 and r2["rows"] == 2 and r2["relayed_windows"] == 1          # rank 0: 2 members + window 0 of member 4
+    assert rs["rows"] == 3 and rs["relayed_windows"] == 0
+    for r in (r2, rs):
+        assert abs(r1["time_mean_rmse_channel_mean"] - r["time_mean_rmse_channel_mean"]) < 2e-4 * r1["time_mean_rmse_channel_mean"]
+        assert r["job_member_forecast_steps_per_s"] > 0
+    r7 = run(18, 7)
+    r3 = run(18, 7, "--gpus", "3", "--share-gpu")
+    assert r3["n_gpus"] == 3 and r3["rows"] == 2 and r3["relayed_windows"] == 1 and r3["finite"]
+    assert abs(r7["time_mean_rmse_channel_mean"] - r3["time_mean_rmse_channel_mean"]) < 2e-4 * r7["time_mean_rmse_channel_mean"]

@@ -8,12 +8,15 @@ time of the windows beside it, finiteness and the aggregator's channel-mean RMSE
 
     python tools/c4_rollout.py --steps 102 --members 25                    # C4: 25 members x ~100 steps = 17 windows of 6
     python tools/c4_rollout.py --steps 600 --members 25                    # a C5-style long sample, extrapolated
-    python tools/c4_rollout.py --steps 102 --members 25 --gpus 8           # C4 as specified: members over 8 GPUs (4,3,3,...)
-    python tools/c4_rollout.py --steps 600 --members 25 --ics 4 --gpus 8   # C5's job (100 trajectories, 12-13 per GPU)
+    python tools/c4_rollout.py --steps 102 --members 25 --gpus 8           # C4 as specified: 3 members per GPU + 1 relayed
+    python tools/c4_rollout.py --steps 600 --members 25 --ics 4 --gpus 8   # C5's job (100 trajectories: 12 per GPU + 4 relayed)
 
 `--gpus N` works by itself: the parent starts one child per GPU before anything touches HIP (never re-executes a process
-that has); every rank runs `run_inference(unit_range=ensemble.shard(...))` on its own share -- no collective on the data
-path -- and the `TimeMeanAggregator(dist=TorchDistributed())` combines the ranks' maps once, at log time (RCCL).
+that has).  A job whose trajectories divide by the ranks runs `run_inference(unit_range=ensemble.shard(...))` on every rank;
+one that does not (25 over 8) runs `run_inference(relay=ensemble.relay_plan(...))`: equal resident blocks and the remainder
+trajectories relayed between the ranks in time slices (`--no-relay`: the static 4,3,3,... split, whose largest share sets the
+pace).  No collective on the data path; the `TimeMeanAggregator(dist=TorchDistributed())` combines the ranks' maps once, at
+log time (RCCL).
 """
 import argparse
 import json
@@ -44,7 +47,7 @@ def windows(names, n_windows, window, nlat, nlon, seed=1234, n_ics=1):
 
 
 def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=360, aggregate=True, warmup=True, n_ics=1,
-        rank=0, world=1, prefetch=2, max_batch=None, dist=None):
+        rank=0, world=1, prefetch=2, max_batch=None, dist=None, relay=True):
     import torch
 
     import sdy_amd
@@ -54,7 +57,15 @@ def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=36
     exp, stepper, names, out_names = build(device, layers=layers, embed=embed, nlat=nlat, nlon=nlon)
     start, cnt, ic_lo, n_ic = ensemble.shard(n_ics, members, rank, world)
     kw = dict(n_ensemble_members=members, eval_device=device, prefetch=prefetch, max_batch=max_batch)
-    if world > 1:
+    n_traj = n_ics * members
+    plan = ensemble.relay_plan(n_traj, world, steps // window, rank) if (relay and world > 1) else None
+    if plan is not None and not any(ensemble.relay_plan(n_traj, world, steps // window, r).tasks for r in range(world)):
+        plan = None                                      # the job divides by the ranks (or has fewer trajectories): static split
+    if plan is not None:
+        # resident block + relayed remainder: the windows hold every initial condition (a relay trajectory's may be any)
+        start, cnt, ic_lo, n_ic = plan.start, plan.count, 0, n_ics
+        kw.update(relay=plan, trajectory_offset=0)
+    elif world > 1:
         kw.update(unit_range=(start, cnt), trajectory_offset=ic_lo)
     agg = None
     if aggregate:
@@ -70,13 +81,24 @@ def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=36
 
     def loader(n_windows, seed):     # a rank's loader delivers only the initial conditions its share touches
         for wdw in windows(names, n_windows, window, nlat, nlon, seed=seed, n_ics=n_ics):
-            if world > 1:
+            if world > 1 and plan is None:
                 wdw.data = {k: v[ic_lo:ic_lo + n_ic] for k, v in wdw.data.items()}
             yield wdw
 
     assert cnt > 0, "every rank has a share (main() rejects world > ics x members)"
     if warmup:   # one untimed window: native objects, weight upload and the workspace are created on first use (~8 s)
-        sdy_amd.run_inference(None, stepper, loader(1, 7), window, window, **kw)
+        wkw = {k: v for k, v in kw.items() if k != "relay"}
+        if plan is not None:
+            wkw.update(unit_range=(start, cnt))
+        sdy_amd.run_inference(None, stepper, loader(1, 7), window, window, **wkw)
+        if plan is not None and plan.tasks:      # (a batch of one as well: its workspace, and the ring's connections)
+            sdy_amd.run_inference(None, stepper, loader(1, 7), window, window, **dict(wkw, unit_range=(plan.tasks[0].unit, 1)))
+    comm = None
+    if plan is not None:
+        comm = ensemble.RelayComm(device=device)
+        comm.warm_up()
+        kw.update(relay_comm=comm)
+    exp.set_dropout_calls((0, 0))        # every rank numbers the job's dropout calls from the same origin
     if dist is not None and world > 1:
         torch.cuda.synchronize(device)
         import torch.distributed as td
@@ -85,6 +107,9 @@ def run(device, steps, members, window=6, layers=8, embed=256, nlat=180, nlon=36
     timers = sdy_amd.run_inference(agg, stepper, loader(steps // window, 1234), steps, window, writer=Writer(), **kw)
     wall = time.perf_counter() - t0
     res = {"steps": steps, "members": members, "ics": n_ics, "rows": cnt, "windows": steps // window, "wall_s": round(wall, 2),
+           "relayed_windows": sum(t.w_end - t.w_begin for t in plan.tasks) if plan is not None else 0,
+           "relay_recv_wait_s": round(timers.get("relay_recv_wait", 0.0), 3),
+           "trajectory_steps": timers["trajectory_steps"],
            "run_on_batch_s": round(timers["run_on_batch"], 2), "data_loading_wait_s": round(timers["data_loading"], 2),
            "member_forecast_steps_per_s": round(timers["forecast_steps_per_second"], 2),
            "member_forecast_steps_per_s_device_time": round(timers["forecast_steps_per_second_run_on_batch"], 2),
@@ -138,6 +163,8 @@ def main():
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--embed", type=int, default=256)
     ap.add_argument("--grid", type=int, nargs=2, default=(180, 360))
+    ap.add_argument("--no-relay", action="store_true",
+                    help="uneven jobs as a static split (25 over 8 = 4,3,3,...) instead of equal blocks + relayed remainder")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: all ranks on GPU 0 with the gloo backend (exercises the N>1 path on a 1-GPU box)")
     a = ap.parse_args()
@@ -167,16 +194,16 @@ def main():
             td.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
         dist = sdy_amd.metrics.TorchDistributed() if not a.share_gpu else _HostDist(td)
     r = run(dev, a.steps, a.members, layers=a.layers, embed=a.embed, nlat=a.grid[0], nlon=a.grid[1], n_ics=a.ics, rank=rank,
-            world=world, prefetch=a.prefetch, max_batch=a.max_batch, dist=dist)
+            world=world, prefetch=a.prefetch, max_batch=a.max_batch, dist=dist, relay=not a.no_relay)
     if world > 1:     # whole-job rate: every rank's trajectories over the slowest rank's wall time
-        t = torch.tensor([r.get("wall_s", 0.0), float(r.get("rows", 0))], dtype=torch.float64,
+        t = torch.tensor([r.get("wall_s", 0.0), float(r.get("trajectory_steps", 0.0))], dtype=torch.float64,
                          device="cpu" if a.share_gpu else dev)
         tmax, tsum = t.clone(), t.clone()
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         td.all_reduce(tsum, op=td.ReduceOp.SUM)
         r["n_gpus"] = world
         r["job_wall_s"] = round(float(tmax[0]), 2)
-        r["job_member_forecast_steps_per_s"] = round(float(tsum[1]) * a.steps / max(float(tmax[0]), 1e-9), 2)
+        r["job_member_forecast_steps_per_s"] = round(float(tsum[1]) / max(float(tmax[0]), 1e-9), 2)
     if rank == 0:
         rate = r.get("job_member_forecast_steps_per_s", r.get("member_forecast_steps_per_s", 0.0))
         if rate:
