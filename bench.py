@@ -130,21 +130,39 @@ def synthetic_state(ic_index, B, device):
 
 
 # ---- roofline ------------------------------------------------------------------------------------------------------------
+def profile_round_key(path):
+    """Order of a directory under profiles/: (round number, letters) of its name -- "r10a" follows "r9z" ("r10a" < "r5d" as
+    strings), and file times say nothing after a checkout."""
+    import re
+
+    m = re.match(r"r(\d+)([a-z]*)$", os.path.basename(os.path.dirname(path)))
+    return (int(m.group(1)), m.group(2)) if m else (-1, "")
+
+
 def measured_traffic():
     """HBM bytes per launch of the dominant kernel, `mlp_h3_kernel<true>` at 25 rows, from the NEWEST counter summary under
     profiles/ (profiles/<round>/pmc_summary.txt: separate rocprofv3 --pmc passes over an interpolator forward with every launch
     at 25 rows, FETCH_SIZE x 2 + WRITE_SIZE with the guide's gfx950 correction; tools/profile_round.sh, tools/pmc_summary.py).
-    Counters cannot be collected inside a timed run, so the bench line cites the file it read.  (bytes, path) or (None, None)."""
+    Counters cannot be collected inside a timed run, so the bench line cites the file it read -- and refuses one that is OLDER
+    than the newest kernel_stats.csv (a round that re-profiled its kernels but forgot the counter passes must not keep citing the
+    previous round's traffic).  Returns (bytes, path, None) or (None, None, reason)."""
     import glob
     import re
 
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.txt")), reverse=True):
-        for line in open(path):
-            if "mlp_h3_kernel<true, false>" in line:
-                m = re.search(r"\s([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+[0-9.]+%", line)
-                if m:
-                    return float(m.group(3)) * 1e9, os.path.relpath(path, ROOT)
-    return None, None
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.txt")), key=profile_round_key)
+    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "kernel_stats.csv")), key=profile_round_key)
+    if not pmc:
+        return None, None, "no profiles/*/pmc_summary.txt"
+    path = pmc[-1]
+    if stats and profile_round_key(stats[-1]) > profile_round_key(path):
+        return None, None, ("stale: the newest counter summary (%s) is older than the newest kernel trace (%s)"
+                            % (os.path.relpath(path, ROOT), os.path.relpath(stats[-1], ROOT)))
+    for line in open(path):
+        if "mlp_h3_kernel<true, false>" in line:
+            m = re.search(r"\s([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+[0-9.]+%", line)
+            if m:
+                return float(m.group(3)) * 1e9, os.path.relpath(path, ROOT), None
+    return None, None, "no mlp_h3_kernel<true, false> row in %s" % os.path.relpath(path, ROOT)
 
 
 def stage_work(B):
@@ -221,13 +239,13 @@ def roofline_from(rows, total_ms, B, h3):
     hbm_bytes = sum(r["gbytes"] * 1e9 * r["launches_per_step"] for r in rows if r["bound"] == "hbm")
     peak = PEAK_F16_MFMA_TFLOPS if h3 else PEAK_F32_MFMA_TFLOPS
     achieved = fl / (ms * 1e-3) / 1e12
-    traffic25, traffic_src = measured_traffic()
+    traffic25, traffic_src, traffic_why = measured_traffic()
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
         # counter traffic of a 25-row launch, scaled to the rows an average launch of this run covered (drop-path skip)
         "traffic": round(traffic25 * dom.get("avg_rows", B) / 25.0) if traffic25 else None,
         "traffic_source": ("%s (mlp_h3_kernel<true> at 25 rows: %.3f GB), x %.2f / 25 rows per launch here"
-                           % (traffic_src, traffic25 / 1e9, dom.get("avg_rows", B))) if traffic25 else None,
+                           % (traffic_src, traffic25 / 1e9, dom.get("avg_rows", B))) if traffic25 else traffic_why,
         "kernel": "mlp_h3_kernel<true> = stage '%s' (fused MLP 256->512->256 + GELU + Philox dropout + residual, 3-pass "
                   "split-f16 MFMA), B=%d, timed in the network" % (dom["name"], B),
         "ms_per_launch": ms, "launches_per_step": dom["launches_per_step"],

@@ -59,6 +59,13 @@ extern "C" {
 
 int sdy_version(void);
 const char* sdy_error_string(int code);
+/* The argument structures below carry no size field: a caller built against another revision of this header would hand the
+ * launchers uninitialised tail bytes (fields are only ever appended).  Contract: zero-initialise every structure with the
+ * sizeof of THIS header, and call sdy_abi_check once after loading the library with your own sizeofs, in the order
+ * {sdy_conv_args, sdy_mlp_args, sdy_pair_args, sdy_sfno_config, sdy_sfno_fwd_args, sdy_var_table, sdy_step_finish_args}:
+ * SDY_OK when all seven equal the library's, SDY_ERR_ARG otherwise (the Python bindings do this at import). */
+#define SDY_ABI_STRUCTS 7
+int sdy_abi_check(const size_t* sizes, int n);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Spherical-harmonic transform plan.
@@ -433,6 +440,26 @@ int sdy_status_flags(unsigned* flags, int reset, void* stream);
  * call, and cleared behind the copy if `reset`; read it after an event recorded behind the call has completed (the window
  * driver reads a window's word, together with its loss terms, while the next window computes). */
 int sdy_status_flags_async(unsigned* flags_host, int reset, void* stream);
+/* Range headroom (debug read-back; first contact with a trained checkpoint should report "x N below the cliff", not pass /
+ * fail).  While enabled (process-wide switch; off by default: the bookkeeping is one atomic per tile), the split-precision
+ * kernels of the default path record the largest magnitude they stage as fp16 -- pre-scale included, i.e. the number that
+ * must stay below 65504 -- per consumer class, on the current device:
+ *   [0] conv_h3 (inner skip and the other Cin -> 256 convolutions)   [1] mlp_h3's x tile   [2] dh_h3's coefficient rows
+ *   [3] Legendre analysis input, recorded where it is PRODUCED (rfft360's stores; the folded kernel adds the two hemispheres'
+ *       entries, so the recorded value is 2 x 16 x |Xf|)   [4] Legendre synthesis input, recorded at dh_h3's stores (16 x |Cs|).
+ * The folded Legendre kernel has no register to spare for a tracker of its own: the two producers raise SDY_FLAG_F16_RANGE
+ * for it (rfft360 at 2 x 16 x |Xf| >= 65504 -- conservative by at most the factor 2 of the fold).
+ * sdy_range_headroom copies the five values (0 where a class has not run), clears them if `reset`, and synchronises `stream`.
+ * headroom factor = 65504 / value. */
+#define SDY_RANGE_SLOTS 5
+int sdy_range_headroom_enable(int on);
+int sdy_range_headroom(float* max_staged5, int reset, void* stream);
+/* The dropout stream's generator evaluated on the host by the library itself (the same function the kernels inline):
+ * the number of Philox rounds it was built with (7; tests hold it to oracle/philox.py and to Random123's seven-round
+ * known-answer vectors) and the four words of one counter / key pair. */
+int sdy_dropout_stream_rounds(void);
+int sdy_dropout_stream_words(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t key_lo, uint32_t key_hi,
+                             uint32_t* out4);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Measurement.  While enabled, every kernel launch of sdy_sfno_forward is bracketed by a pair of

@@ -140,6 +140,7 @@ class SdySfnoFwdArgs(C.Structure):
 SIGNATURES = {
     "sdy_version": (C.c_int, []),
     "sdy_error_string": (C.c_char_p, [C.c_int]),
+    "sdy_abi_check": (C.c_int, [C.POINTER(C.c_size_t), C.c_int]),
     "sdy_sht_tables_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdy_sht_plan_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sdy_sht_plan_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -208,6 +209,11 @@ SIGNATURES = {
                                           C.c_float, C.c_void_p, C.c_void_p]),
     "sdy_status_flags": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
     "sdy_status_flags_async": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "sdy_range_headroom_enable": (C.c_int, [C.c_int]),
+    "sdy_range_headroom": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "sdy_dropout_stream_rounds": (C.c_int, []),
+    "sdy_dropout_stream_words": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.POINTER(C.c_uint32)]),
     "sdy_ensemble_series": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sdy_profile_enable": (C.c_int, [C.c_int]),
@@ -235,6 +241,12 @@ def _load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    # the argument structures carry no size field: the bindings' layouts must be the library's (include/sdy_amd.h, sdy_abi_check)
+    structs = (SdyConvArgs, SdyMlpArgs, SdyPairArgs, SdySfnoConfig, SdySfnoFwdArgs, SdyVarTable, SdyStepFinishArgs)
+    sizes = (C.c_size_t * len(structs))(*[C.sizeof(t) for t in structs])
+    if lib.sdy_abi_check(sizes, len(structs)) != 0:
+        raise ImportError(f"{LIB_PATH}: argument structures of the bindings and of the library differ in size "
+                          f"({[C.sizeof(t) for t in structs]}): rebuild the library (make -C spherical-dyffusion_amd/csrc)")
     return lib
 
 

@@ -47,7 +47,16 @@ static float h3_pack_host(std::vector<_Float16>& buf, int nb, int rows, int K, i
 }
 
 
-extern "C" int sdy_version(void) { return 100; }
+extern "C" int sdy_version(void) { return 101; }
+
+extern "C" int sdy_abi_check(const size_t* sizes, int n) {
+  const size_t mine[SDY_ABI_STRUCTS] = {sizeof(sdy_conv_args), sizeof(sdy_mlp_args), sizeof(sdy_pair_args), sizeof(sdy_sfno_config),
+                                        sizeof(sdy_sfno_fwd_args), sizeof(sdy_var_table), sizeof(sdy_step_finish_args)};
+  if (!sizes || n != SDY_ABI_STRUCTS) return SDY_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (sizes[i] != mine[i]) return SDY_ERR_ARG;
+  return SDY_OK;
+}
 
 extern "C" const char* sdy_error_string(int code) {
   switch (code) {
@@ -97,19 +106,18 @@ struct sdy_sht_plan {
 
 // Every environment switch of the library, read once per process.  Each routes a stage to its fallback kernel (the only
 // implementation for other shapes; tests/test_gpu_variants.py holds all of them to the default path's output) -- INTEGRATION.md
-// section 5 lists what they do.
+// section 5 lists what they do.  (Retired in round 6 with their questions settled: SDY_NO_FUSED_STATS, SDY_NO_POLAR_SKIP,
+// SDY_NO_PAIR, SDY_NO_CONV_FRAG -- the paths they selected are still what other shapes take, and are tested there.)
 namespace {
 struct SdySwitches {
-  bool gemm_f32, no_polar_skip, no_fft360, no_leg_par, no_leg_frag, no_dh_frag, no_conv_frag, no_pair, no_fused_stats,
-      no_fused_mlp, no_drop_skip;
+  bool gemm_f32, no_fft360, no_leg_par, no_leg_frag, no_dh_frag, no_fused_mlp, no_drop_skip;
 };
 const SdySwitches& sw() {
   static const SdySwitches v = [] {
     auto on = [](const char* n) { return std::getenv(n) != nullptr; };
     const char* g = std::getenv("SDY_GEMM_MODE");
-    return SdySwitches{g && std::string(g) == "f32", on("SDY_NO_POLAR_SKIP"), on("SDY_NO_FFT360"), on("SDY_NO_LEG_PAR"),
-                       on("SDY_NO_LEG_FRAG"), on("SDY_NO_DH_FRAG"), on("SDY_NO_CONV_FRAG"), on("SDY_NO_PAIR"),
-                       on("SDY_NO_FUSED_STATS"), on("SDY_NO_FUSED_MLP"), on("SDY_NO_DROP_SKIP")};
+    return SdySwitches{g && std::string(g) == "f32", on("SDY_NO_FFT360"), on("SDY_NO_LEG_PAR"), on("SDY_NO_LEG_FRAG"),
+                       on("SDY_NO_DH_FRAG"), on("SDY_NO_FUSED_MLP"), on("SDY_NO_DROP_SKIP")};
   }();
   return v;
 }
@@ -135,6 +143,7 @@ extern "C" int sdy_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, in
   const int n = nlon / 2;
   p->fft.n = n;
   p->fft.S = (n + 1) | 1;
+  p->fft.guard_f16 = gemm_mode == 1 ? 1 : 0;   // split-precision Legendre kernels stage the transform's output as fp16
   int r = sdy_factor_radices(n, p->fft.radices, &p->fft.nstages);
   if (r != SDY_OK) { delete p; return r; }
   if ((size_t)(4 * 16 * p->fft.S + 4 * n + 2) * sizeof(float) > 64 * 1024) { delete p; return SDY_ERR_UNSUPPORTED; }
@@ -318,7 +327,7 @@ extern "C" int sdy_legendre_fwd(const sdy_sht_plan* p, const float* Xf, float* C
 // polar: skip the rows / orders of the polar cut-off (only valid when the producer / consumer of Xf is fft360 with the same
 // cut-off: plan_polar_ok)
 static bool plan_polar_ok(const sdy_sht_plan* p, int C) {
-  const bool off = sw().no_polar_skip || sw().no_fft360 || sw().no_leg_par || sw().no_leg_frag;
+  const bool off = sw().no_fft360 || sw().no_leg_par || sw().no_leg_frag;
   return !off && p->d_kdead && p->d_wq_par && p->fft.n == 180 && C % 16 == 0;
 }
 // Tile-major grid-frequency tensor (fft.h, ilv == 2): like the polar cut-off a contract between fft360 and leg_par only --
@@ -1149,12 +1158,11 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   };
 
   sdy_conv_args cv;
-  const bool no_frag = sw().no_conv_frag;
   auto use_w = [&](const DevBuf& b) {
     cv.wt = b.p;
     if (c.gemm_mode == 1) {
       cv.w_h3 = b.h3; cv.w_h3_scale = b.h3_scale;
-      if (!no_frag) { cv.w_frag = b.frag; cv.w_frag_scale = b.frag_scale; }
+      cv.w_frag = b.frag; cv.w_frag_scale = b.frag_scale;
     }
   };
   auto conv_reset = [&]() {
@@ -1163,23 +1171,19 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   };
 
   // ---- encoder (sfnonet.py:609-618,810,824): conv+bias -> GELU -> conv (no bias) -> + pos_embed
-  const bool no_pair = sw().no_pair;   // A/B: the two-launch encoder / decoder
-  const bool no_stats0 = sw().no_fused_stats;
   // The encoder writes to a buffer of its own (xe) and its statistics to `ste`; block 0 works on a copy of the statistics
   // (sdy_instnorm_from_stats clears what it reads), so that a following forward on the same inputs can restart here.
   bool have_ste = false;
   if (reuse) {
     have_ste = n->enc_has_stats;
-  } else if (n->enc.w && !no_pair) {   // one launch (pair_h3.hip), block 0's norm0 statistics from its epilogue
+  } else if (n->enc.w) {   // one launch (pair_h3.hip), block 0's norm0 statistics from its epilogue
     sdy_pair_args pa{};
     pa.x = cat_in; pa.x_bstride = cat_bs; pa.w = n->enc.w; pa.w1_scale = n->enc.s1; pa.w2_scale = n->enc.s2;
     pa.b1 = n->e0b.p; pa.out = xe; pa.out_bstride = (long)E * HW;
     if (c.pos_embed) { pa.add = n->pos.p; pa.add_bstride = 0; }
     pa.B = B; pa.Cin = Cin; pa.hidden = E; pa.Cout = E; pa.HW = HW;
-    if (!no_stats0) {
-      SDY_HIP_TRY(hipMemsetAsync(ste, 0, (size_t)B * E * 2 * sizeof(double), stream));
-      pa.stats = ste; have_ste = true;
-    }
+    SDY_HIP_TRY(hipMemsetAsync(ste, 0, (size_t)B * E * 2 * sizeof(double), stream));
+    pa.stats = ste; have_ste = true;
     SDY_STAGE(ST_ENC_PAIR, sdy_pair_h3(&pa, stream));
   } else {
   conv_reset();
@@ -1191,7 +1195,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   cv.Cin = E; cv.Cout = E;
   if (c.pos_embed) { cv.add = n->pos.p; cv.add_bstride = 0; cv.add_mode = 2; }
   // block 0's norm0 statistics from this convolution's epilogue (persistent kernel only): no pass over its output
-  if (cv.w_frag && sdy_conv256_h3_supported(E, E) && !no_stats0) {
+  if (cv.w_frag && sdy_conv256_h3_supported(E, E)) {
     SDY_HIP_TRY(hipMemsetAsync(ste, 0, (size_t)B * E * 2 * sizeof(double), stream));
     cv.stats = ste; have_ste = true;
   }
@@ -1233,9 +1237,8 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     // Cs / Cs2 tile-major by order too (analysis stores and synthesis loads become contiguous tiles; dh_h3 reads and writes
     // 256-byte pieces instead of 2 KB rows, which it does not notice: it is matrix / issue bound).
     const bool cs_tiled = tiled_in && tiled_out && bw.fw.frag && pin->lmax == pout->lmax && pin->mtr == pout->mtr;
-    const bool no_stats1 = sw().no_fused_stats;
-    const bool frag_conv = c.gemm_mode == 1 && !no_frag && bw.skw.frag && sdy_conv256_h3_supported(E, E);
-    const bool stats1 = frag_conv && !no_stats1;   // norm1 statistics from the inner-skip convolution's epilogue
+    const bool frag_conv = c.gemm_mode == 1 && bw.skw.frag && sdy_conv256_h3_supported(E, E);
+    const bool stats1 = frag_conv;   // norm1 statistics from the inner-skip convolution's epilogue
     // The tensor between the inner skip and the fused MLP has exactly one producer and one consumer, both walking 64-pixel
     // tiles: it is stored TILE-MAJOR (a tile = one contiguous 64 KB block for the stores of one and the loads of the other).
     const bool z_tiled = stats1 && fused_mlp;
@@ -1305,8 +1308,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
         SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
     }
     // MLP (layers.py:73-80): fc1 + GELU + dropout
-    const bool no_stats = sw().no_fused_stats;
-    const bool stats_next = fused_mlp && i < L - 1 && !no_stats;   // the next block's norm0 statistics from this block's epilogue
+    const bool stats_next = fused_mlp && i < L - 1;   // the next block's norm0 statistics from this block's epilogue
     if (Bp == 0) {
       // (every trajectory dropped: nothing of the branch runs)
     } else if (fused_mlp) {
@@ -1358,7 +1360,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   }
 
   // ---- decoder (sfnonet.py:734-744,831-837)
-  if (n->dec.w && !no_pair) {
+  if (n->dec.w) {
     sdy_pair_args pa{};
     pa.x = cat; pa.x_bstride = cat_bs; pa.w = n->dec.w; pa.w1_scale = n->dec.s1; pa.w2_scale = n->dec.s2;
     pa.b1 = n->d0b.p; pa.out = a->out; pa.out_bstride = (long)c.out_chans * HW;

@@ -46,6 +46,10 @@ inline int sdy_cu_count(int* n_cu) {                 // compute units of the CUR
 }
 // Device address of the current device's sticky status word (allocated and zeroed on first use; pointwise.hip).
 int sdy_flags_ptr(unsigned** flags);
+// Range headroom (include/sdy_amd.h, sdy_range_headroom): device word of consumer class `slot` while the debug read-back is
+// enabled, nullptr otherwise (kernels skip the bookkeeping on a null pointer).
+enum { SDY_RANGE_CONV = 0, SDY_RANGE_MLP = 1, SDY_RANGE_DHCONV = 2, SDY_RANGE_LEG_ANALYSIS = 3, SDY_RANGE_LEG_SYNTHESIS = 4 };
+int sdy_headroom_ptr(int slot, unsigned** word);
 struct SdyOncePerDevice {                            // `static SdyOncePerDevice once;` next to a kernel's attribute setup
   std::atomic<bool> done[SDY_MAX_DEVICES] = {};      // (setting a function attribute twice is harmless; the flag is not a lock)
   int slot(std::atomic<bool>** flag) {
@@ -121,6 +125,15 @@ __device__ __forceinline__ void sdy_split8(const float* v, sdy_f16x8& hi, sdy_f1
 #define SDY_F16_LIMIT 65504.0f
 __device__ __forceinline__ void sdy_flag_range(unsigned* flags, float amax) {
   if (flags && amax >= SDY_F16_LIMIT) atomicOr(flags, (unsigned)SDY_FLAG_F16_RANGE);
+}
+// The same plus the debug read-back of sdy_range_headroom: `head` (null unless enabled) keeps the largest staged magnitude
+// its consumer class has seen, as float bits (non-negative floats order like unsigned integers).
+__device__ __forceinline__ void sdy_flag_range(unsigned* flags, float amax, unsigned* head) {
+  sdy_flag_range(flags, amax);
+  if (head) {
+    const unsigned bits = __float_as_uint(amax);
+    if (bits > *reinterpret_cast<volatile unsigned*>(head)) atomicMax(head, bits);
+  }
 }
 // 16-byte store of a streaming output (written once, read by a later kernel after 1.6 GB of other traffic)
 #ifdef SDY_NT_STORE

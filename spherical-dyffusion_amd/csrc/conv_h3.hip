@@ -70,6 +70,7 @@ struct ConvParams {
   int Cin;                         // input channels (the weight stream is zero-padded to KBLK * 64)
   float out_scale;
   unsigned* flags;                 // sticky status word (sdy_status_flags)
+  unsigned* head;                  // range headroom word of this consumer class (sdy_range_headroom; null unless enabled)
   const float* gelu_tab;           // GELU table in global memory (sdy_gelu_table_ptr)
   SdyImgMap xmap;                  // drop-path skip: image z of this launch reads x / pa / pd of batch row xmap.idx[z] (common.h)
   unsigned long long* stamps;    // timing experiments only (SDY_CONV_STAMPS)
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_h3_kernel(const
           *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
         }
       }
-      sdy_flag_range(p.flags, amax);
+      sdy_flag_range(p.flags, amax, p.head);
     }
     __syncthreads();
     stamp(1);
@@ -449,6 +450,7 @@ int sdy_conv256_h3_launch(const sdy_conv_args* a, hipStream_t stream) {
   if (a->out_tiled && a->add_mode && a->add == a->out) return SDY_ERR_ARG;   // a tile-major output cannot alias the NCHW addend
   p.stats = a->stats;
   SDY_TRY(sdy_flags_ptr(&p.flags));
+  SDY_TRY(sdy_headroom_ptr(SDY_RANGE_CONV, &p.head));
   SDY_TRY(sdy_gelu_table_ptr(&p.gelu_tab));
   p.HW = a->HW; p.B = a->B; p.Cin = a->Cin;
   SDY_TRY(sdy_img_map_fill(p.xmap, a->x_rows, a->B));

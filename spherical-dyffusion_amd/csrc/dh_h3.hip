@@ -53,6 +53,8 @@ struct DhParams {
                                    // 64-column pieces sit at ((8 r + piece) L + l) * 64: no division, no per-degree stride
   float out_scale;
   unsigned* flags;                 // sticky status word (sdy_status_flags)
+  unsigned* head_in;               // range headroom words (sdy_range_headroom; null unless enabled): the rows this kernel stages,
+  unsigned* head_out;              // and what it stores -- the Legendre synthesis stages that with the same pre-scale
   unsigned long long* stamps;      // timing experiments only (SDY_DH_STAMPS)
   int B_in;                        // images per order of the INPUT tensor (>= B; tiled only): row (m, b) of this launch is input
                                    // row m B_in + b -- the drop-path skip contracts only the first B of B_in images (capi.hip)
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
       *reinterpret_cast<f16x8*>(Xs_hi + off) = vh;
       *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
     }
-    sdy_flag_range(p.flags, amax);
+    sdy_flag_range(p.flags, amax, p.head_in);
     stamp(1);
     __syncthreads();
     stamp(2);
@@ -272,6 +274,9 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
                           : p.out + (long)cur.l * p.sC + (long)row0 * DN;   // uniform: rows are added in SGPR arithmetic
       const unsigned olane = p.tiled ? (unsigned)(srow * orow + 4 * sc4) * 4u
                                      : (unsigned)(srow * DN + gcol) * 4u;   // the lane part of every store address
+      // The stored coefficients are what the Legendre synthesis stages as fp16 (x SDY_ACT_SX, leg_par.hip), and that kernel has
+      // no register left for a range guard of its own: its input is guarded HERE, where it is produced.
+      float omax = 0.0f;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -279,7 +284,12 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) stg[(q + 4 * h) * 64 + scol + tstep * t] = acc[t][j][4 * g + q] * p.out_scale;
+            for (int q = 0; q < 4; q += 2) {
+              const float v0 = acc[t][j][4 * g + q] * p.out_scale, v1 = acc[t][j][4 * g + q + 1] * p.out_scale;
+              omax = __builtin_fmaxf(omax, __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+              stg[(q + 4 * h) * 64 + scol + tstep * t] = v0;
+              stg[(q + 1 + 4 * h) * 64 + scol + tstep * t] = v1;
+            }
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(512) void dh_h3_kernel(const DhParams p) {
           }
           __builtin_amdgcn_wave_barrier();
         }
+      sdy_flag_range(p.flags, omax * DSX, p.head_out);   // (rows past the ragged edge are zero rows: they cannot raise it)
     }
     stamp(4);
     if (SDY_STAMPS_ON && p.stamps && blockIdx.x == 11 && tile_it < 63 && !more) {
@@ -371,6 +382,8 @@ int sdy_dh_h3_launch(const float* Cs_in, const void* packed, float scale, float*
   p.B_in = B_in; p.b_magic = (unsigned)((1ull << 32) / (unsigned)B) + 1u;
   p.out_scale = 1.0f / (scale * DSX);
   SDY_TRY(sdy_flags_ptr(&p.flags));
+  SDY_TRY(sdy_headroom_ptr(SDY_RANGE_DHCONV, &p.head_in));
+  SDY_TRY(sdy_headroom_ptr(SDY_RANGE_LEG_SYNTHESIS, &p.head_out));
   p.stamps = nullptr;
   {   // degree -> XCD: degrees by falling tile count (ties: higher degree first), each to the XCD with the fewest tiles so far
     p.use_table = L <= 256 ? 1 : 0;

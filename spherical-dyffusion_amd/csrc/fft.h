@@ -9,6 +9,8 @@ struct SdyFftDesc {
   int radices[10]; // product = n, each in {2,3,4,5}
   const float* tw; // dev [n][2]    exp(-2*pi*i*j/n)
   const float* pw; // dev [n+1][2]  exp(-2*pi*i*m/nlon)
+  int guard_f16;   // the consumer of the forward transform stages it as fp16 (split-precision Legendre kernels): fft360 raises
+                   // SDY_FLAG_F16_RANGE for the folded analysis kernel, which has no register left for a tracker of its own
 };
 
 // Polar cut-off (fused forward only): for latitude ring k only the orders m < mcut[k] are written (forward) / read (inverse);

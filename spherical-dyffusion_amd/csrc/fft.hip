@@ -207,10 +207,11 @@ template <int NH, int KPW>
 __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const float* __restrict__ x,
                                                        const float* __restrict__ pa, const float* __restrict__ pd,
                                                        float* __restrict__ xn_out, float* __restrict__ Xf, int B,
-                                                       int C, int K, int mtr, int ilv) {
+                                                       int C, int K, int mtr, int ilv, unsigned* flags) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int n = NH ? NH : f.n, N = 2 * n, S = NH ? ((NH + 1) | 1) : f.S;
   LdsView L = carve(sm, S, n);
+  float amax = 0.0f;   // fp16 range guard on behalf of the folded Legendre analysis (fft360.hip has the reasoning)
   const int c0 = blockIdx.x * CB, b = blockIdx.z;
   const int k_begin = blockIdx.y * KPW, k_end = min(K, k_begin + KPW);
   load_tables(f, L);
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const 
         for (int j = 0; j < 4; ++j) {
           vr[j] = zr[(4 * c4 + j) * S + m];
           vi[j] = zi[(4 * c4 + j) * S + m];
+          amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(vr[j]), __builtin_fabsf(vi[j])));
         }
         *reinterpret_cast<f32x4*>(Xf + o) = vr;
         *reinterpret_cast<f32x4*>(Xf + o + (ilv ? CB : C)) = vi;
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(NT) void rfft_fwd_kernel(const SdyFftDesc f, const 
     }
     __syncthreads();   // the LDS image is rewritten by the next ring
   }
+  sdy_flag_range(flags, amax * (2.0f * SDY_ACT_SX));
 }
 
 // Yf[m][k][b][ri][c] -> y (B,C,K,N) (+ bias[c]); same ring pipeline as the forward kernel
@@ -443,13 +446,15 @@ int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, cons
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = 4;   // latitude rings per workgroup on the pipelined (compile-time size) paths
   dim3 grid((C + CB - 1) / CB, (K + KPW - 1) / KPW, B);
+  unsigned* flags = nullptr;
+  if (f.guard_f16) SDY_TRY(sdy_flags_ptr(&flags));
   if (f.n == 180) {
-    hipLaunchKernelGGL((rfft_fwd_kernel<180, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv);
+    hipLaunchKernelGGL((rfft_fwd_kernel<180, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, flags);
   } else if (f.n == 32) {
-    hipLaunchKernelGGL((rfft_fwd_kernel<32, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv);
+    hipLaunchKernelGGL((rfft_fwd_kernel<32, KPW>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, flags);
   } else {
     grid.y = K;
-    hipLaunchKernelGGL((rfft_fwd_kernel<0, 1>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv);
+    hipLaunchKernelGGL((rfft_fwd_kernel<0, 1>), grid, dim3(NT), smem, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, flags);
   }
   return sdy_launch_status();
 }

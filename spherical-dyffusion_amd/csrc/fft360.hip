@@ -224,7 +224,8 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
                                                            const float* __restrict__ pa, const float* __restrict__ pd,
                                                            float* __restrict__ xn_out, float* __restrict__ Xf, int B,
                                                            int C, int K, int mtr, int ilv,
-                                                           const int* __restrict__ mcut, const SdyImgMap xmap) {
+                                                           const int* __restrict__ mcut, const SdyImgMap xmap,
+                                                           unsigned* flags, unsigned* head) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
   __shared__ c2 TW[TWN];
   __shared__ c2 AD[ROWS];   // per-slot affine (a, d)
@@ -264,6 +265,10 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
   //   m * mstride + (column tile j = (b * C/16 + c0/16) / 2) * K * 64 + k * 64 + (odd channel block ? 32 : 0)
   const long tile_base = (long)((b * (C / ROWS) + id.x) >> 1) * K * 64 + (id.x & 1) * 32 + 4 * c4;
 
+  // fp16 range guard on behalf of the Legendre analysis (leg_par.hip stages (x[k] +- x[mirror]) * SDY_ACT_SX as fp16 and has
+  // no register to spare): the largest magnitude this workgroup stores, checked once at the end (the kernel is HBM bound at
+  // 52 registers: one v_max3 per two stored values is free)
+  float amax = 0.0f;
   f32x4 regs[8];
   auto gload = [&](int k) {
 #pragma unroll
@@ -320,6 +325,7 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
           const c2 X = (0.5f * scale) * S + cmul(D, W[it]);
           vr[j] = X.x;
           vi[j] = X.y;
+          amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(X.x), __builtin_fabsf(X.y)));
         }
         float* o = Xk + (long)m * mstride;
         SDY_STREAM_STORE(o, vr);
@@ -328,6 +334,8 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
     }
     __syncthreads();   // the rows are rewritten by the next ring
   }
+  // the fold adds the entries of the two hemispheres: 2 x SDY_ACT_SX x |Xf| bounds what the analysis stages
+  sdy_flag_range(flags, amax * (2.0f * SDY_ACT_SX), head);
 }
 
 // ----------------------------------------------------------------------------------------------------------- inverse
@@ -440,7 +448,13 @@ int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, c
   SdyImgMap xmap;
   SDY_TRY(sdy_img_map_fill(xmap, x_rows, B));
   dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
-  hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut, xmap);
+  unsigned *flags = nullptr, *head = nullptr;
+  if (f.guard_f16) {
+    SDY_TRY(sdy_flags_ptr(&flags));
+    SDY_TRY(sdy_headroom_ptr(SDY_RANGE_LEG_ANALYSIS, &head));
+  }
+  hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut, xmap,
+                     flags, head);
   return sdy_launch_status();
 }
 

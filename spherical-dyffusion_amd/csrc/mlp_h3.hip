@@ -71,6 +71,7 @@ struct MlpParams {
   double* stats;                           // optional [B][ME][2]: sum and sum of squares of the stored output rows
   const float* keep_h; const float* keep_o; // INJECT instantiation only (tests): 0/1 masks (B, MH, HW) / (B, ME, HW)
   unsigned* flags;                         // sticky status word (sdy_status_flags)
+  unsigned* head;                          // range headroom word of the x tile (sdy_range_headroom; null unless enabled)
   unsigned long long* stamps;              // timing experiments only (SDY_MLP_STAMPS): per-phase s_memtime of one wave
   SdyImgMap omap;                          // drop-path skip (common.h): image z of this launch (x, pa, pd) is batch row omap.idx[z]
                                            // of add / add_a / add_d / out / stats / batch_scale / keep_* and of the dropout stream
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void mlp_h3_kernel(const MlpParams p) {
         *reinterpret_cast<f16x8*>(Xs_lo + off) = vl;
       }
     }
-    sdy_flag_range(p.flags, amax);
+    sdy_flag_range(p.flags, amax, p.head);
   };
   if (full) stage_x(std::true_type{});   // (workgroup-uniform)
   else stage_x(std::false_type{});
@@ -928,6 +929,7 @@ extern "C" int sdy_mlp_h3(const sdy_mlp_args* a, void* stream) {
   p.add_local = a->add_by_launch_row ? 1 : 0;
   SDY_TRY(sdy_img_map_fill(p.omap, a->out_rows, a->B));
   SDY_TRY(sdy_flags_ptr(&p.flags));
+  SDY_TRY(sdy_headroom_ptr(SDY_RANGE_MLP, &p.head));
   p.stamps = nullptr;
 #if SDY_STAMPS_ON && !defined(SDY_MLP_INJECT_TU)
   if (std::getenv("SDY_MLP_STAMPS")) {

@@ -1,5 +1,6 @@
 // HBM-bound pointwise / reduction kernels of the SFNO block and the DYffusion sampler, gfx950.
 #include <cmath>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -742,6 +743,40 @@ int sdy_gelu_table_ptr(const float** table_dev) {
     tabs[dev] = d;
   }
   *table_dev = tabs[dev];
+  return SDY_OK;
+}
+
+// ---- range headroom (debug read-back): words 1 .. 5 of the status allocation hold the float bits of the largest magnitude
+// each consumer class has staged since the last reset
+static std::atomic<bool> g_headroom_on{false};
+int sdy_headroom_ptr(int slot, unsigned** word) {
+  *word = nullptr;
+  if (!g_headroom_on.load(std::memory_order_relaxed) || slot < 0 || slot >= SDY_RANGE_SLOTS) return SDY_OK;
+  unsigned* d = nullptr;
+  SDY_TRY(sdy_flags_ptr(&d));
+  *word = d + 1 + slot;
+  return SDY_OK;
+}
+extern "C" int sdy_range_headroom_enable(int on) {
+  g_headroom_on.store(on != 0);
+  return SDY_OK;
+}
+extern "C" int sdy_range_headroom(float* max_staged, int reset, void* stream) {
+  if (!max_staged) return SDY_ERR_ARG;
+  unsigned* d = nullptr;
+  SDY_TRY(sdy_flags_ptr(&d));
+  SDY_HIP_TRY(hipMemcpyAsync(max_staged, d + 1, SDY_RANGE_SLOTS * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (reset) SDY_HIP_TRY(hipMemsetAsync(d + 1, 0, SDY_RANGE_SLOTS * sizeof(unsigned), (hipStream_t)stream));
+  SDY_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return SDY_OK;
+}
+// Host evaluation of the dropout stream's generator (the same __host__ __device__ function the kernels call)
+extern "C" int sdy_dropout_stream_rounds(void) { return SDY_PHILOX_ROUNDS; }
+extern "C" int sdy_dropout_stream_words(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t key_lo, uint32_t key_hi,
+                                        uint32_t* out4) {
+  if (!out4) return SDY_ERR_ARG;
+  const philox4 w = philox4x32(c0, c1, c2, c3, key_lo, key_hi);
+  out4[0] = w.x; out4[1] = w.y; out4[2] = w.z; out4[3] = w.w;
   return SDY_OK;
 }
 

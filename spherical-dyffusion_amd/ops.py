@@ -355,6 +355,37 @@ def status_flags(reset: bool = True, device=None) -> int:
     return int(out.value)
 
 
+RANGE_CLASSES = ("conv_h3 x tile", "mlp_h3 x tile", "dh_h3 coefficient rows", "Legendre analysis input (at rfft360's stores)",
+                 "Legendre synthesis input (at dh_h3's stores)")
+
+
+class range_headroom:
+    """Context manager around `sdy_range_headroom*` (include/sdy_amd.h): while the block runs, the split-precision kernels of
+    the default path record the largest magnitude they stage as fp16 (pre-scale included: the number that must stay below
+    65504), per consumer class.  Afterwards `.max_staged` = {class: value} and `.factor` = {class: 65504 / value} -- "x N below
+    the cliff" for a checkpoint's first contact with the library, instead of SDY_FLAG_F16_RANGE's pass / fail.  Debug aid: one
+    atomic per tile while enabled."""
+
+    LIMIT = 65504.0
+
+    def __enter__(self):
+        buf = (C.c_float * len(RANGE_CLASSES))()
+        with torch.cuda.device(torch.cuda.current_device()):
+            check(lib.sdy_range_headroom(buf, 1, current_stream()), "sdy_range_headroom")     # drop stale maxima
+        check(lib.sdy_range_headroom_enable(1))
+        self.max_staged, self.factor = {}, {}
+        return self
+
+    def __exit__(self, *exc):
+        check(lib.sdy_range_headroom_enable(0))
+        buf = (C.c_float * len(RANGE_CLASSES))()
+        with torch.cuda.device(torch.cuda.current_device()):
+            check(lib.sdy_range_headroom(buf, 1, current_stream()), "sdy_range_headroom")
+        self.max_staged = {n: float(buf[i]) for i, n in enumerate(RANGE_CLASSES)}
+        self.factor = {n: (self.LIMIT / v if v > 0.0 else float("inf")) for n, v in self.max_staged.items()}
+        return False
+
+
 def raise_on_status_flags(flags: int, where: str) -> None:
     if not flags:
         return

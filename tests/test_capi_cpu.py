@@ -87,7 +87,7 @@ def test_no_cpu_fallback(sdy):
 def test_philox_known_answers():
     """Random123 known-answer vectors of Philox4x32-10 pin the round function, the constants and the key schedule of the
     oracle's generator; the dropout stream runs the same code for seven rounds (oracle.philox.ROUNDS, SDY_PHILOX_ROUNDS), for
-    which Random123 publishes the vector of the pi / e example."""
+    which Random123 publishes known-answer vectors as well."""
     from oracle.philox import ROUNDS, philox4x32
 
     kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
@@ -98,8 +98,23 @@ def test_philox_known_answers():
         got = tuple(int(x) for x in philox4x32(*ctr, *key, rounds=10))
         assert got == exp
     assert ROUNDS == 7
-    got7 = tuple(int(x) for x in philox4x32(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0))
-    assert got7 != kat[2][2] and len(set(got7)) == 4
+    # Random123's known-answer vectors of philox4x32 with SEVEN rounds (kat_vectors: "philox4x32 7 ..."), the count the dropout
+    # stream runs: held by the oracle's generator AND by the library's own (the __host__ __device__ function the kernels
+    # inline, evaluated on the host through sdy_dropout_stream_words; no GPU needed)
+    kat7 = [((0, 0, 0, 0), (0, 0), (0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48)),
+            ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662)),
+            ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+             (0x4DFCCABA, 0x190A87F0, 0xC47362BA, 0xB6B5242A))]
+    import ctypes as C
+
+    import sdy_amd
+
+    assert sdy_amd.lib.sdy_dropout_stream_rounds() == ROUNDS          # a rebuilt library cannot silently change seeded results
+    for ctr, key, exp in kat7:
+        assert tuple(int(x) for x in philox4x32(*ctr, *key)) == exp
+        out = (C.c_uint32 * 4)()
+        assert sdy_amd.lib.sdy_dropout_stream_words(*ctr, *key, out) == 0
+        assert tuple(out) == exp
 
 
 def test_element_dropout_stream_definition():

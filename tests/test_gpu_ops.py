@@ -547,6 +547,70 @@ def test_fp16_range_guard_sets_the_sticky_flag(sdy):
     assert rel_l2(got, F.conv2d(xs.double(), ws.double())) < 5e-6
 
 
+def test_legendre_inputs_are_guarded_at_their_producers(sdy):
+    """The folded Legendre kernel (leg_par) stages (x[k] +- x[mirror]) * 16 as fp16 and has no register left for a range guard, so
+    its inputs are guarded where they are PRODUCED.  Analysis: rfft360 -- a field that is harmless everywhere else (|x| = 400:
+    x 16 = 6400) has the zonal-mean coefficient Xf[m = 0] = 2 pi x 400 = 2513, and 2 x 16 x 2513 passes 65504: the flag must
+    come from the FFT's stores, not one InstanceNorm later as "non-finite".  Synthesis: dh_h3's stores -- small coefficients,
+    large filter weights.  The fp32 mode has no limit and raises nothing."""
+    ops = sdy.ops
+    nlat, nlon = 180, 360
+    ops.status_flags(reset=True)
+    x = torch.zeros(1, 16, nlat, nlon)
+    x[:, 3] = 300.0                                  # 2 pi 300 x 32 = 60.3e3: inside
+    sht = sdy.RealSHT(nlat, nlon, grid="legendre-gauss", gemm_mode="h3")
+    c = sht(x.cuda())
+    assert ops.status_flags(reset=True) == 0 and torch.isfinite(torch.view_as_real(c)).all()
+    x[:, 3] = 400.0                                  # 2 pi 400 x 32 = 80.4e3: outside the (conservative) bound
+    sht(x.cuda())
+    assert ops.status_flags(reset=True) & ops.FLAG_F16_RANGE
+    sdy.RealSHT(nlat, nlon, grid="legendre-gauss", gemm_mode="f32")(x.cuda())
+    assert ops.status_flags(reset=True) == 0
+    # dh_h3: |x| ~ 1, weights ~ 300: outputs of ~ 300 sqrt(512) = 6800 > 4094 = 65504 / 16
+    g = _gen(8)
+    L, M = 20, 11
+    xc = torch.randn(2, 256, L, M, dtype=torch.complex64, generator=g) * (torch.arange(M)[None, :] <= torch.arange(L)[:, None])
+    w = torch.randn(256, 256, L, 2, generator=g)
+    got = ops.contract_dhconv(xc.cuda(), (0.02 * w).cuda(), gemm_mode="h3")
+    assert ops.status_flags(reset=True) == 0
+    got = ops.contract_dhconv(xc.cuda(), (300.0 * w).cuda(), gemm_mode="h3")
+    assert float(torch.view_as_real(got).abs().max()) > 4094.0 and torch.isfinite(torch.view_as_real(got)).all()
+    assert ops.status_flags(reset=True) & ops.FLAG_F16_RANGE          # the coefficients themselves are fine: their CONSUMER is not
+
+
+def test_range_headroom_reports_the_distance_to_the_cliff(sdy):
+    """`sdy_range_headroom` (ops.range_headroom): the largest magnitude each consumer class stages as fp16, pre-scale included,
+    while the debug read-back is on -- "x N below the cliff" instead of pass / fail.  Exact for a single convolution (max |x| = 3
+    -> 16 x 3 = 48); all five classes report for a forward of a production-width network, none of them near 65504 for a
+    trained-like network on standardised inputs; nothing is recorded while the switch is off."""
+    ops = sdy.ops
+    g = _gen(9)
+    x = torch.randn(1, 256, 32, 64, generator=g).clamp(-2.5, 2.5)
+    x[0, 200, 31, 63] = -3.0
+    w = torch.randn(256, 256, 1, 1, generator=g) / 16.0
+    with ops.range_headroom() as h:
+        ops.conv1x1(x.cuda(), w, None, h3=True)
+    assert h.max_staged["conv_h3 x tile"] == 48.0 and abs(h.factor["conv_h3 x tile"] - 65504.0 / 48.0) < 1e-9
+    assert h.max_staged["mlp_h3 x tile"] == 0.0 and h.factor["mlp_h3 x tile"] == float("inf")
+    with ops.range_headroom() as h2:
+        pass
+    ops.conv1x1(x.cuda(), w, None, h3=True)           # switch off: no bookkeeping
+    with ops.range_headroom() as h3:
+        pass
+    assert all(v == 0.0 for v in h2.max_staged.values()) and all(v == 0.0 for v in h3.max_staged.values())
+    from sdy_amd import synthetic
+    net = synthetic.build_network(8, 6, 2, nlat=180, nlon=360, embed=256, layers=2, dropout_mlp=0.1, drop_path_rate=0.1,
+                                  time_range=(0.0, 5.0))
+    xin = torch.randn(2, 8, 180, 360, generator=g).cuda()
+    cond = torch.randn(2, 2, 180, 360, generator=g).cuda()
+    ops.status_flags(reset=True)
+    with ops.range_headroom() as hn:
+        net(xin, time=torch.tensor([1.0, 4.0]).cuda(), condition=cond)
+    assert ops.status_flags(reset=True) == 0
+    for name, v in hn.max_staged.items():
+        assert 1.0 < v < 65504.0 / 4.0, f"{name}: staged maximum {v} (factor {hn.factor[name]:.1f})"
+
+
 def test_decoder_pair_flags_nonfinite_inputs_and_takes_any_magnitude(sdy):
     """The decoder is the only consumer of the last block's output (no InstanceNorm in between, whose statistics flag
     non-finite tensors everywhere else) and a max-based guard ignores NaNs: sdy_pair_h3's decoder shapes set

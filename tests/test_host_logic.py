@@ -438,11 +438,17 @@ def test_bench_reads_the_counter_traffic_of_the_newest_profile():
     sys.path.insert(0, root)
     import bench
 
-    traffic, src = bench.measured_traffic()
-    assert src is not None and os.path.exists(os.path.join(root, src)) and src.endswith("pmc_summary.txt")
-    newest = sorted(d for d in os.listdir(os.path.join(root, "profiles"))
-                    if os.path.exists(os.path.join(root, "profiles", d, "pmc_summary.txt")))[-1]
-    assert src == os.path.join("profiles", newest, "pmc_summary.txt")
+    traffic, src, why = bench.measured_traffic()
+    prof = os.path.join(root, "profiles")
+    key = lambda d: bench.profile_round_key(os.path.join(prof, d, "x"))  # noqa: E731
+    assert key("r10a") > key("r5d") > key("r5c") > key("r4f") and key("bench_r1_first.json") == (-1, "")   # rounds, not strings
+    newest_pmc = sorted((d for d in os.listdir(prof) if os.path.exists(os.path.join(prof, d, "pmc_summary.txt"))), key=key)[-1]
+    newest_trace = sorted((d for d in os.listdir(prof) if os.path.exists(os.path.join(prof, d, "kernel_stats.csv"))), key=key)[-1]
+    if key(newest_trace) > key(newest_pmc):       # a round that re-profiled without the counter passes: null, with the reason
+        assert traffic is None and src is None and "stale" in why
+        return
+    assert why is None and src == os.path.join("profiles", newest_pmc, "pmc_summary.txt")
+    assert os.path.exists(os.path.join(root, src))
     algorithmic = 3 * 4.0 * 256 * 180 * 360 * 25            # x, residual, output: fp32 (25, 256, 180, 360) tensors
     assert algorithmic <= traffic <= 1.15 * algorithmic, (traffic, algorithmic)
     # the per-launch work of a stage scales with the rows its launches covered (drop-path skip)
