@@ -332,6 +332,10 @@ typedef struct sdy_sfno_fwd_args {
                               src/diffusion/dyffusion.py:497,515): the input concat and the encoder are skipped and the forward
                               restarts from the stored encoder output -- bit-identical results (time, dropout call number and
                               masks may differ: they enter after the encoder).  SDY_ERR_STATE if there is no such forward. */
+  int shared_inputs;       /* 1 (needs rows_per_call = n < B): the stacked calls share their inputs -- every `in` tensor holds n
+                              rows, and row b of the forward reads input row b % n (the two interpolations of a cold-sampling
+                              step as ONE forward of 2n rows: same (x_0, forecast) and static condition, other time and dropout
+                              call).  The encoder then runs on n rows; results are bit-identical to stacking copies. */
 } sdy_sfno_fwd_args;
 int sdy_sfno_forward(sdy_sfno* net, const sdy_sfno_fwd_args* args, void* stream);
 

@@ -133,6 +133,7 @@ class SdySfnoFwdArgs(C.Structure):
         ("drop_path_keep", C.c_void_p),
         ("ws", C.c_void_p), ("ws_floats", C.c_size_t),
         ("reuse_encoder", C.c_int),
+        ("shared_inputs", C.c_int),
     ]
 
 

@@ -1130,13 +1130,21 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   if (ns == 0 || ctot != Cin) return SDY_ERR_SHAPE;
   const long cat_bs = (long)n->catC * HW;
   float* cat_in = cat + (size_t)(n->catC - Cin) * HW;
-  // (reuse_encoder: the inputs already sit in the tail of `cat` -- no block writes there -- and the encoder output in xe)
-  if (!reuse) SDY_STAGE(ST_CONCAT, sdy_concat_launch(srcs, chans, ns, cat_in, cat_bs, B, HW, stream));
-
-  // ---- time embedding + per-layer (scale|shift) + drop-path scales
   const bool drop = a->enable_dropout != 0;
   if (a->rows_per_call < 0 || (a->rows_per_call > 0 && B % a->rows_per_call)) return SDY_ERR_ARG;
   const int rpc = a->rows_per_call > 0 ? a->rows_per_call : B;   // stacked calls (sdy_sfno_fwd_args.rows_per_call)
+  // shared_inputs: the stacked calls read the same rpc input rows (row b: input row b % rpc).  The concat still writes all B
+  // rows (the decoder reads them beside every row's own block output); the ENCODER runs on the rpc distinct rows when block 0
+  // can take its input through a row rule -- its only reader is then the forward FFT (x_mod): the grid-changing first block of
+  // an equiangular data grid on the fft360 + leg_par path, with the encoder's own statistics (the production shape).
+  const bool shared = a->shared_inputs != 0;
+  if (shared && (reuse || rpc >= B)) return SDY_ERR_ARG;
+  // (reuse_encoder: the inputs already sit in the tail of `cat` -- no block writes there -- and the encoder output in xe)
+  if (!reuse) SDY_STAGE(ST_CONCAT, sdy_concat_launch(srcs, chans, ns, cat_in, cat_bs, B, HW, stream, shared ? rpc : 0));
+  const bool enc_once = shared && n->enc.w && n->plan_data != n->plan_lg && plan_tiled_ok(n->plan_data, E, spec_ilv(c));
+  const int Be = enc_once ? rpc : B;                               // rows the encoder computes
+
+  // ---- time embedding + per-layer (scale|shift) + drop-path scales
   SDY_STAGE(ST_TIME_MLP, sdy_time_mlp_launch(n->tm, a->time, B, trep, ss, dp, a->drop_path_keep, drop ? 1 : 0, a->seed,
                                              a->call, a->batch_offset, rpc, stream,
                                              trep + (size_t)B * (n->cfg.with_time_emb ? n->cfg.time_dim : 1)));
@@ -1181,10 +1189,10 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
     pa.x = cat_in; pa.x_bstride = cat_bs; pa.w = n->enc.w; pa.w1_scale = n->enc.s1; pa.w2_scale = n->enc.s2;
     pa.b1 = n->e0b.p; pa.out = xe; pa.out_bstride = (long)E * HW;
     if (c.pos_embed) { pa.add = n->pos.p; pa.add_bstride = 0; }
-    pa.B = B; pa.Cin = Cin; pa.hidden = E; pa.Cout = E; pa.HW = HW;
-    SDY_HIP_TRY(hipMemsetAsync(ste, 0, (size_t)B * E * 2 * sizeof(double), stream));
+    pa.B = Be; pa.Cin = Cin; pa.hidden = E; pa.Cout = E; pa.HW = HW;
+    SDY_HIP_TRY(hipMemsetAsync(ste, 0, (size_t)Be * E * 2 * sizeof(double), stream));
     pa.stats = ste; have_ste = true;
-    SDY_STAGE(ST_ENC_PAIR, sdy_pair_h3(&pa, stream));
+    SDY_STAGE_N(ST_ENC_PAIR, Be, sdy_pair_h3(&pa, stream));
   } else {
   conv_reset();
   cv.x = cat_in; cv.x_bstride = cat_bs; use_w(n->e0w); cv.ldw = E; cv.out = xa; cv.out_bstride = (long)E * HW;
@@ -1201,9 +1209,11 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
   }
   SDY_STAGE(ST_ENC2, sdy_conv1x1(&cv, stream));
   }
-  n->enc_ws = ws; n->enc_B = B; n->enc_has_stats = have_ste;
-  if (have_ste) {
-    SDY_HIP_TRY(hipMemcpyAsync(st0, ste, (size_t)B * E * 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  // (a forward that ran the encoder on the shared rows only leaves nothing a later reuse_encoder forward of B rows could take)
+  n->enc_ws = enc_once ? nullptr : ws; n->enc_B = B; n->enc_has_stats = have_ste;
+  if (have_ste) {   // every stacked call starts from the statistics of the rows it shares
+    for (int b0 = 0; b0 < B; b0 += Be)
+      SDY_HIP_TRY(hipMemcpyAsync(st0 + (size_t)b0 * E * 2, ste, (size_t)Be * E * 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
     have_st0 = true;
   }
 
@@ -1272,7 +1282,8 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
 
     if (Bf > 0) {
       SDY_STAGE_N(ST_FFT_FWD, Bf, sdy_fft_launch_fwd(pin->fft, cur, ca, cd, (scale_residual || lazy_norm) ? nullptr : xn, Xf, Bf, E,
-                                                     pin->nlat, pin->mtr, tiled_in ? 2 : ilv, polar_in ? pin->d_mcut : nullptr, stream, rows));
+                                                     pin->nlat, pin->mtr, tiled_in ? 2 : ilv, polar_in ? pin->d_mcut : nullptr, stream, rows,
+                                                     (i == 0 && enc_once) ? Be : 0));
       SDY_STAGE_N(ST_LEG_FWD, Bf, legendre_fwd_impl(pin, Xf, Cs, Bf, E, polar_in, stream, tiled_in, cs_tiled));
       if (scale_residual) {  // residual = inverse_transform(forward_transform(x)); in the order `perm` when rows were dropped
         SDY_STAGE(ST_LEG_INV, legendre_inv_impl(pout, Cs, Xf, B, E, polar_out, stream, tiled_out, cs_tiled));

@@ -18,9 +18,10 @@ struct SdyFftDesc {
 
 // x_rows (host, [B], or nullptr = identity; fft360 only, B <= 128): row b of Xf is the transform of batch row x_rows[b] of
 // x / a / d / xn_out -- the drop-path skip of the fused forward runs a block on its active trajectories only (common.h, SdyImgMap)
+// x_mod > 0 (fft360 only): x holds x_mod rows and batch row r reads x row r % x_mod (stacked calls that share their inputs)
 int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                        int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream,
-                       const unsigned char* x_rows = nullptr);
+                       const unsigned char* x_rows = nullptr, int x_mod = 0);
 int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K, int mtr,
                        int ilv, const int* mcut, hipStream_t stream);
 
@@ -36,6 +37,6 @@ int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, 
 // nlon = 360 specialisation (fft360.hip); SDY_ERR_UNSUPPORTED when the shape does not fit
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                           int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream,
-                          const unsigned char* x_rows = nullptr);
+                          const unsigned char* x_rows = nullptr, int x_mod = 0);
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
                           int mtr, int ilv, const int* mcut, hipStream_t stream);

@@ -434,14 +434,14 @@ bool use_generic_only() {
 
 int sdy_fft_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                        int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream,
-                       const unsigned char* x_rows) {
+                       const unsigned char* x_rows, int x_mod) {
   if (ilv && C % CB != 0) return SDY_ERR_UNSUPPORTED;
   if (f.n == 180 && !use_generic_only()) {
-    const int rc = sdy_fft360_launch_fwd(f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut, stream, x_rows);
+    const int rc = sdy_fft360_launch_fwd(f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut, stream, x_rows, x_mod);
     if (rc != SDY_ERR_UNSUPPORTED) return rc;
   }
-  // polar cut-off / tile-major layout / image map: contracts of fft360 only
-  if (mcut || ilv == 2 || x_rows) return SDY_ERR_UNSUPPORTED;
+  // polar cut-off / tile-major layout / image map / shared input rows: contracts of fft360 only
+  if (mcut || ilv == 2 || x_rows || x_mod) return SDY_ERR_UNSUPPORTED;
   const size_t smem = fft_smem_bytes(f);
   if (smem > 64 * 1024) return SDY_ERR_UNSUPPORTED;
   constexpr int KPW = 4;   // latitude rings per workgroup on the pipelined (compile-time size) paths

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
                                                            float* __restrict__ xn_out, float* __restrict__ Xf, int B,
                                                            int C, int K, int mtr, int ilv,
                                                            const int* __restrict__ mcut, const SdyImgMap xmap,
-                                                           unsigned* flags, unsigned* head) {
+                                                           unsigned* flags, unsigned* head, int x_mod) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
   __shared__ c2 TW[TWN];
   __shared__ c2 AD[ROWS];   // per-slot affine (a, d)
@@ -241,7 +241,9 @@ __global__ __launch_bounds__(NT, MINB_F) void rfft360_kernel(const SdyFftDesc f,
     AD[s] = pa ? c2{pa[bx * C + ch], pd[bx * C + ch]} : c2{1.0f, 0.0f};
   }
 
-  const float* xw = x + (((long)bx * C + c0 + L.wave) * K) * NLON + 4 * L.lane;      // row r of the wave: + 4 r K N
+  // x_mod > 0: the batch stacks calls that share their input tensor, which holds x_mod rows (the affine and xn_out stay per row)
+  const int bsrc = x_mod > 0 ? bx % x_mod : bx;
+  const float* xw = x + (((long)bsrc * C + c0 + L.wave) * K) * NLON + 4 * L.lane;    // row r of the wave: + 4 r K N
   float* xnw = xn_out ? xn_out + (((long)bx * C + c0 + L.wave) * K) * NLON + 4 * L.lane : nullptr;
   const long rstride = 4L * K * NLON;
   c2* zw = Z + 4 * L.wave * P + 2 * L.lane;
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
 // nlon = 360 fast path; returns SDY_ERR_UNSUPPORTED when the shape does not fit (the caller falls back to fft.hip)
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                           int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream,
-                          const unsigned char* x_rows) {
+                          const unsigned char* x_rows, int x_mod) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
   if (ilv == 2 && (C % (2 * ROWS) != 0 || ROWS != 16)) return SDY_ERR_UNSUPPORTED;   // a 64-column tile = two channel blocks
   constexpr int KPW = SDY_FFT_KPW;
@@ -454,7 +456,7 @@ int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, c
     SDY_TRY(sdy_headroom_ptr(SDY_RANGE_LEG_ANALYSIS, &head));
   }
   hipLaunchKernelGGL((rfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, x, a, d, xn_out, Xf, B, C, K, mtr, ilv, mcut, xmap,
-                     flags, head);
+                     flags, head, x_mod);
   return sdy_launch_status();
 }
 

@@ -21,7 +21,7 @@ struct SdyTimeMlp {
 int sdy_instnorm_coeffs_launch(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
                                const float* ss, long ss_stride, float eps, float* a, float* d, hipStream_t stream);
 int sdy_concat_launch(const float* const* src, const int* chans, int nsrc, float* out, long out_bstride, int B, int HW,
-                      hipStream_t stream);
+                      hipStream_t stream, int src_rows = 0);   // src_rows > 0: output row b reads source row b % src_rows
 int sdy_cold_update_launch(const float* xs, const float* xn, const float* xi, float* out, size_t n, hipStream_t stream);
 // scratch: dev, B * T floats (2 B T when trep is NULL) -- the hidden layer between the launches
 int sdy_time_mlp_launch(const SdyTimeMlp& t, const float* time, int B, float* trep, float* ss, float* dp,

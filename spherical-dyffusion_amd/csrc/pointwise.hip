@@ -150,19 +150,20 @@ struct ConcatArgs {
   int nsrc;
 };
 __global__ __launch_bounds__(256) void concat_kernel(const ConcatArgs a, float* __restrict__ out, long out_bstride,
-                                                      int HW4) {
+                                                      int HW4, int src_rows) {
   // grid: (ceil(HW4/256), total_chans, B); one float4 per thread
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= HW4) return;
   int c = blockIdx.y;
   const int b = blockIdx.z;
+  const int bs = src_rows > 0 ? b % src_rows : b;   // stacked calls that share their inputs (sdy_sfno_fwd_args.shared_inputs)
   int s = 0, coff = 0;
   while (s < a.nsrc - 1 && c >= a.chans[s]) {
     c -= a.chans[s];
     coff += a.chans[s];
     ++s;
   }
-  const f32x4* src = reinterpret_cast<const f32x4*>(a.src[s] + ((long)b * a.chans[s] + c) * HW4 * 4);
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.src[s] + ((long)bs * a.chans[s] + c) * HW4 * 4);
   f32x4* dst = reinterpret_cast<f32x4*>(out + (long)b * out_bstride + (long)(coff + c) * HW4 * 4);
   dst[i] = src[i];
 }
@@ -833,7 +834,7 @@ int sdy_affine_copy_stats_launch(const float* x, long x_bs, const float* a, cons
 }
 
 int sdy_concat_launch(const float* const* src, const int* chans, int nsrc, float* out, long out_bstride, int B, int HW,
-                      hipStream_t stream) {
+                      hipStream_t stream, int src_rows) {
   if (!src || !chans || !out || nsrc < 1 || nsrc > 4 || B <= 0 || HW <= 0) return SDY_ERR_ARG;
   if (HW & 3) return SDY_ERR_ALIGN;
   ConcatArgs a;
@@ -848,7 +849,7 @@ int sdy_concat_launch(const float* const* src, const int* chans, int nsrc, float
   }
   a.nsrc = nsrc;
   const int HW4 = HW / 4;
-  hipLaunchKernelGGL(concat_kernel, dim3((HW4 + 255) / 256, total, B), dim3(256), 0, stream, a, out, out_bstride, HW4);
+  hipLaunchKernelGGL(concat_kernel, dim3((HW4 + 255) / 256, total, B), dim3(256), 0, stream, a, out, out_bstride, HW4, src_rows);
   return sdy_launch_status();
 }
 

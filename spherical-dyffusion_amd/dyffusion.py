@@ -95,6 +95,8 @@ class DYffusion(torch.nn.Module):
         # (same inputs: sdy_sfno_fwd_args.reuse_encoder); False = two full forwards (A/B, tests)
         import os
         self.reuse_interpolator_encoder = bool(reuse_interpolator_encoder) and os.environ.get("SDY_NO_ENCODER_REUSE") is None
+        # the stacked pair hands its (identical) inputs over once and encodes them once; SDY_NO_SHARED_INPUTS=1: stacked copies (A/B)
+        self.share_pair_inputs = os.environ.get("SDY_NO_SHARED_INPUTS") is None
         self.full_sampling_schedule = list(range(0, self.num_timesteps))
         self.sampling_schedule = sampling_schedule or self.full_sampling_schedule
         # DYffusion.__init__ consistency check (dyffusion.py:632-640)
@@ -268,19 +270,27 @@ class DYffusion(torch.nn.Module):
         kwargs.pop("num_predictions", None)
         dyn = kwargs.pop("dynamical_condition", None)
         two = lambda v: torch.cat([v, v], dim=0)  # noqa: E731
-        kwargs = {k: (two(v) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in kwargs.items()}
-        if dyn is not None:   # the condition at each call's own time
-            kwargs["condition"] = torch.cat([self.interpolator.get_dynamical_condition(dyn, i_a),
-                                             self.interpolator.get_dynamical_condition(dyn, i_b)], dim=0)
         time = torch.cat([self._time_tensor(i_a, x0), self._time_tensor(i_b, x0)])
         hack = self.hparams.hack_for_imprecise_interpolation
         inputs = ops.concat_channels([x_end] + ([x_end[:, :1]] if hack else []) + [x0])
+        # Without a time-dependent condition the two calls see the SAME input rows: they are handed over once
+        # (`shared_inputs`: row b of the stacked batch reads input row b % B) and the encoder runs once.
+        share = dyn is None and self.share_pair_inputs and \
+            getattr(getattr(self.interpolator, "model", None), "supports_shared_inputs", False)
+        if not share:
+            kwargs = {k: (two(v) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in kwargs.items()}
+            if dyn is not None:   # the condition at each call's own time
+                kwargs["condition"] = torch.cat([self.interpolator.get_dynamical_condition(dyn, i_a),
+                                                 self.interpolator.get_dynamical_condition(dyn, i_b)], dim=0)
+            inputs = two(inputs)
+        else:
+            kwargs["shared_inputs"] = True
         do_enable = bool(
             self.enable_interpolator_dropout in [True, "always"]
             or (self.enable_interpolator_dropout == "except_dynamical_steps" and is_artificial_step)
         )
         with self.interpolator.inference_dropout_scope(condition=do_enable):
-            out = self.interpolator.predict_packed(two(inputs), time=time, rows_per_call=B, **kwargs)["preds"]
+            out = self.interpolator.predict_packed(inputs, time=time, rows_per_call=B, **kwargs)["preds"]
         if hack:
             out = ops.concat_channels([two(x_end[:, :1]), out])
         return out[:B], out[B:]

@@ -117,6 +117,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         self.batch_offset = 0           # global index of the first trajectory this rank owns
         self._call = 0                  # advances the dropout stream on every forward
         self.mask_injector = None       # tests: callable(call_index) -> (keep_masks, drop_path_keep) replacing Philox
+        self.supports_shared_inputs = True     # forward(shared_inputs=True): stacked calls that share their input rows
 
         E, T, H, Cin, L = embed_dim, self.time_dim, self.mlp_hidden, self.in_chans, self.modes_lat
         P = lambda *s: nn.Parameter(torch.zeros(*s), requires_grad=False)  # noqa: E731
@@ -329,7 +330,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
     # ---- forward ------------------------------------------------------------------------------------------------
     def forward(self, inputs, time=None, condition=None, static_condition=None, return_time_emb: bool = False,
                 keep_masks=None, drop_path_keep=None, rows_per_call: Optional[int] = None, reuse_encoder: bool = False,
-                **kwargs):
+                shared_inputs: bool = False, **kwargs):
         """`reuse_encoder=True`: the caller guarantees that `inputs` / `condition` / `static_condition` hold the same values
         as in the previous forward of this network (same batch): the input concat and the encoder are skipped and the
         forward restarts from the stored encoder output -- bit-identical results; `time` and the dropout call number may
@@ -337,7 +338,10 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         `rows_per_call=n` (n divides the batch): the batch stacks B / n CALLS of n trajectories each -- row b draws the
         dropout stream of call number `_call + b // n`, trajectory `batch_offset + b % n`, exactly as if the calls had
         been issued one after the other, and the call counter advances by B / n.  (The two interpolator calls of a DYffusion
-        sampling step share their inputs, reference dyffusion.py:497,515.)"""
+        sampling step share their inputs, reference dyffusion.py:497,515.)
+        `shared_inputs=True` (with `rows_per_call=n`): the stacked calls share their inputs -- `inputs` / `condition` /
+        `static_condition` hold n rows, `time` one value per row of the stacked batch (B = len(time)), and row b reads input
+        row b % n: no stacked copy of the inputs is made and the encoder runs once (bit-identical to stacking copies)."""
         if return_time_emb:
             raise NotImplementedError("return_time_emb is a training-path feature")
         if not inputs.is_cuda:
@@ -352,10 +356,14 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             assert condition is None, "condition is not None but num_conditional_channels is 0"
             assert static_condition is None, "static_condition is not None but num_conditional_channels is 0"
         pieces = [t.to(torch.float32).contiguous() for t in (inputs, condition, static_condition) if t is not None]
-        B = inputs.shape[0]
+        B = B_in = inputs.shape[0]
+        if shared_inputs:
+            assert rows_per_call == B_in and self.with_time_emb and torch.is_tensor(time) and time.numel() % B_in == 0 \
+                and time.numel() > B_in, "shared_inputs: rows_per_call = the inputs' rows, one time per stacked row"
+            B = time.numel()
         nlat, nlon = self.img_shape
         for t in pieces:
-            assert t.shape[0] == B and tuple(t.shape[-2:]) == (nlat, nlon), f"bad input shape {tuple(t.shape)}"
+            assert t.shape[0] == B_in and tuple(t.shape[-2:]) == (nlat, nlon), f"bad input shape {tuple(t.shape)}"
         if sum(t.shape[1] for t in pieces) != self.in_chans:
             raise RuntimeError(f"inputs.shape: {tuple(inputs.shape)}, expected {self.in_chans} channels in total, got "
                                f"{[t.shape[1] for t in pieces]}")
@@ -381,7 +389,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             # One native call covers `max_b` rows (32-bit lane offsets in the spectral workspace: 60 at 180 x 360, E = 256).
             # A larger batch runs as consecutive calls on near-equal row ranges; every row keeps its dropout stream (same call
             # number, batch_offset + first row of the range), so the result equals the single call's row for row.
-            if rows_per_call not in (None, B) or keep_masks is not None or drop_path_keep is not None or \
+            if rows_per_call not in (None, B) or shared_inputs or keep_masks is not None or drop_path_keep is not None or \
                     (self.mask_injector is not None and self.inference_dropout):
                 raise _lib.SdyError(f"batch {B} > {max_b} rows per native call cannot be split with stacked calls / injected masks")
             n_chunks = -(-B // max_b)
@@ -403,12 +411,12 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         if keep_masks is None and drop_path_keep is None and self.mask_injector is not None and self.inference_dropout:
             keep_masks, drop_path_keep = self.mask_injector(self._call)
         self._native_call(h, dev, pieces, tt, out, self._call, self.batch_offset, rows_per_call, keep_masks, drop_path_keep,
-                          reuse_encoder=bool(reuse_encoder))
+                          reuse_encoder=bool(reuse_encoder), shared_inputs=bool(shared_inputs))
         self._call += n_calls
         return out
 
     def _native_call(self, h, dev, pieces, tt, out, call: int, batch_offset: int, rows_per_call: Optional[int] = None,
-                     keep_masks=None, drop_path_keep=None, reuse_encoder: bool = False) -> None:
+                     keep_masks=None, drop_path_keep=None, reuse_encoder: bool = False, shared_inputs: bool = False) -> None:
         """One sdy_sfno_forward on prepared (fp32, contiguous-per-row) inputs; `out` is a (B, out_chans, nlat, nlon) view."""
         B = out.shape[0]
         ws = self._workspace(h, dev, B)
@@ -438,6 +446,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             a.drop_path_keep = ptr(dk)
         a.ws, a.ws_floats = ptr(ws), ws.numel()
         a.reuse_encoder = int(reuse_encoder)
+        a.shared_inputs = int(shared_inputs)
         with torch.cuda.device(dev):
             check(lib.sdy_sfno_forward(h, C.byref(a), current_stream()), "sdy_sfno_forward")
 

@@ -373,6 +373,45 @@ def test_fused_interpolator_pair_equals_two_calls(hack):
         inet(torch.cat([inp, inp]), time=t, static_condition=torch.cat([c, c]), rows_per_call=4)
 
 
+@pytest.mark.parametrize("shape", ["production", "generic"])
+def test_stacked_calls_that_share_their_inputs_run_the_encoder_once(shape):
+    """`forward(shared_inputs=True, rows_per_call=n)`: the stacked calls of a cold-sampling step read the same n input rows
+    (reference call sites dyffusion.py:497,515: same x_0, forecast and static condition, other time and dropout call).  On the
+    production shape (180 x 360, E = 256, equiangular data grid: fft360 + leg_par, fused encoder) the encoder runs on n rows
+    and the first block's FFT reads its rows modulo n; other shapes fall back to encoding every row.  Either way the result
+    equals the forward on stacked copies bit for bit, dropout and drop path on, and the stage timer sees the encoder's rows."""
+    import sdy_amd
+    from sdy_amd import synthetic
+
+    g = torch.Generator(device="cpu").manual_seed(31)
+    if shape == "production":
+        nlat, nlon, embed = 180, 360, 256
+    else:
+        nlat, nlon, embed = 32, 64, 16
+    net = synthetic.build_network(10, 5, 2, nlat=nlat, nlon=nlon, embed=embed, layers=2, dropout_mlp=0.1, drop_path_rate=0.2,
+                                  time_range=(1.0, 5.0))
+    n = 3
+    x = torch.randn(n, 10, nlat, nlon, generator=g).cuda()
+    c = torch.randn(n, 2, nlat, nlon, generator=g).cuda()
+    t = torch.tensor([2.0] * n + [1.0] * n).cuda()
+    net.enable_inference_dropout()
+    net.batch_offset, net._call = 4, 10
+    with sdy_amd.ops.stage_timer() as tm:
+        a = net(torch.cat([x, x]), time=t, static_condition=torch.cat([c, c]), rows_per_call=n)
+    net._call = 10
+    with sdy_amd.ops.stage_timer() as ts:
+        b = net(x, time=t, static_condition=c, rows_per_call=n, shared_inputs=True)
+    assert net._call == 12 and a.shape == b.shape == (2 * n, 5, nlat, nlon)
+    assert torch.equal(a, b), f"shared inputs differ from stacked copies: {float((a - b).abs().max()):.3e}"
+    assert not torch.equal(b[:n], b[n:])                       # the two calls are different samples at different times
+    if shape == "production":
+        assert tm.rows["encoder (fused pair)"] == 2 * n and ts.rows["encoder (fused pair)"] == n
+    if shape == "production":     # a forward that encoded the shared rows only cannot serve a later reuse_encoder forward
+        with pytest.raises(sdy_amd.SdyError):
+            net(torch.cat([x, x]), time=t, static_condition=torch.cat([c, c]), rows_per_call=n, reuse_encoder=True)
+    net.disable_inference_dropout()
+
+
 def test_stepper_autoregressive_init_handoff():
     """use_cold_sampling_for_last_step = False (dyffusion.py:503-510): the last prediction of a window is the plain forecast,
     while the cold-sampled state is handed to the next window as `preds_autoregressive_init` (stepper_multistep.py:412-418),

@@ -588,13 +588,14 @@ def test_range_headroom_reports_the_distance_to_the_cliff(sdy):
     x = torch.randn(1, 256, 32, 64, generator=g).clamp(-2.5, 2.5)
     x[0, 200, 31, 63] = -3.0
     w = torch.randn(256, 256, 1, 1, generator=g) / 16.0
+    frag = ops.pack_conv256(w, torch.device("cuda"))            # the persistent kernel conv_h3 (the tile GEMMs are not tracked)
     with ops.range_headroom() as h:
-        ops.conv1x1(x.cuda(), w, None, h3=True)
+        ops.conv1x1(x.cuda(), w, None, frag_prepared=frag)
     assert h.max_staged["conv_h3 x tile"] == 48.0 and abs(h.factor["conv_h3 x tile"] - 65504.0 / 48.0) < 1e-9
     assert h.max_staged["mlp_h3 x tile"] == 0.0 and h.factor["mlp_h3 x tile"] == float("inf")
     with ops.range_headroom() as h2:
         pass
-    ops.conv1x1(x.cuda(), w, None, h3=True)           # switch off: no bookkeeping
+    ops.conv1x1(x.cuda(), w, None, frag_prepared=frag)           # switch off: no bookkeeping
     with ops.range_headroom() as h3:
         pass
     assert all(v == 0.0 for v in h2.max_staged.values()) and all(v == 0.0 for v in h3.max_staged.values())
