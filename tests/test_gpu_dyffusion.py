@@ -63,6 +63,56 @@ def test_sample_matches_oracle(hack):
         assert err < TOL, f"{k} (hack={hack}): rel L2 {err:.3e}"
 
 
+@pytest.mark.parametrize("schedule", [None, "every2nd"])
+def test_sample_with_artificial_steps_and_per_call_dropout_matches_oracle(schedule):
+    """additional_interpolation_steps = 2 with `enable_interpolator_dropout="except_dynamical_steps"` on the PRODUCT's own dropout
+    stream (Philox, replayed by the oracle): the steps that land on an artificial time run their interpolations with dropout on,
+    the others with it off -- in the product as stacked pairs with shared inputs (B = 2 <= 8), in the oracle call by call.  The
+    call counter advances with every interpolator forward whether or not it draws, so the oracle numbers its calls likewise.
+    (The reference's recorded masks drive the same configuration in tests/test_gpu_golden.py.)"""
+    import sdy_amd
+
+    horizon, hack = 6, True
+    cs, n_forc, C = 7, 2, 6
+    fcfg = SFNOConfig(in_chans=cs + n_forc, out_chans=C, nlat=32, nlon=64, embed_dim=16, num_layers=2, with_time_emb=True,
+                      min_time=0.0, max_time=5.0)
+    icfg = SFNOConfig(in_chans=2 * cs + n_forc, out_chans=C, nlat=32, nlon=64, embed_dim=16, num_layers=2, with_time_emb=True,
+                      dropout_mlp=0.1, drop_path_rate=0.1, min_time=0.0, max_time=5.0)
+    fnet, fora, _ = make_pair(fcfg, cs, n_forc, seed=11)
+    inet, iora, _ = make_pair(icfg, 2 * cs, n_forc, seed=22, net_seed=4242)
+    ipol = sdy_amd.InterpolationExperiment(inet, horizon=horizon)
+    inet.set_min_max_time(0.0, 5.0)          # (the experiment pins [1, 5]; artificial steps need the range opened)
+    extra = dict(additional_interpolation_steps=2, enable_interpolator_dropout="except_dynamical_steps")
+    if schedule:
+        extra["sampling_schedule"] = schedule
+    exp = sdy_amd.MultiHorizonForecastingDYffusion(fnet, ipol, horizon=horizon,
+                                                   diffusion_config=dict(hack_for_imprecise_interpolation=hack, **extra))
+    masks = PhiloxMasks(icfg, seed=4242)
+    calls = {"n": 0, "on": 0}
+    oracle = None
+
+    def ora_i(x, time, condition=None, static_condition=None):
+        masks.call = calls["n"]
+        calls["n"] += 1
+        calls["on"] += int(oracle.dropout_on)
+        return iora(x, time=time, condition=condition, static_condition=static_condition,
+                    mask_fn=masks if oracle.dropout_on else None)
+
+    oracle = OracleDYffusion(lambda x, time, condition=None, static_condition=None: fora(
+        x, time=time, condition=condition, static_condition=static_condition), ora_i, timesteps=horizon,
+        hack_for_imprecise_interpolation=hack, **extra)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x0 = torch.randn(2, cs, 32, 64, generator=g)
+    sc = torch.randn(2, n_forc, 32, 64, generator=g)
+    ref = oracle.sample(x0, static_condition=sc)
+    got = exp.model.sample(x0.cuda(), static_condition=sc.cuda())
+    assert inet._call == calls["n"] and 0 < calls["on"] < calls["n"]
+    assert sorted(got) == sorted(ref) == [f"t{i}_preds" for i in range(1, 7)]
+    for k in ref:
+        err = rel_l2(got[k], ref[k])
+        assert err < 2e-5, f"{k}: rel L2 {err:.3e}"
+
+
 def test_get_preds_at_t_for_batch_surface():
     """The stepper's call pattern (stepper_multistep.py:365-427): horizon 1 computes, 2..6 pop the cache."""
     exp, oracle, cs, n_forc = _build(hack=True)
@@ -793,7 +843,7 @@ def test_window_driver_relays_the_remainder_trajectory():
                 for t in range(v.shape[1]):
                     key = (start_sample + r, start_timestep + t)
                     assert key not in self.fields, f"trajectory / time step {key} written twice"
-                    self.fields[key] = v[r, t].clone()
+                    self.fields[key] = v[r, t].detach().cpu().clone()
 
     def job(**kw):
         exp.set_dropout_calls((0, 0))
@@ -809,8 +859,10 @@ def test_window_driver_relays_the_remainder_trajectory():
     for rank in range(world):
         plan = ensemble.relay_plan(members, world, n_windows, rank)
         assert plan.count == 2 and [t.unit for t in plan.tasks] == [6]
-        wr, agg, timers = job(relay=plan, relay_comm=_MailboxComm(box))
-        assert timers["forecast_steps_per_second"] > 0
+        # (the driver's other options ride along: device batches of one row, the synchronous loop with pinned-host outputs)
+        opts = [{}, {"max_batch": 1}, {"prefetch": 0, "host_outputs": True}][rank]
+        wr, agg, timers = job(relay=plan, relay_comm=_MailboxComm(box), **opts)
+        assert timers["forecast_steps_per_second"] > 0 and timers["trajectory_steps"] == (2 * n_windows + 2) * window
         assert not (set(wr.fields) & set(seen))
         seen.update(wr.fields)
         gen_sum = agg._gen_data[out_names[1]].double() if gen_sum is None else gen_sum + agg._gen_data[out_names[1]].double()
