@@ -845,6 +845,17 @@ def test_window_driver_relays_the_remainder_trajectory():
                     assert key not in self.fields, f"trajectory / time step {key} written twice"
                     self.fields[key] = v[r, t].detach().cpu().clone()
 
+    keyed = {}       # (first global trajectory of a device batch, rows) -> dropout call counters it started from, per job
+
+    run_on_batch = stepper.run_on_batch
+
+    def logged(data, *a, **k):
+        rows = next(iter(data.values())).shape[0]
+        keyed.setdefault("log", []).append((exp.model.interpolator.model.batch_offset, rows, exp.dropout_calls()))
+        return run_on_batch(data, *a, **k)
+
+    stepper.run_on_batch = logged
+
     def job(**kw):
         exp.set_dropout_calls((0, 0))
         wr = Writer()
@@ -855,6 +866,11 @@ def test_window_driver_relays_the_remainder_trajectory():
 
     full, agg_full, _ = job()
     assert len(full.fields) == members * (steps + 1)
+    per_window = {c for _, _, c in keyed.pop("log")}
+    assert len(per_window) == n_windows
+    c0, c1 = sorted(per_window)[:2]
+    delta = (c1[0] - c0[0], c1[1] - c0[1])                   # dropout calls of one window (forecaster, interpolator)
+    assert c0 == (0, 0) and delta[1] > 0
     box, seen, gen_sum, gen_rows = {}, {}, None, 0.0
     for rank in range(world):
         plan = ensemble.relay_plan(members, world, n_windows, rank)
@@ -865,6 +881,16 @@ def test_window_driver_relays_the_remainder_trajectory():
         assert timers["forecast_steps_per_second"] > 0 and timers["trajectory_steps"] == (2 * n_windows + 2) * window
         assert not (set(wr.fields) & set(seen))
         seen.update(wr.fields)
+        # The stream position of every device batch, bit for bit (not through chain-amplified states): a batch of window w
+        # starts from the unsharded job's call numbers of window w, whichever rank runs it and in whatever order -- resident
+        # rows keyed by the block's first trajectory, the relay trajectory by its own index.
+        log = keyed.pop("log")
+        res = [e for e in log if e[0] != 6]
+        rel = [e for e in log if e[0] == 6]
+        assert [c for _, _, c in res if True][::(2 if opts.get("max_batch") else 1)] == \
+            [(w * delta[0], w * delta[1]) for w in range(n_windows)]
+        assert [c for _, _, c in rel] == [(w * delta[0], w * delta[1]) for w in range(plan.tasks[0].w_begin, plan.tasks[0].w_end)]
+        assert all(rows == 1 for _, rows, _ in rel) and {off for off, _, _ in res} <= {plan.start, plan.start + 1}
         gen_sum = agg._gen_data[out_names[1]].double() if gen_sum is None else gen_sum + agg._gen_data[out_names[1]].double()
         gen_rows += agg._gen_rows
     assert not box
