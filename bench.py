@@ -179,6 +179,8 @@ def stage_work(B):
         "mlp fused (dropout)": (4.0 * E * Hd * HW * B, 3 * act, "mfma"),
         "mlp fused": (4.0 * E * Hd * HW * B, 3 * act, "mfma"),
         "inner-skip conv": (2.0 * E * E * HW * B, 3 * act, "hbm"),
+        # first / last block: the skip's matrix is folded into the dhconv weights, what remains is GELU + statistics over y
+        "inner skip folded (gelu)": (0.0, 2 * act, "hbm"),
         "legendre analysis": (leg_f, xf + cs, "hbm"),
         "legendre synthesis": (leg_f, xf + cs, "hbm"),
         "rfft (lon)": (0.0, act + xf, "hbm"),

@@ -601,6 +601,11 @@ struct BlockW {
   std::vector<float> w1_host, w2_host;
   void* mlp = nullptr;
   float mlp_s1 = 1.0f, mlp_s2 = 1.0f;
+  // Inner skip FOLDED into the dhconv (grid-changing blocks only, see skip_foldable): host copies of the filter weight, the
+  // skip weight and the two biases until all are known; then `fw.frag` holds W_dh[l] + W_skip and `fbs` = filter bias + skip bias
+  std::vector<float> fw_host, skw_host, fb_host, skb_host;
+  bool skip_folded = false;
+  DevBuf fbs;
 };
 
 }  // namespace
@@ -608,6 +613,19 @@ struct BlockW {
 // Channel order of the forward's spectral buffers (fft.h): the 128-byte-line order whenever the dhconv weights can be
 // packed for it (split-fp16 GEMM path, E % 16 == 0).
 static int spec_ilv(const sdy_sfno_config& c) { return (c.gemm_mode == 1 && c.embed_dim % 16 == 0) ? 1 : 0; }
+
+// Folding the inner skip into the dhconv.  In a grid-changing block (the first / last block of an equiangular data grid) the
+// residual the inner skip reads is ITSELF an inverse transform of the block's coefficients, residual = ISHT(Cs)
+// (s2convolutions.py:79-83,165-168), and a 1 x 1 convolution mixes channels at every pixel, so it commutes with the transform:
+//     ISHT(W_dh[l] Cs) + b_f + W_s ISHT(Cs) + b_s  =  ISHT((W_dh[l] + W_s) Cs) + (b_f + b_s)        (sfnonet.py:303-311)
+// -- the 256 -> 256 convolution of those blocks (8.5 GF and three tensors of traffic each) costs one matrix addition at load
+// time, and `x = act(x + inner_skip(residual))` becomes a GELU pass over the inverse FFT's output.  Exact in exact arithmetic
+// (the two transforms are the same linear map, polar cut-off included); in fp32 the rounding differs at the 1e-7 level.  Only
+// on the dh_h3 path (split-fp16 mode, 256 channels); every other configuration runs the convolution as the reference does.
+static bool skip_foldable(const sdy_sfno_config& c, int i) {
+  const bool first = i == 0, last = i == c.num_layers - 1;
+  return c.gemm_mode == 1 && c.data_grid != SDY_GRID_LEGENDRE_GAUSS && first != last && !std::getenv("SDY_NO_SKIP_FOLD");
+}
 
 struct sdy_sfno {
   sdy_sfno_config cfg;
@@ -730,7 +748,7 @@ extern "C" void sdy_sfno_destroy(sdy_sfno* n) {
                    &n->t3w, &n->t3b, &n->freq, &n->wbt, &n->bb};
   for (DevBuf* b : top) dev_free(*b);
   for (BlockW& w : n->blk) {
-    DevBuf* bs[] = {&w.n0w, &w.n0b, &w.n1w, &w.n1b, &w.fw, &w.fb, &w.skw, &w.skb, &w.w1, &w.b1, &w.w2, &w.b2};
+    DevBuf* bs[] = {&w.n0w, &w.n0b, &w.n1w, &w.n1b, &w.fw, &w.fb, &w.skw, &w.skb, &w.w1, &w.b1, &w.w2, &w.b2, &w.fbs};
     for (DevBuf* b : bs) dev_free(*b);
     if (w.mlp) (void)hipFree(w.mlp);
   }
@@ -830,10 +848,29 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
       w.tb.set = true;
       return SDY_OK;
     }
+    // (re)packs the dh_h3 stream of a foldable block once the filter weight AND the skip weight are known: W_dh[l] + W_skip
+    auto pack_folded = [&]() -> int {
+      if (w.fw_host.empty() || w.skw_host.empty()) return SDY_OK;
+      std::vector<float> sum(w.fw_host);
+      for (int ii = 0; ii < E; ++ii)
+        for (int oo = 0; oo < E; ++oo) {
+          const float ws = w.skw_host[(size_t)oo * E + ii];            // conv weight (out, in); dhconv weight (in, out, l, re | im)
+          float* d = sum.data() + ((size_t)ii * E + oo) * c.lmax * 2;
+          for (int l = 0; l < c.lmax; ++l) d[2 * l] += ws;
+        }
+      if (!w.fw.frag) SDY_HIP_TRY(hipMalloc(&w.fw.frag, sdy_dhconv_frag_pack_bytes(c.lmax)));
+      SDY_TRY(sdy_dh_h3_pack(sum.data(), c.lmax, w.fw.frag, &w.fw.frag_scale, spec_ilv(c)));
+      w.skip_folded = true;
+      return SDY_OK;
+    };
+    const bool fold = skip_foldable(c, i) && sdy_dhconv_frag_supported(E, E) && !sw().no_dh_frag;
     if (rest == "filter.filter.weight") {
       EXPECT_NUMEL((size_t)E * E * c.lmax * 2);
       const bool no_dh_frag = sw().no_dh_frag;
-      if (h3 && sdy_dhconv_frag_supported(E, E) && !no_dh_frag) {   // persistent fragment-stream kernel (dh_h3.hip)
+      if (fold) {   // packed when the skip weight is here too
+        w.fw_host.assign(host, host + numel);
+        SDY_TRY(pack_folded());
+      } else if (h3 && sdy_dhconv_frag_supported(E, E) && !no_dh_frag) {   // persistent fragment-stream kernel (dh_h3.hip)
         if (!w.fw.frag) SDY_HIP_TRY(hipMalloc(&w.fw.frag, sdy_dhconv_frag_pack_bytes(c.lmax)));
         SDY_TRY(sdy_dh_h3_pack(host, c.lmax, w.fw.frag, &w.fw.frag_scale, spec_ilv(c)));
       } else if (h3) {
@@ -848,9 +885,32 @@ extern "C" int sdy_sfno_set_param(sdy_sfno* n, const char* name_c, const float* 
       w.fw.set = true;
       return SDY_OK;
     }
-    if (rest == "filter.filter.bias") { EXPECT_NUMEL(E); return dev_upload(w.fb, host, numel); }
-    if (rest == "inner_skip.weight") { EXPECT_NUMEL((size_t)E * E); return dev_upload_conv(w.skw, host, E, E, E, h3); }
-    if (rest == "inner_skip.bias") { EXPECT_NUMEL(E); return dev_upload(w.skb, host, numel); }
+    auto fold_bias = [&]() -> int {
+      if (!fold || w.fb_host.empty() || w.skb_host.empty()) return SDY_OK;
+      std::vector<float> sum(E);
+      for (int k = 0; k < E; ++k) sum[k] = w.fb_host[k] + w.skb_host[k];
+      return dev_upload(w.fbs, sum.data(), E);
+    };
+    if (rest == "filter.filter.bias") {
+      EXPECT_NUMEL(E);
+      w.fb_host.assign(host, host + numel);
+      SDY_TRY(fold_bias());
+      return dev_upload(w.fb, host, numel);
+    }
+    if (rest == "inner_skip.weight") {
+      EXPECT_NUMEL((size_t)E * E);
+      if (fold) {
+        w.skw_host.assign(host, host + numel);
+        SDY_TRY(pack_folded());
+      }
+      return dev_upload_conv(w.skw, host, E, E, E, h3);
+    }
+    if (rest == "inner_skip.bias") {
+      EXPECT_NUMEL(E);
+      w.skb_host.assign(host, host + numel);
+      SDY_TRY(fold_bias());
+      return dev_upload(w.skb, host, numel);
+    }
     // fused MLP stream: (re)packed whenever both fc weights are known
     auto pack_mlp = [&]() -> int {
       if (!h3 || !sdy_mlp_h3_supported(E, H) || w.w1_host.empty() || w.w2_host.empty()) return SDY_OK;
@@ -1004,12 +1064,13 @@ namespace {
 enum SdyStage {
   ST_CONCAT, ST_TIME_MLP, ST_ENC0, ST_ENC2, ST_NORM_COEFFS, ST_FFT_FWD, ST_LEG_FWD, ST_LEG_INV, ST_FFT_INV, ST_DHCONV,
   ST_SKIP_CONV, ST_MLP_FUSED, ST_MLP_FUSED_DROP, ST_FC1, ST_FC2, ST_DEC0, ST_DEC2, ST_ENC_PAIR, ST_DEC_PAIR, ST_DROP_COPY,
-  ST_COUNT
+  ST_SKIP_GELU, ST_COUNT
 };
 const char* const kStageNames[ST_COUNT] = {
   "concat", "time_mlp", "encoder.0 conv", "encoder.2 conv", "instnorm coefficients", "rfft (lon)", "legendre analysis",
   "legendre synthesis", "irfft (lon)", "dhconv", "inner-skip conv", "mlp fused", "mlp fused (dropout)", "mlp fc1", "mlp fc2",
-  "decoder.0 conv", "decoder.2 conv", "encoder (fused pair)", "decoder (fused pair)", "drop-path copy"};
+  "decoder.0 conv", "decoder.2 conv", "encoder (fused pair)", "decoder (fused pair)", "drop-path copy",
+  "inner skip folded (gelu)"};
 // Single-threaded by contract (one host thread issues forwards while the switch is on); the mutex only keeps the record list
 // consistent against a concurrent sdy_profile_read.  Events come from a pool and are reused across reads.
 struct SdyProfiler {
@@ -1299,9 +1360,18 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
         SDY_STAGE(ST_DHCONV, sdy_dhconv_h3(Cs, bw.fw.h3, bw.fw.h3_scale, Cs2, c.lmax, pin->mtr, B, E, E, stream));
       else
         SDY_STAGE(ST_DHCONV, sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
+      // grid-changing block with the inner skip folded into the dhconv weights (skip_foldable): y = filter + skip + both biases
+      const bool folded = bw.skip_folded && scale_residual && bw.fw.frag && bw.fbs.set;
       SDY_STAGE_N(ST_LEG_INV, Bp, legendre_inv_impl(pout, Cs2, Xf, Bp, E, polar_out, stream, tiled_out, cs_tiled));
-      SDY_STAGE_N(ST_FFT_INV, Bp, sdy_fft_launch_inv(pout->fft, Xf, bw.fb.p, y, Bp, E, pout->nlat, pout->mtr, tiled_out ? 2 : ilv,
-                                                     polar_out ? pout->d_mcut : nullptr, stream));
+      SDY_STAGE_N(ST_FFT_INV, Bp, sdy_fft_launch_inv(pout->fft, Xf, folded ? bw.fbs.p : bw.fb.p, y, Bp, E, pout->nlat, pout->mtr,
+                                                     tiled_out ? 2 : ilv, polar_out ? pout->d_mcut : nullptr, stream));
+      if (folded) {
+        // x = GELU(y): the 256 -> 256 convolution has become a matrix addition at load time; norm1 statistics from this pass
+        float* zo = z_tiled ? ws + w.zt : y;
+        SDY_STAGE_N(ST_SKIP_GELU, Bp, sdy_gelu_stats_launch(y, (long)E * HW, zo, z_tiled ? zt_bs : (long)E * HW, z_tiled ? 1 : 0, st1,
+                                                           Bp, E, HW, stream));
+        SDY_STAGE_N(ST_NORM_COEFFS, Bp, sdy_instnorm_from_stats(st1, Bp, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+      } else {
       // x = GELU(y + inner_skip(residual))  (sfnonet.py:303-311), in place over y
       conv_reset();
       cv.B = Bp; cv.x_rows = lazy_norm ? rows : nullptr;   // (xn is in the launch's own row order)
@@ -1317,6 +1387,7 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
         SDY_STAGE_N(ST_NORM_COEFFS, Bp, sdy_instnorm_from_stats(st1, Bp, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
       else
         SDY_STAGE(ST_NORM_COEFFS, sdy_instnorm_coeffs_launch(y, B, E, HW, bw.n1w.p, bw.n1b.p, nullptr, 0, 1e-6f, ca1, cd1, stream));
+      }
     }
     // MLP (layers.py:73-80): fc1 + GELU + dropout
     const bool stats_next = fused_mlp && i < L - 1;   // the next block's norm0 statistics from this block's epilogue

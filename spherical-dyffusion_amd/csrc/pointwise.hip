@@ -143,6 +143,52 @@ __global__ __launch_bounds__(256) void affine_copy_stats_kernel(const float* __r
   }
 }
 
+// ---- GELU + InstanceNorm statistics (+ tile-major store) of one tensor ---------------------------------------------------
+// The block's `x = act(x + inner_skip(residual))` (sfnonet.py:303-311) where the inner skip has been FOLDED into the dhconv
+// weights (capi.hip: the grid-changing blocks, whose residual is itself an inverse transform of the same coefficients): what
+// the inverse FFT left in `y` already holds filter(x) + inner_skip(residual) + both biases, and the 256 -> 256 convolution
+// launch shrinks to this pass -- read y, exact-erf GELU, the norm1 statistics conv_h3's epilogue would have produced (fp32 per
+// 4-pixel quad, fp64 across quads), store in the layout the MLP reads (tile-major [64-pixel tile][C][64], or NCHW).
+// One workgroup per (channel, image): it is the one writer of its statistics slot.
+__global__ __launch_bounds__(256) void gelu_stats_kernel(const float* __restrict__ y, long y_bs, float* __restrict__ out,
+                                                          long out_bs, int out_tiled, double* __restrict__ stats, int C,
+                                                          int HW) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(y + (long)b * y_bs + (long)c * HW);
+  float* ob = out + (long)b * out_bs + (out_tiled ? (long)c * 64 : (long)c * HW);
+  const long tile_stride = (long)C * 64;
+  double s = 0.0, s2 = 0.0;
+  const int n4 = HW >> 2;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 r = p4[i];
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_exact(r[e]);
+    const int px = 4 * i;
+    float* o = out_tiled ? ob + (long)(px >> 6) * tile_stride + (px & 63) : ob + px;
+    *reinterpret_cast<f32x4*>(o) = v;
+    s += (double)sdy_quad_sum(v);
+    s2 += (double)sdy_quad_sumsq(v);
+  }
+  if (!stats) return;   // (uniform)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  __shared__ double sh[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[wave] = s;
+    sh[4 + wave] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // the one writer of this (image, channel): the caller zeroed the slot
+    stats[((long)b * C + c) * 2] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    stats[((long)b * C + c) * 2 + 1] += (sh[4] + sh[5]) + (sh[6] + sh[7]);
+  }
+}
+
 // ---- channel concat (torch.cat(dim=1)) ------------------------------------------------------------------
 struct ConcatArgs {
   const float* src[4];
@@ -818,6 +864,14 @@ extern "C" int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, cons
   SDY_TRY(sdy_flags_ptr(&flags));
   hipLaunchKernelGGL(instnorm_from_stats_kernel, dim3((BC + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, BC, C, HW,
                      gamma, beta, ss, ss_stride, eps, a, d, flags);
+  return sdy_launch_status();
+}
+
+int sdy_gelu_stats_launch(const float* y, long y_bs, float* out, long out_bs, int out_tiled, double* stats, int B, int C,
+                          int HW, hipStream_t stream) {
+  if (!y || !out || B <= 0 || C <= 0 || HW <= 0) return SDY_ERR_ARG;
+  if ((HW & 3) || (y_bs & 3) || (out_bs & 3)) return SDY_ERR_ALIGN;
+  hipLaunchKernelGGL(gelu_stats_kernel, dim3(C, B), dim3(256), 0, stream, y, y_bs, out, out_bs, out_tiled, stats, C, HW);
   return sdy_launch_status();
 }
 

@@ -600,7 +600,8 @@ def test_range_headroom_reports_the_distance_to_the_cliff(sdy):
         pass
     assert all(v == 0.0 for v in h2.max_staged.values()) and all(v == 0.0 for v in h3.max_staged.values())
     from sdy_amd import synthetic
-    net = synthetic.build_network(8, 6, 2, nlat=180, nlon=360, embed=256, layers=2, dropout_mlp=0.1, drop_path_rate=0.1,
+    # (three blocks: the inner skip of the first and the last one is folded into their dhconv weights, the middle one runs conv_h3)
+    net = synthetic.build_network(8, 6, 2, nlat=180, nlon=360, embed=256, layers=3, dropout_mlp=0.1, drop_path_rate=0.1,
                                   time_range=(0.0, 5.0))
     xin = torch.randn(2, 8, 180, 360, generator=g).cuda()
     cond = torch.randn(2, 2, 180, 360, generator=g).cuda()
