@@ -110,14 +110,14 @@ struct sdy_sht_plan {
 // SDY_NO_PAIR, SDY_NO_CONV_FRAG -- the paths they selected are still what other shapes take, and are tested there.)
 namespace {
 struct SdySwitches {
-  bool gemm_f32, no_fft360, no_leg_par, no_leg_frag, no_dh_frag, no_fused_mlp, no_drop_skip;
+  bool gemm_f32, no_fft360, no_leg_par, no_leg_frag, no_dh_frag, no_fused_mlp, no_drop_skip, no_skip_fold;
 };
 const SdySwitches& sw() {
   static const SdySwitches v = [] {
     auto on = [](const char* n) { return std::getenv(n) != nullptr; };
     const char* g = std::getenv("SDY_GEMM_MODE");
     return SdySwitches{g && std::string(g) == "f32", on("SDY_NO_FFT360"), on("SDY_NO_LEG_PAR"), on("SDY_NO_LEG_FRAG"),
-                       on("SDY_NO_DH_FRAG"), on("SDY_NO_FUSED_MLP"), on("SDY_NO_DROP_SKIP")};
+                       on("SDY_NO_DH_FRAG"), on("SDY_NO_FUSED_MLP"), on("SDY_NO_DROP_SKIP"), on("SDY_NO_SKIP_FOLD")};
   }();
   return v;
 }
@@ -624,7 +624,7 @@ static int spec_ilv(const sdy_sfno_config& c) { return (c.gemm_mode == 1 && c.em
 // on the dh_h3 path (split-fp16 mode, 256 channels); every other configuration runs the convolution as the reference does.
 static bool skip_foldable(const sdy_sfno_config& c, int i) {
   const bool first = i == 0, last = i == c.num_layers - 1;
-  return c.gemm_mode == 1 && c.data_grid != SDY_GRID_LEGENDRE_GAUSS && first != last && !std::getenv("SDY_NO_SKIP_FOLD");
+  return c.gemm_mode == 1 && c.data_grid != SDY_GRID_LEGENDRE_GAUSS && first != last && !sw().no_skip_fold;
 }
 
 struct sdy_sfno {
@@ -977,7 +977,7 @@ extern "C" const char* sdy_sfno_missing(const sdy_sfno* n) { return n ? n->missi
 
 namespace {
 struct WsLayout {
-  size_t cat, xa, xb, xe, xn, y, zt, hid, xf, cs, cs2, ca, cd, ca1, cd1, st0, st1, ste, ss, dp, trep, total;
+  size_t cat, xa, xb, xe, xn, y, zt, hid, xf, cs, cs2, ca, cd, ca1, cd1, st0, st1, ste, ss, dp, trep, sp, total;
 };
 WsLayout ws_layout(const sdy_sfno* n, int B) {
   const sdy_sfno_config& c = n->cfg;
@@ -1006,6 +1006,7 @@ WsLayout ws_layout(const sdy_sfno* n, int B) {
   w.ss = take((size_t)B * c.num_layers * 2 * E);
   w.dp = take((size_t)B * c.num_layers);
   w.trep = take((size_t)2 * B * (c.with_time_emb ? c.time_dim : 1));   // t_repr, then the time MLP's hidden layer
+  w.sp = take((size_t)B * E * c.nlat * 4);   // per-ring (sum, sumsq) doubles of a folded block's act output (fft360.hip)
   w.total = off;
   return w;
 }
@@ -1363,9 +1364,20 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       // grid-changing block with the inner skip folded into the dhconv weights (skip_foldable): y = filter + skip + both biases
       const bool folded = bw.skip_folded && scale_residual && bw.fw.frag && bw.fbs.set;
       SDY_STAGE_N(ST_LEG_INV, Bp, legendre_inv_impl(pout, Cs2, Xf, Bp, E, polar_out, stream, tiled_out, cs_tiled));
+      // ... and on the fft360 path with the tile-major conv -> MLP tensor the act itself rides on the inverse FFT's stores
+      // (GELU, tile-major layout, per-ring norm1 statistics): no pass over y at all
+      const bool act_in_fft = folded && tiled_out && z_tiled;
+      if (act_in_fft) {
+        double* part = reinterpret_cast<double*>(ws + w.sp);
+        SDY_STAGE_N(ST_FFT_INV, Bp, sdy_fft360_launch_inv(pout->fft, Xf, bw.fbs.p, nullptr, Bp, E, pout->nlat, pout->mtr, 2,
+                                                          polar_out ? pout->d_mcut : nullptr, stream, ws + w.zt, zt_bs, part));
+        SDY_STAGE_N(ST_NORM_COEFFS, Bp, sdy_instnorm_from_partials_launch(part, pout->nlat, Bp, E, HW, bw.n1w.p, bw.n1b.p, 1e-6f, ca1,
+                                                                          cd1, stream));
+      } else
       SDY_STAGE_N(ST_FFT_INV, Bp, sdy_fft_launch_inv(pout->fft, Xf, folded ? bw.fbs.p : bw.fb.p, y, Bp, E, pout->nlat, pout->mtr,
                                                      tiled_out ? 2 : ilv, polar_out ? pout->d_mcut : nullptr, stream));
-      if (folded) {
+      if (act_in_fft) {
+      } else if (folded) {
         // x = GELU(y): the 256 -> 256 convolution has become a matrix addition at load time; norm1 statistics from this pass
         float* zo = z_tiled ? ws + w.zt : y;
         SDY_STAGE_N(ST_SKIP_GELU, Bp, sdy_gelu_stats_launch(y, (long)E * HW, zo, z_tiled ? zt_bs : (long)E * HW, z_tiled ? 1 : 0, st1,

@@ -38,5 +38,10 @@ int sdy_fft_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, 
 int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, const float* d, float* xn_out, float* Xf,
                           int B, int C, int K, int mtr, int ilv, const int* mcut, hipStream_t stream,
                           const unsigned char* x_rows = nullptr, int x_mod = 0);
+// zt / part (both or neither; fft360 only): instead of y (B, C, K, nlon) the kernel stores GELU(ring + bias) TILE-MAJOR
+// ([b][64-pixel tile][C][64], zt_bs floats per image) and the ring's (sum, sum of squares) per channel into
+// part[b][k][c][2] (doubles, one writer per slot) -- the act + norm1 statistics of a block whose inner skip is folded into
+// its dhconv weights (capi.hip, skip_foldable)
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
-                          int mtr, int ilv, const int* mcut, hipStream_t stream);
+                          int mtr, int ilv, const int* mcut, hipStream_t stream, float* zt = nullptr, long zt_bs = 0,
+                          double* part = nullptr);

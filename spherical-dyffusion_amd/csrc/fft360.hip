@@ -345,7 +345,8 @@ template <int KPW>
 __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f, const float* __restrict__ Yf,
                                                             const float* __restrict__ bias, float* __restrict__ y, int B,
                                                             int C, int K, int mtr, int ilv,
-                                                            const int* __restrict__ mcut) {
+                                                            const int* __restrict__ mcut, float* __restrict__ zt,
+                                                            long zt_bs, double* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) c2 Z[ROWS * P];
   __shared__ c2 TW[TWN];
   __shared__ c2 PW[NH];       // exp(+2 pi i j / N)
@@ -427,12 +428,48 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
     pass_b<+1, false>(L);
 
     // ---- rows out: y[2j] = Re z[j], y[2j+1] = Im z[j]
+    if (zt) {
+      // Block with the inner skip folded into the dhconv (capi.hip, skip_foldable): the ring IS filter + skip + biases, so the
+      // block's `x = act(...)` (sfnonet.py:310-311) happens here -- GELU, the store in the MLP's tile-major layout
+      // [64-pixel tile][C][64] (a lane's four pixels never straddle a tile: 360 k and 4 lane are multiples of 4), and the
+      // ring's share of the norm1 statistics: fp32 per 4-pixel quad, fp64 across the wave, ONE writer per (image, channel,
+      // ring) slot -- no atomics, summed over the rings in a fixed order by instnorm_from_partials.
+      float* ztb = zt + (long)b * zt_bs;
+      const int px0 = k * NLON + 4 * L.lane, px1 = px0 + 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float bs = BS[4 * L.wave + r];
+        const int ch = c0 + L.wave + 4 * r;
+        f32x4 v = *reinterpret_cast<const f32x4*>(zw + r * P) + bs;
+        v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+        SDY_STREAM_STORE(ztb + (long)(px0 >> 6) * (C * 64) + ch * 64 + (px0 & 63), v);
+        double ds = (double)sdy_quad_sum(v), ds2 = (double)sdy_quad_sumsq(v);
+        if (tail) {
+          f32x4 u = *reinterpret_cast<const f32x4*>(zw + r * P + 128) + bs;
+          u = f32x4{gelu_erf(u.x), gelu_erf(u.y), gelu_erf(u.z), gelu_erf(u.w)};
+          SDY_STREAM_STORE(ztb + (long)(px1 >> 6) * (C * 64) + ch * 64 + (px1 & 63), u);
+          ds += (double)sdy_quad_sum(u);
+          ds2 += (double)sdy_quad_sumsq(u);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          ds += __shfl_down(ds, off, 64);
+          ds2 += __shfl_down(ds2, off, 64);
+        }
+        if (L.lane == 0) {
+          double* slot = part + (((long)b * K + k) * C + ch) * 2;   // [b][k][c]: the reader's threads (b, c) read coalesced
+          slot[0] = ds;
+          slot[1] = ds2;
+        }
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float bs = BS[4 * L.wave + r];
       float* dst = yw + r * rstride + (long)k * NLON;
       SDY_STREAM_STORE(dst, *reinterpret_cast<const f32x4*>(zw + r * P) + bs);
       if (tail) SDY_STREAM_STORE(dst + 256, *reinterpret_cast<const f32x4*>(zw + r * P + 128) + bs);
+    }
     }
     __syncthreads();   // the rows are rewritten by the next ring
   }
@@ -461,11 +498,12 @@ int sdy_fft360_launch_fwd(const SdyFftDesc& f, const float* x, const float* a, c
 }
 
 int sdy_fft360_launch_inv(const SdyFftDesc& f, const float* Yf, const float* bias, float* y, int B, int C, int K,
-                          int mtr, int ilv, const int* mcut, hipStream_t stream) {
+                          int mtr, int ilv, const int* mcut, hipStream_t stream, float* zt, long zt_bs, double* part) {
   if (f.n != NH || C % ROWS != 0 || mtr > NH + 1 || (long)ROWS * K * NLON >= (1L << 31)) return SDY_ERR_UNSUPPORTED;
   if (ilv == 2 && (C % (2 * ROWS) != 0 || ROWS != 16)) return SDY_ERR_UNSUPPORTED;   // a 64-column tile = two channel blocks
+  if ((zt == nullptr) != (part == nullptr) || (!zt && !y)) return SDY_ERR_ARG;
   constexpr int KPW = SDY_FFT_KPW;
   dim3 grid((C / ROWS) * ((K + KPW - 1) / KPW) * B);
-  hipLaunchKernelGGL((irfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, Yf, bias, y, B, C, K, mtr, ilv, mcut);
+  hipLaunchKernelGGL((irfft360_kernel<KPW>), grid, dim3(NT), 0, stream, f, Yf, bias, y, B, C, K, mtr, ilv, mcut, zt, zt_bs, part);
   return sdy_launch_status();
 }

@@ -29,6 +29,9 @@ int sdy_time_mlp_launch(const SdyTimeMlp& t, const float* time, int B, float* tr
                         uint32_t batch_offset, int rows_per_call, hipStream_t stream, float* scratch);
 int sdy_spec_to_torch_launch(const float* Cs, float* out, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);
 int sdy_torch_to_spec_launch(const float* in, float* Cs, int B, int C, int L, int mtr, int Mfull, hipStream_t stream);
+// InstanceNorm coefficients (no time scale / shift) from per-ring partial statistics part[b][k][c][2] (fft360.hip's act epilogue)
+int sdy_instnorm_from_partials_launch(const double* part, int K, int B, int C, int HW, const float* gamma, const float* beta,
+                                      float eps, float* a, float* d, hipStream_t stream);
 // out = GELU(y) (exact erf), B images of C channels; `stats` (dev double [B][C][2], zeroed by the caller, or null) receives the
 // (sum, sum of squares) of what is stored; out_tiled: [b][64-pixel tile][C][64] with out_bs floats per image, else NCHW
 int sdy_gelu_stats_launch(const float* y, long y_bs, float* out, long out_bs, int out_tiled, double* stats, int B, int C,

@@ -96,6 +96,32 @@ __global__ __launch_bounds__(256) void instnorm_from_stats_kernel(double* __rest
   d_out[i] = d;
 }
 
+// The same from PARTIAL statistics with one writer per slot: part[b][k][c] = (sum, sumsq) of ring k (the inverse FFT's fused
+// act epilogue, fft360.hip), summed here in the order of k -- no atomics anywhere, bit-reproducible coefficients.
+__global__ __launch_bounds__(256) void instnorm_from_partials_kernel(const double* __restrict__ part, int K, int BC, int C, int HW,
+                                                                      const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta, float eps,
+                                                                      float* __restrict__ a_out, float* __restrict__ d_out,
+                                                                      unsigned* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= BC) return;
+  const int b = i / C, c = i - b * C;
+  const double* q = part + ((long)b * K * C + c) * 2;
+  double S = 0.0, S2 = 0.0;
+  for (int k = 0; k < K; ++k) {
+    S += q[(long)k * C * 2];
+    S2 += q[(long)k * C * 2 + 1];
+  }
+  if (flags && !(fabs(S) <= 1.7e308 && S2 <= 1.7e308)) atomicOr(flags, (unsigned)SDY_FLAG_NONFINITE);   // inf or NaN
+  const double mean = S / HW;
+  double var = S2 / HW - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float a = gamma[c] * rstd;
+  a_out[i] = a;
+  d_out[i] = beta[c] - (float)mean * a;
+}
+
 // ---- drop-path skip: the block output of a trajectory whose branch DropPath zeroed ------------------------------------
 // The block computes  out = drop_path(mlp(...)) + residual  with residual = norm0(x) (+ time scale / shift) = a x + d
 // (src/models/sfno/sfnonet.py:289-337, src/models/modules/drop_path.py:15-22); for a dropped trajectory that is
@@ -864,6 +890,17 @@ extern "C" int sdy_instnorm_from_stats(double* stats, int B, int C, int HW, cons
   SDY_TRY(sdy_flags_ptr(&flags));
   hipLaunchKernelGGL(instnorm_from_stats_kernel, dim3((BC + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, BC, C, HW,
                      gamma, beta, ss, ss_stride, eps, a, d, flags);
+  return sdy_launch_status();
+}
+
+int sdy_instnorm_from_partials_launch(const double* part, int K, int B, int C, int HW, const float* gamma, const float* beta,
+                                      float eps, float* a, float* d, hipStream_t stream) {
+  if (!part || !gamma || !beta || !a || !d || K <= 0 || B <= 0 || C <= 0 || HW <= 0) return SDY_ERR_ARG;
+  const int BC = B * C;
+  unsigned* flags = nullptr;
+  SDY_TRY(sdy_flags_ptr(&flags));
+  hipLaunchKernelGGL(instnorm_from_partials_kernel, dim3((BC + 255) / 256), dim3(256), 0, stream, part, K, BC, C, HW, gamma, beta, eps,
+                     a, d, flags);
   return sdy_launch_status();
 }
 

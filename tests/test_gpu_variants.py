@@ -13,7 +13,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (retired with their questions settled, round 6: SDY_NO_CONV_FRAG, SDY_NO_FUSED_STATS, SDY_NO_POLAR_SKIP, SDY_NO_PAIR -- the paths
 #  they selected remain what other shapes take and are held to the oracle there, tests/test_gpu_sfno.py, test_gpu_golden.py)
-VARIANTS = ["SDY_NO_DH_FRAG", "SDY_NO_FFT360", "SDY_NO_FUSED_MLP", "SDY_NO_LEG_FRAG", "SDY_NO_LEG_PAR"]
+# SDY_NO_SKIP_FOLD: the first / last block's inner skip as the reference computes it (a convolution of the residual) instead of
+# folded into the dhconv weights -- the two agree to rounding, which this test holds them to
+VARIANTS = ["SDY_NO_DH_FRAG", "SDY_NO_FFT360", "SDY_NO_FUSED_MLP", "SDY_NO_LEG_FRAG", "SDY_NO_LEG_PAR", "SDY_NO_SKIP_FOLD"]
 TOL = 2e-5
 
 
