@@ -1362,7 +1362,9 @@ extern "C" int sdy_sfno_forward(sdy_sfno* n, const sdy_sfno_fwd_args* a, void* s
       else
         SDY_STAGE(ST_DHCONV, sdy_dhconv(Cs, bw.fw.p, Cs2, c.lmax, pin->mtr, B, E, E, stream));
       // grid-changing block with the inner skip folded into the dhconv weights (skip_foldable): y = filter + skip + both biases
-      const bool folded = bw.skip_folded && scale_residual && bw.fw.frag && bw.fbs.set;
+      // (the packed dhconv stream of such a block HOLDS the skip: running the convolution as well would count it twice)
+      if (bw.skip_folded && !(scale_residual && bw.fw.frag && bw.fbs.set)) return SDY_ERR_STATE;
+      const bool folded = bw.skip_folded;
       SDY_STAGE_N(ST_LEG_INV, Bp, legendre_inv_impl(pout, Cs2, Xf, Bp, E, polar_out, stream, tiled_out, cs_tiled));
       // ... and on the fft360 path with the tile-major conv -> MLP tensor the act itself rides on the inverse FFT's stores
       // (GELU, tile-major layout, per-ring norm1 statistics): no pass over y at all
