@@ -500,14 +500,20 @@ def run_inference(aggregator, stepper, data, n_forward_steps: int, forward_steps
                 if i in runner.pending_windows():
                     retained[i] = (window, win, last_step)
                 last_step = {k: v[:, -1].clone() for k, v in win.items()}
+                t_relay = time.time()
                 runner.after_window(i)
-                keep = runner.pending_windows()
+                timers["relay_host"] += time.time() - t_relay      # (host time of the hosted relay windows; the device time
+                keep = runner.pending_windows()                     #  of their batches is part of run_on_batch)
                 for w in [w for w in retained if w not in keep]:
                     del retained[w]
+                now += time.time() - t_relay
             timers["writer_and_aggregator"] += time.time() - now
             now = time.time()
         if runner is not None:
+            t_relay = time.time()
             runner.drain(n_windows - 1)
+            timers["relay_host"] += time.time() - t_relay
+            now += time.time() - t_relay
             timers["relay_recv_wait"] = getattr(runner.comm, "recv_wait_s", 0.0)
         while pending:
             flush(pending.pop(0))
