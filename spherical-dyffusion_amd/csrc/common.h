@@ -150,6 +150,18 @@ __device__ __forceinline__ float sdy_quad_sum(f32x4 v) { return (v.x + v.y) + (v
 __device__ __forceinline__ float sdy_quad_sumsq(f32x4 v) {
   return __builtin_fmaf(v.x, v.x, v.y * v.y) + __builtin_fmaf(v.z, v.z, v.w * v.w);
 }
+// sum over the 16 lanes of a DPP row (all of them end up with the total)
+__device__ __forceinline__ float row16_sum(float x) {
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  x += dpp(x, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  x += dpp(x, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  x += dpp(x, std::integral_constant<int, 0x140>{});   // row_mirror
+  return x;
+}
+
 // MEASUREMENT BUILDS ONLY (csrc/Makefile EXTRA=-DSDY_H3_PASSES=1): drop the two cross terms Ah.Bl + Al.Bh of every
 // split-precision product, i.e. single-pass f16 MFMA arithmetic (fp16-class accuracy: ~1e-3) with everything else -- the
 // hi / lo splits, the loads of the lo fragments, the schedules -- unchanged.  Bounds what the three passes cost and gives the

@@ -81,18 +81,6 @@ __device__ __forceinline__ int cv_swz(int px) { return (px & 15) ^ (((px >> 4) &
 template <int KROW>
 __device__ __forceinline__ int cv_off(int px, int c) { return px * KROW + (((c & ~15) | ((c ^ cv_swz(px)) & 15)) << 3); }
 
-// sum over the 16 lanes of a DPP row (all of them end up with the total)
-__device__ __forceinline__ float row16_sum(float x) {
-  auto dpp = [](float v, auto ctrl) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
-  };
-  x += dpp(x, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
-  x += dpp(x, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
-  x += dpp(x, std::integral_constant<int, 0x141>{});   // row_half_mirror
-  x += dpp(x, std::integral_constant<int, 0x140>{});   // row_mirror
-  return x;
-}
-
 // KBLK = ceil(Cin / 64): k-blocks of 4 k-steps actually streamed (4 for the block's 256 -> 256 convs, 2 / 3 for the
 // encoders, 6 for the decoder)
 template <int KBLK, int NW>

@@ -443,19 +443,20 @@ __global__ __launch_bounds__(NT, MINB_I) void irfft360_kernel(const SdyFftDesc f
         f32x4 v = *reinterpret_cast<const f32x4*>(zw + r * P) + bs;
         v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
         SDY_STREAM_STORE(ztb + (long)(px0 >> 6) * (C * 64) + ch * 64 + (px0 & 63), v);
-        double ds = (double)sdy_quad_sum(v), ds2 = (double)sdy_quad_sumsq(v);
+        float qs = sdy_quad_sum(v), qs2 = sdy_quad_sumsq(v);
         if (tail) {
           f32x4 u = *reinterpret_cast<const f32x4*>(zw + r * P + 128) + bs;
           u = f32x4{gelu_erf(u.x), gelu_erf(u.y), gelu_erf(u.z), gelu_erf(u.w)};
           SDY_STREAM_STORE(ztb + (long)(px1 >> 6) * (C * 64) + ch * 64 + (px1 & 63), u);
-          ds += (double)sdy_quad_sum(u);
-          ds2 += (double)sdy_quad_sumsq(u);
+          qs += sdy_quad_sum(u);
+          qs2 += sdy_quad_sumsq(u);
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          ds += __shfl_down(ds, off, 64);
-          ds2 += __shfl_down(ds2, off, 64);
-        }
+        // fp32 over the 16 lanes of a DPP row (<= 128 values, as conv_h3 does), fp64 across the wave's four rows
+        double ds = (double)row16_sum(qs), ds2 = (double)row16_sum(qs2);
+        ds += __shfl_xor(ds, 16, 64);
+        ds2 += __shfl_xor(ds2, 16, 64);
+        ds += __shfl_xor(ds, 32, 64);
+        ds2 += __shfl_xor(ds2, 32, 64);
         if (L.lane == 0) {
           double* slot = part + (((long)b * K + k) * C + ch) * 2;   // [b][k][c]: the reader's threads (b, c) read coalesced
           slot[0] = ds;
