@@ -32,6 +32,32 @@ def _build(layers, seed_i=1000):
     return exp, fnet, inet, fora, iora, icfg
 
 
+def test_production_forward_takes_the_fused_paths():
+    """Which kernels a production-shape forward (180 x 360, E = 256, equiangular data grid, dropout on) actually launches, by the
+    stage timer -- so that a silent fall-back to a slower path cannot pass as parity: the first and last block's inner skip is
+    folded into their dhconv weights (4 of 4 middle blocks launch the skip convolution, the GELU rides on the inverse FFT: no
+    pass of its own), the MLP is the fused kernel, encoder and decoder one launch each, every block on dh_h3 / leg_par / fft360."""
+    import sdy_amd
+
+    layers = 6
+    exp, fnet, inet, _, _, _ = _build(layers)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(2, 2 * C_STATE, NLAT, NLON, generator=g).cuda()
+    c = torch.randn(2, C_FORC, NLAT, NLON, generator=g).cuda()
+    inet.enable_inference_dropout()
+    with sdy_amd.ops.stage_timer() as t:
+        y = inet(x, time=torch.tensor([2.0, 4.0]).cuda(), static_condition=c)
+    inet.disable_inference_dropout()
+    assert torch.isfinite(y).all()
+    n = {k: v[0] for k, v in t.stages.items()}
+    assert n.get("inner-skip conv") == layers - 2 and "inner skip folded (gelu)" not in n
+    assert n.get("mlp fused (dropout)") == layers and "mlp fc1" not in n and "mlp fc2" not in n
+    assert n.get("encoder (fused pair)") == 1 and n.get("decoder (fused pair)") == 1
+    assert n.get("dhconv") == layers and n.get("rfft (lon)") == layers
+    assert n.get("legendre synthesis") == layers + 2 and n.get("irfft (lon)") == layers + 2      # + the two residual resamplings
+    assert n.get("legendre analysis") == layers
+
+
 @pytest.mark.parametrize("layers", [2, 8])
 def test_c3_full_size_sampling_pass_with_dropout_vs_oracle(layers):
     """BASELINE.json configs[2]: one horizon-6 DYffusion sampling pass, 180x360, E = 256, B = 1, interpolator dropout and
